@@ -1,0 +1,166 @@
+"""ctypes bindings used by the tests only: the compiled reference (oracle/_ref/libminiprot_ref.so,
+built from /root/reference by oracle/Makefile) and our C restatement (oracle/libmporacle.so).
+
+Nothing here is imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libminiprot_ref.so")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "miniprot")
+ORA_SO = os.path.join(ORACLE_DIR, "libmporacle.so")
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+# ---------------------------------------------------------------- reference structs (nasw.h:62-80)
+class NsOpt(C.Structure):
+    _fields_ = [("flag", C.c_int32), ("go", C.c_int32), ("ge", C.c_int32), ("io", C.c_int32), ("fs", C.c_int32),
+                ("xdrop", C.c_int32), ("end_bonus", C.c_int32), ("asize", C.c_int32), ("sp", C.c_int32 * 6),
+                ("sp_null_bonus", C.c_int32), ("ie_coef", C.c_float), ("sc", C.c_void_p), ("nt4", C.c_void_p),
+                ("aa20", C.c_void_p), ("codon", C.c_void_p)]
+
+
+class NsRst(C.Structure):
+    _fields_ = [("n_cigar", C.c_int32), ("m_cigar", C.c_int32), ("nt_len", C.c_int32), ("aa_len", C.c_int32),
+                ("score", C.c_int32), ("cigar", C.POINTER(C.c_uint32))]
+
+
+class MpoOpt(C.Structure):
+    _fields_ = [("flag", C.c_int32), ("go", C.c_int32), ("ge", C.c_int32), ("io", C.c_int32), ("fs", C.c_int32),
+                ("xdrop", C.c_int32), ("end_bonus", C.c_int32), ("sp", C.c_int32 * 6), ("sp_null_bonus", C.c_int32),
+                ("ie_coef", C.c_float), ("mat", C.c_void_p), ("codon", C.c_void_p)]
+
+
+class MpoRst(C.Structure):
+    _fields_ = [("nt_len", C.c_int32), ("aa_len", C.c_int32), ("score", C.c_int32), ("n_cigar", C.c_int32),
+                ("m_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint32))]
+
+
+_ref = None
+_ora = None
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        _ref.ns_make_tables(1)
+        _ref.ns_global_gs16b.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                         C.POINTER(NsOpt), C.c_void_p, C.POINTER(NsRst)]
+        _ref.ns_global_gs16b.restype = None
+        _ref.mp_chain.restype = C.c_void_p
+        _ref.mp_chain.argtypes = [C.c_int32] * 7 + [C.c_float] + [C.c_int32] * 3 + [C.c_int64, C.c_void_p,
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_void_p]
+    return _ref
+
+
+def ora():
+    global _ora
+    if _ora is None:
+        if not os.path.exists(ORA_SO):
+            build_oracle()
+        _ora = C.CDLL(ORA_SO)
+        _ora.mpo_nasw.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(MpoOpt), C.c_void_p,
+                                  C.POINTER(MpoRst)]
+        _ora.mpo_nasw.restype = None
+        _ora.mpo_chain.restype = C.c_int32
+        _ora.mpo_chain.argtypes = [C.c_int32] * 7 + [C.c_float] + [C.c_int32] * 3 + [C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_int64)]
+        _ora.mpo_sketch_prot.restype = C.c_int64
+        _ora.mpo_sketch_prot.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _ora.mpo_sketch_nt4.restype = C.c_int64
+        _ora.mpo_sketch_nt4.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                        C.c_void_p, C.c_int64]
+        _ora.mpo_comput_sc.restype = C.c_int32
+        _ora.mpo_comput_sc.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                       C.c_int32, C.c_int32]
+        _ora.mpo_radix_sort64.argtypes = [C.c_void_p, C.c_void_p]
+        _ora.mpo_radix_sort128x.argtypes = [C.c_void_p, C.c_void_p]
+    return _ora
+
+
+# ---------------------------------------------------------------- shared DP parameter record
+class DpParams:
+    """The scalar parameters of one DP call, in miniprot's mapping defaults (options.c:72-85,
+    align.c:50-60) unless overridden."""
+
+    def __init__(self, mat, go=11, ge=1, io=29, fs=23, xdrop=100, end_bonus=5, sp=(8, 15, 21, 30, 0, 0),
+                 sp_null_bonus=-7, ie_coef=0.5):
+        self.mat = np.ascontiguousarray(mat, dtype=np.int8)
+        self.go, self.ge, self.io, self.fs = go, ge, io, fs
+        self.xdrop, self.end_bonus, self.sp, self.sp_null_bonus, self.ie_coef = xdrop, end_bonus, tuple(sp), sp_null_bonus, ie_coef
+
+
+def mapping_matrix(fs=23):
+    """BLOSUM62 over ARNDCQEGHILKMFPSTWYV*X with the stop row/column set to -fs
+    (options.c:84-85 + nasw-tab.c:149-156), taken from the reference when it is present, otherwise
+    from the product's own copy of the table."""
+    if have_ref():
+        m = (C.c_int8 * 484).in_dll(ref(), "ns_mat_blosum62")
+        mat = np.frombuffer(m, dtype=np.int8).copy().reshape(22, 22)
+    else:
+        from miniprot_amd import tables
+        mat = tables.blosum62().copy()
+    sc = mat[20, 20]
+    mat[20, :] = -fs
+    mat[:, 20] = -fs
+    mat[20, 20] = sc
+    return mat
+
+
+def cigar_str(cig):
+    ops = "MIDNSHP=XBFGUVE"
+    return "".join("%d%s" % (c >> 4, ops[c & 0xf]) for c in cig)
+
+
+def ref_nasw(nt, aa, P, flag, ss=None):
+    """nt: bytes of 0..4 codes; aa: ASCII bytes.  Returns (nt_len, aa_len, score, cigar list)."""
+    r = ref()
+    o = NsOpt()
+    o.flag, o.go, o.ge, o.io, o.fs, o.xdrop, o.end_bonus, o.asize = flag, P.go, P.ge, P.io, P.fs, P.xdrop, P.end_bonus, 22
+    for i in range(6):
+        o.sp[i] = P.sp[i]
+    o.sp_null_bonus, o.ie_coef = P.sp_null_bonus, P.ie_coef
+    o.sc = P.mat.ctypes.data
+    o.nt4 = C.addressof((C.c_uint8 * 256).in_dll(r, "ns_tab_nt4"))
+    o.aa20 = C.addressof((C.c_uint8 * 256).in_dll(r, "ns_tab_aa20"))
+    o.codon = C.addressof((C.c_uint8 * 64).in_dll(r, "ns_tab_codon"))
+    rst = NsRst()
+    ssp = None if ss is None else C.cast(C.c_char_p(bytes(ss)), C.c_void_p)
+    r.ns_global_gs16b(None, bytes(nt), len(nt), bytes(aa), len(aa), C.byref(o), ssp, C.byref(rst))
+    cig = [rst.cigar[i] for i in range(rst.n_cigar)]
+    if rst.n_cigar or rst.cigar:
+        _libc.free(rst.cigar)
+    return rst.nt_len, rst.aa_len, rst.score, cig
+
+
+def ora_nasw(nt, aa, P, flag, ss=None):
+    o = MpoOpt()
+    o.flag, o.go, o.ge, o.io, o.fs, o.xdrop, o.end_bonus = flag, P.go, P.ge, P.io, P.fs, P.xdrop, P.end_bonus
+    for i in range(6):
+        o.sp[i] = P.sp[i]
+    o.sp_null_bonus, o.ie_coef = P.sp_null_bonus, P.ie_coef
+    o.mat = P.mat.ctypes.data
+    o.codon = None
+    rst = MpoRst()
+    ssp = None if ss is None else C.cast(C.c_char_p(bytes(ss)), C.c_void_p)
+    ora().mpo_nasw(bytes(nt), len(nt), bytes(aa), len(aa), C.byref(o), ssp, C.byref(rst))
+    cig = [rst.cigar[i] for i in range(rst.n_cigar)]
+    if rst.cigar:
+        _libc.free(rst.cigar)
+    return rst.nt_len, rst.aa_len, rst.score, cig
