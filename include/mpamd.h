@@ -1,0 +1,210 @@
+/* mpamd.h -- C ABI of the MI355X-native miniprot hot path (libmpamd.so).
+ *
+ * Plain C, plain pointers and sizes; no torch types.  Every entry point cites the interface of the
+ * reference (lh3/miniprot v0.18-r281) that it replaces.  INTEGRATION.md shows the few lines a
+ * miniprot maintainer adds to map.c / align.c to call these instead of the pthread + SSE path.
+ *
+ * Two boundaries, as in the reference:
+ *   #2 operator level  -- mpa_dp_run():     a BATCH of ns_global_gs16b() calls  (nasw.h:135)
+ *   #1 library level   -- mpa_map_batch():  a BATCH of mp_map() calls           (miniprot.h:268, map.c:264-271)
+ *                         mpa_idx_restore(): mp_idx_restore()                    (miniprot.h:232, index.c:204)
+ *                         mpa_format_paf():  mp_write_output() PAF branch        (format.c:333-358,453)
+ *
+ * The DP, the per-row splice/codon preparation and the traceback run on the GPU.  There is NO CPU
+ * fallback: if no HIP device is usable every compute entry point returns MPA_ERR_NO_DEVICE.
+ *
+ * For CPU-only testing of the HOST logic the library-level path is also exposed as an explicit stage
+ * machine (mpa_batch_*): the caller pulls DP tasks, executes them with any executor and pushes the
+ * results back.  mpa_map_batch() is exactly that loop with mpa_dp_run() as the executor.
+ */
+#ifndef MPAMD_H
+#define MPAMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPA_OK               0
+#define MPA_ERR_NO_DEVICE   (-1)   /* no usable HIP device / kernels missing */
+#define MPA_ERR_HIP         (-2)   /* a HIP runtime call failed (message via mpa_last_error) */
+#define MPA_ERR_UNSUPPORTED (-3)   /* parameters outside what the kernels implement exactly */
+#define MPA_ERR_IO          (-4)
+#define MPA_ERR_ARG         (-5)
+
+/* DP flags = NS_F_* (nasw.h:48-50) */
+#define MPA_F_CIGAR      0x1
+#define MPA_F_EXT_LEFT   0x2
+#define MPA_F_EXT_RIGHT  0x4
+
+/* mapping flags = MP_F_* (miniprot.h:8-17) */
+#define MPA_MF_NO_SPLICE    0x1
+#define MPA_MF_NO_ALIGN     0x2
+#define MPA_MF_SHOW_UNMAP   0x4
+#define MPA_MF_NO_PRE_CHAIN 0x40
+#define MPA_MF_NO_CS        0x200
+
+/* ---- options: field-for-field mirrors of mp_idxopt_t / mp_mapopt_t (miniprot.h:36-77) ---------- */
+typedef struct {
+	int32_t bbit, min_aa_len, kmer, mod_bit;
+	uint32_t trans_code;
+} mpa_idxopt_t;                               /* also the .mpi header record, index.c:196 */
+
+typedef struct {
+	uint32_t flag;
+	int64_t mini_batch_size;
+	int32_t max_occ, max_gap, max_intron, min_max_intron, max_max_intron, bw, max_ext, max_ava;
+	int32_t min_chn_cnt, max_chn_max_skip, max_chn_iter, min_chn_sc;
+	float chn_coef_log, mask_level;
+	int32_t mask_len;
+	float pri_ratio, out_sim, out_cov;
+	int32_t best_n, out_n, kmer2;
+	int32_t go, ge, io, fs, io_end;
+	float ie_coef;
+	int32_t sp_model, sp_null_bonus, sp_max_bonus;
+	float sp_scale;
+	int32_t xdrop, end_bonus, asize, gff_delim, max_intron_flank;
+	const char *gff_prefix;
+	int8_t mat[484];
+} mpa_mapopt_t;
+
+void mpa_idxopt_init(mpa_idxopt_t *io);                         /* mp_idxopt_init, options.c:10 */
+void mpa_mapopt_init(mpa_mapopt_t *mo);                         /* mp_mapopt_init, options.c:42 */
+void mpa_mapopt_set_fs(mpa_mapopt_t *mo, int32_t fs);           /* mp_mapopt_set_fs, options.c:24 */
+void mpa_mapopt_set_max_intron(mpa_mapopt_t *mo, int64_t gsize);/* mp_mapopt_set_max_intron, options.c:31 */
+
+/* ---- device context -------------------------------------------------------------------------------- */
+typedef struct mpa_ctx_s mpa_ctx_t;
+/* device = HIP ordinal.  Returns NULL (and sets mpa_last_error) when there is no usable device. */
+mpa_ctx_t *mpa_ctx_create(int device);
+void mpa_ctx_destroy(mpa_ctx_t *ctx);
+const char *mpa_last_error(void);
+int mpa_device_count(void);
+
+/* ---- index: mp_idx_t (miniprot.h:100-106) loaded from a .mpi file (index.c:189-229) ----------------- */
+typedef struct mpa_idx_s mpa_idx_t;
+mpa_idx_t *mpa_idx_restore(const char *fn);                     /* mp_idx_restore, index.c:204 */
+/* genome-only index from nt4 codes (A0 C1 G2 T3 N4) held in memory, contigs concatenated; no k-mer table */
+mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4);
+int mpa_idx_dump(const char *fn, const mpa_idx_t *mi);          /* mp_idx_dump, index.c:189: byte-identical file */
+void mpa_idx_destroy(mpa_idx_t *mi);
+int32_t mpa_idx_n_ctg(const mpa_idx_t *mi);
+int64_t mpa_idx_ctg_len(const mpa_idx_t *mi, int32_t cid);
+const char *mpa_idx_ctg_name(const mpa_idx_t *mi, int32_t cid);
+int64_t mpa_idx_genome_len(const mpa_idx_t *mi);                /* nt->l_seq */
+const mpa_idxopt_t *mpa_idx_opt(const mpa_idx_t *mi);
+/* mp_ntseq_get_by_v (ntseq.c:108-114): nt4 codes of [st,en) on strand-oriented contig vid=cid<<1|rev */
+int64_t mpa_idx_get_nt(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out);
+/* upload the packed genome (and later the k-mer index) to the context's device; idempotent */
+int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi);
+
+/* ---- boundary #2: batched spliced DP ------------------------------------------------------------------- */
+/* Scalar parameters of ns_opt_t (nasw.h:62-73).  io is per task (io vs io_end, align.c:292,326). */
+typedef struct {
+	int32_t go, ge, fs, xdrop, end_bonus;
+	int32_t sp[6];                  /* already scaled (align.c:59) */
+	float ie_coef;
+	int8_t mat[484];
+} mpa_dpopt_t;
+void mpa_dpopt_from_mapopt(const mpa_mapopt_t *mo, mpa_dpopt_t *dp);  /* mp_map2ns_opt, align.c:50-60 */
+
+/* One ns_global_gs16b() call (nasw.h:135).  The nucleotide side is a window of the device-resident
+ * genome, the protein side a slice of a query of the batch. */
+typedef struct {
+	int64_t nt_off;                 /* window start, strand-local coordinate on vid */
+	int32_t vid;                    /* contig<<1 | strand */
+	int32_t nl;                     /* rows (window length) */
+	int32_t qid;                    /* which query of the batch */
+	int32_t aa_off, al;             /* protein slice */
+	int32_t flag;                   /* MPA_F_* */
+	int32_t io;                     /* intron-open penalty of this call */
+	int32_t tag;                    /* opaque to the executor */
+} mpa_dp_task_t;
+
+/* ns_rst_t (nasw.h:75-80); the CIGAR lives in a shared pool at [cigar_off, cigar_off+n_cigar) */
+typedef struct {
+	int32_t nt_len, aa_len, score, n_cigar;
+	int64_t cigar_off;
+} mpa_dp_rst_t;
+
+/* Queries of a batch as one concatenated ASCII buffer: query q = seqs[q_off[q] .. q_off[q+1]). */
+typedef struct {
+	int32_t n_seq;
+	const char *seqs;
+	const int64_t *q_off;           /* n_seq+1 entries */
+} mpa_qbatch_t;
+
+/* Run n DP calls on the GPU.  rst[n] is filled; *cigar_pool receives a malloc'd pool (caller frees with
+ * mpa_free) holding every CIGAR as len<<4|op words (nasw.h:33-44).  The index must be on the device. */
+int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
+               int64_t n, const mpa_dp_task_t *tasks, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool);
+void mpa_free(void *p);
+
+/* Statistics of the last mpa_dp_run() on this context (for bench.py's roofline record). */
+typedef struct {
+	int64_t n_ext, n_glob;          /* calls by mode */
+	int64_t cells_ext, cells_glob;  /* padded DP cells (nl-2) * 8*ceil(al/8), SURVEY.md 8(d) */
+	int64_t rows_prep;              /* rows of per-row records produced by the prep kernel */
+	int64_t alg_bytes_ext, alg_bytes_glob; /* algorithmic HBM bytes, SURVEY.md 8(d) */
+	double ms_prep, ms_ext, ms_glob, ms_backtrack, ms_total; /* HIP-event timings on the context's stream */
+	int32_t launches_ext, launches_glob;
+} mpa_dp_stats_t;
+void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
+
+/* ---- boundary #1: batched mp_map() ------------------------------------------------------------------------ */
+/* mp_feat_t / mp_extra_t / mp_reg1_t (miniprot.h:108-145) flattened for a C ABI */
+typedef struct {
+	int64_t vs, ve;
+	int32_t qs, qe;
+	int16_t type, phase;
+	int32_t n_fs, n_stop, score, n_iden, blen;
+	char donor[2], acceptor[2];
+} mpa_feat_t;
+
+typedef struct {
+	int32_t qid;                    /* query index within the batch */
+	int32_t id, parent, n_sub, subsc, cnt;
+	int32_t n_exon, chn_sc, chn_sc_ungap;
+	uint32_t vid;
+	int32_t qs, qe;
+	int64_t vs, ve;
+	int32_t has_aln;                /* r->p != NULL */
+	int32_t dp_score, dp_max, dp_max2, blen, n_fs, n_stop, dist_stop, dist_start, n_iden, n_plus;
+	int32_t n_cigar, n_feat;
+	int64_t cigar_off, feat_off;    /* into the result's cigar / feat pools */
+} mpa_hit_t;
+
+typedef struct mpa_result_s mpa_result_t;
+int64_t mpa_result_n_hit(const mpa_result_t *r);
+const mpa_hit_t *mpa_result_hits(const mpa_result_t *r);       /* grouped by qid ascending, in mp_map()'s order */
+const int64_t *mpa_result_hit_off(const mpa_result_t *r);      /* n_seq+1 offsets into hits[] */
+const uint32_t *mpa_result_cigars(const mpa_result_t *r);
+const mpa_feat_t *mpa_result_feats(const mpa_result_t *r);
+void mpa_result_destroy(mpa_result_t *r);
+
+/* The batched replacement of kt_for(worker_for) (map.c:264-271,291): maps every query of the batch.
+ * n_threads host threads run the non-DP stages; the DP runs on ctx's GPU. */
+int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q,
+                  int n_threads, mpa_result_t **out);
+
+/* The same computation as an explicit stage machine (used by mpa_map_batch itself). */
+typedef struct mpa_batch_s mpa_batch_t;
+mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads);
+/* Returns the DP tasks of the next round (0 when mapping is complete); the array stays owned by the batch. */
+int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpopt_t *opt);
+int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool);
+mpa_result_t *mpa_batch_finish(mpa_batch_t *b);                 /* destroys the batch */
+
+/* mp_write_output() for PAF (format.c:333-358, 453-473) + the output filters of map.c:298-311.
+ * Appends the text of all queries of the batch to a malloc'd buffer (caller frees with mpa_free).
+ * names[q] is the query name.  Returns the byte count. */
+int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                       const mpa_result_t *r, char **out);
+
+const char *mpa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,250 @@
+"""miniprot_amd -- Python view of libmpamd.so, the MI355X-native drop-in for miniprot's hot path.
+
+This module is plumbing only: it loads the C-ABI library (include/mpamd.h) with ctypes and offers thin
+helpers for the tests and bench.py.  All compute lives in miniprot_amd/csrc (hand-written HIP for
+gfx950 + host C++).  There is no Python or CPU fallback: if the shared library is missing this import
+fails, and if no GPU is usable Context() raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpamd.so")
+
+F_CIGAR, F_EXT_LEFT, F_EXT_RIGHT = 1, 2, 4
+
+DP_TASK = np.dtype([("nt_off", "<i8"), ("vid", "<i4"), ("nl", "<i4"), ("qid", "<i4"), ("aa_off", "<i4"),
+                    ("al", "<i4"), ("flag", "<i4"), ("io", "<i4"), ("tag", "<i4")], align=True)
+DP_RST = np.dtype([("nt_len", "<i4"), ("aa_len", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"),
+                   ("cigar_off", "<i8")], align=True)
+HIT = np.dtype([("qid", "<i4"), ("id", "<i4"), ("parent", "<i4"), ("n_sub", "<i4"), ("subsc", "<i4"), ("cnt", "<i4"),
+                ("n_exon", "<i4"), ("chn_sc", "<i4"), ("chn_sc_ungap", "<i4"), ("vid", "<u4"), ("qs", "<i4"),
+                ("qe", "<i4"), ("vs", "<i8"), ("ve", "<i8"), ("has_aln", "<i4"), ("dp_score", "<i4"),
+                ("dp_max", "<i4"), ("dp_max2", "<i4"), ("blen", "<i4"), ("n_fs", "<i4"), ("n_stop", "<i4"),
+                ("dist_stop", "<i4"), ("dist_start", "<i4"), ("n_iden", "<i4"), ("n_plus", "<i4"),
+                ("n_cigar", "<i4"), ("n_feat", "<i4"), ("cigar_off", "<i8"), ("feat_off", "<i8")], align=True)
+
+
+class MapOpt(C.Structure):
+    _fields_ = [("flag", C.c_uint32), ("mini_batch_size", C.c_int64), ("max_occ", C.c_int32), ("max_gap", C.c_int32),
+                ("max_intron", C.c_int32), ("min_max_intron", C.c_int32), ("max_max_intron", C.c_int32),
+                ("bw", C.c_int32), ("max_ext", C.c_int32), ("max_ava", C.c_int32), ("min_chn_cnt", C.c_int32),
+                ("max_chn_max_skip", C.c_int32), ("max_chn_iter", C.c_int32), ("min_chn_sc", C.c_int32),
+                ("chn_coef_log", C.c_float), ("mask_level", C.c_float), ("mask_len", C.c_int32),
+                ("pri_ratio", C.c_float), ("out_sim", C.c_float), ("out_cov", C.c_float), ("best_n", C.c_int32),
+                ("out_n", C.c_int32), ("kmer2", C.c_int32), ("go", C.c_int32), ("ge", C.c_int32), ("io", C.c_int32),
+                ("fs", C.c_int32), ("io_end", C.c_int32), ("ie_coef", C.c_float), ("sp_model", C.c_int32),
+                ("sp_null_bonus", C.c_int32), ("sp_max_bonus", C.c_int32), ("sp_scale", C.c_float),
+                ("xdrop", C.c_int32), ("end_bonus", C.c_int32), ("asize", C.c_int32), ("gff_delim", C.c_int32),
+                ("max_intron_flank", C.c_int32), ("gff_prefix", C.c_char_p), ("mat", C.c_int8 * 484)]
+
+
+class DpOpt(C.Structure):
+    _fields_ = [("go", C.c_int32), ("ge", C.c_int32), ("fs", C.c_int32), ("xdrop", C.c_int32),
+                ("end_bonus", C.c_int32), ("sp", C.c_int32 * 6), ("ie_coef", C.c_float), ("mat", C.c_int8 * 484)]
+
+
+class QBatch(C.Structure):
+    _fields_ = [("n_seq", C.c_int32), ("seqs", C.c_char_p), ("q_off", C.POINTER(C.c_int64))]
+
+
+class DpStats(C.Structure):
+    _fields_ = [("n_ext", C.c_int64), ("n_glob", C.c_int64), ("cells_ext", C.c_int64), ("cells_glob", C.c_int64),
+                ("rows_prep", C.c_int64), ("alg_bytes_ext", C.c_int64), ("alg_bytes_glob", C.c_int64),
+                ("ms_prep", C.c_double), ("ms_ext", C.c_double), ("ms_glob", C.c_double),
+                ("ms_backtrack", C.c_double), ("ms_total", C.c_double), ("launches_ext", C.c_int32),
+                ("launches_glob", C.c_int32)]
+
+
+def build(verbose=False):
+    """Compile libmpamd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libmpamd.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no Python/CPU fallback for the HIP kernels)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mpa_last_error.restype = C.c_char_p
+        L.mpa_version.restype = C.c_char_p
+        L.mpa_ctx_create.restype = C.c_void_p
+        L.mpa_ctx_create.argtypes = [C.c_int]
+        L.mpa_ctx_destroy.argtypes = [C.c_void_p]
+        L.mpa_idx_restore.restype = C.c_void_p
+        L.mpa_idx_restore.argtypes = [C.c_char_p]
+        L.mpa_idx_from_nt4.restype = C.c_void_p
+        L.mpa_idx_from_nt4.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
+        L.mpa_idx_dump.argtypes = [C.c_char_p, C.c_void_p]
+        L.mpa_idx_destroy.argtypes = [C.c_void_p]
+        L.mpa_idx_n_ctg.argtypes = [C.c_void_p]
+        L.mpa_idx_ctg_len.restype = C.c_int64
+        L.mpa_idx_ctg_len.argtypes = [C.c_void_p, C.c_int32]
+        L.mpa_idx_ctg_name.restype = C.c_char_p
+        L.mpa_idx_ctg_name.argtypes = [C.c_void_p, C.c_int32]
+        L.mpa_idx_genome_len.restype = C.c_int64
+        L.mpa_idx_genome_len.argtypes = [C.c_void_p]
+        L.mpa_idx_get_nt.restype = C.c_int64
+        L.mpa_idx_get_nt.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+        L.mpa_idx_to_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.mpa_mapopt_init.argtypes = [C.POINTER(MapOpt)]
+        L.mpa_mapopt_set_fs.argtypes = [C.POINTER(MapOpt), C.c_int32]
+        L.mpa_mapopt_set_max_intron.argtypes = [C.POINTER(MapOpt), C.c_int64]
+        L.mpa_dpopt_from_mapopt.argtypes = [C.POINTER(MapOpt), C.POINTER(DpOpt)]
+        L.mpa_dp_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(DpOpt), C.POINTER(QBatch), C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
+        L.mpa_dp_last_stats.argtypes = [C.c_void_p, C.POINTER(DpStats)]
+        L.mpa_free.argtypes = [C.c_void_p]
+        for name, res, args in [
+            ("mpa_batch_begin", C.c_void_p, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int]),
+            ("mpa_batch_dp_tasks", C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(DpOpt)]),
+            ("mpa_batch_dp_results", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+            ("mpa_batch_finish", C.c_void_p, [C.c_void_p]),
+            ("mpa_map_batch", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+            ("mpa_result_n_hit", C.c_int64, [C.c_void_p]),
+            ("mpa_result_hits", C.c_void_p, [C.c_void_p]),
+            ("mpa_result_hit_off", C.POINTER(C.c_int64), [C.c_void_p]),
+            ("mpa_result_cigars", C.POINTER(C.c_uint32), [C.c_void_p]),
+            ("mpa_result_destroy", None, [C.c_void_p]),
+            ("mpa_format_paf", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
+                                           C.c_void_p, C.POINTER(C.c_void_p)]),
+        ]:
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().mpa_last_error().decode()
+
+
+class MpaError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise MpaError("libmpamd error %d: %s" % (rc, last_error()))
+
+
+class Context:
+    """A HIP device context (one per GPU / per process rank)."""
+
+    def __init__(self, device=0):
+        self.h = lib().mpa_ctx_create(device)
+        if not self.h:
+            raise MpaError("cannot create a device context: " + last_error())
+
+    def close(self):
+        if self.h:
+            lib().mpa_ctx_destroy(self.h)
+            self.h = None
+
+    def dp_stats(self):
+        st = DpStats()
+        lib().mpa_dp_last_stats(self.h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in DpStats._fields_}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    def __init__(self, handle):
+        if not handle:
+            raise MpaError("cannot open the index: " + last_error())
+        self.h = handle
+
+    @classmethod
+    def restore(cls, path):
+        return cls(lib().mpa_idx_restore(os.fsencode(path)))
+
+    @classmethod
+    def from_nt4(cls, contigs, names=None):
+        """contigs: list of uint8 arrays of nt4 codes."""
+        n = len(contigs)
+        names = names or ["ctg%d" % i for i in range(n)]
+        arr = (C.c_char_p * n)(*[s.encode() for s in names])
+        lens = np.array([len(c) for c in contigs], dtype=np.int64)
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint8) for c in contigs]))
+        return cls(lib().mpa_idx_from_nt4(n, arr, lens.ctypes.data, cat.ctypes.data))
+
+    def to_device(self, ctx):
+        _check(lib().mpa_idx_to_device(ctx.h, self.h))
+
+    def n_ctg(self):
+        return lib().mpa_idx_n_ctg(self.h)
+
+    def ctg_len(self, cid):
+        return lib().mpa_idx_ctg_len(self.h, cid)
+
+    def ctg_name(self, cid):
+        return lib().mpa_idx_ctg_name(self.h, cid).decode()
+
+    def genome_len(self):
+        return lib().mpa_idx_genome_len(self.h)
+
+    def get_nt(self, vid, st, en):
+        buf = np.zeros(max(en - st, 0), dtype=np.uint8)
+        n = lib().mpa_idx_get_nt(self.h, vid, st, en, buf.ctypes.data)
+        return buf[:max(n, 0)]
+
+    def dump(self, path):
+        _check(lib().mpa_idx_dump(os.fsencode(path), self.h))
+
+    def close(self):
+        if self.h:
+            lib().mpa_idx_destroy(self.h)
+            self.h = None
+
+
+class Queries:
+    """A batch of protein sequences as the C ABI wants them (one concatenated buffer + offsets)."""
+
+    def __init__(self, seqs, names=None):
+        self.seqs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        self.names = names or ["q%d" % i for i in range(len(self.seqs))]
+        self.buf = b"".join(self.seqs)
+        self.off = np.zeros(len(self.seqs) + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in self.seqs], out=self.off[1:])
+        self.c = QBatch(len(self.seqs), self.buf, self.off.ctypes.data_as(C.POINTER(C.c_int64)))
+
+
+def default_mapopt():
+    mo = MapOpt()
+    lib().mpa_mapopt_init(C.byref(mo))
+    return mo
+
+
+def dpopt_from(mo):
+    dp = DpOpt()
+    lib().mpa_dpopt_from_mapopt(C.byref(mo), C.byref(dp))
+    return dp
+
+
+def dp_run(ctx, idx, dpopt, queries, tasks):
+    """Run a batch of DP calls on the GPU.  tasks: numpy array of DP_TASK.  Returns (results, cigar_pool)."""
+    tasks = np.ascontiguousarray(tasks, dtype=DP_TASK)
+    rst = np.zeros(len(tasks), dtype=DP_RST)
+    pool = C.POINTER(C.c_uint32)()
+    n_pool = C.c_int64(0)
+    _check(lib().mpa_dp_run(ctx.h, idx.h, C.byref(dpopt), C.byref(queries.c), len(tasks), tasks.ctypes.data,
+                            rst.ctypes.data, C.byref(pool), C.byref(n_pool)))
+    cig = np.ctypeslib.as_array(pool, (max(n_pool.value, 1),))[:n_pool.value].copy() if n_pool.value else np.zeros(0, np.uint32)
+    lib().mpa_free(pool)
+    return rst, cig

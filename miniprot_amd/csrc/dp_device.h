@@ -1,0 +1,72 @@
+// dp_device.h -- device-side data layout shared by the DP kernels (dp_kernels.hip) and the executor.
+#pragma once
+#include <cstdint>
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+
+namespace mpa {
+
+// One DP call as the kernels see it (built by the executor from mpa_dp_task_t).
+struct DTask {
+	int64_t nt_off;      // strand-local start of the window on vid
+	int64_t q_off;       // offset of aa[0] of this call in the concatenated query buffer
+	int64_t rec_off;     // first per-row record (uint32 units) in the record pool
+	int64_t prof_off;    // query profile (int16 units) in the profile pool, layout [22][pw]
+	int64_t tb_off;      // traceback matrix (uint16 units), layout [nl][ncol]         (global mode only)
+	int64_t cig_off;     // CIGAR slot (uint32 units) in the cigar pool               (global mode only)
+	int64_t bnd_off;     // column-block boundary scratch (16 B units), nl entries     (global mode, ncol>64)
+	int32_t vid, nl, al, flag, io;
+	int32_t ncol;        // 8*ceil(al/8): the columns the striped reference computes (padded columns are live)
+	int32_t pw;          // profile row width (columns, multiple of the lane-group width)
+	int32_t cig_cap;
+	int32_t out_idx;     // index into the caller's task array
+	int32_t pad_;
+};
+
+// Per-row record produced by the prep kernel, one uint32 per window row i:
+//   byte0 nas[i]        amino acid (aa20 code) of the codon ending at row i, 21 when undefined
+//   byte1 donor[i+1]    (int8)  penalty of an intron whose first base is row i+2
+//   byte2 gei[i]        (uint8) gap-extension of D at this row: fs when nas[i] is a stop, else ge
+//   byte3 acceptor[i]   (int8)  penalty of an intron whose last base is row i
+// The byte positions are chosen so that v_perm_b32 can sign-extend byte1/byte3 into packed int16.
+__host__ __device__ static inline uint32_t make_rec(uint32_t nas, int32_t donor_next, uint32_t gei, int32_t acceptor)
+{
+	return (nas & 0xff) | ((uint32_t)(donor_next & 0xff) << 8) | ((gei & 0xff) << 16) | ((uint32_t)(acceptor & 0xff) << 24);
+}
+
+// A wave of the extension kernel works on up to 8 calls at once: lanes are split in 64/G groups of G
+// columns, and each 32-bit lane register carries two independent calls in its int16 halves.
+struct ExtWave {
+	int32_t task[8];     // slot = half * (64/G) + group ; -1 = empty
+	int32_t max_nl;      // rows this wave iterates
+	int32_t pad_[3];
+	int64_t rec_base;    // smallest rec_off of the wave's tasks (record reads are base + 32-bit offset)
+};
+
+struct ExtOut { int32_t nt_len, aa_len, score, flags; };
+
+// penalty on the extension length (nasw-sse.c:426) as a step function of x = i - 3*al:
+// pen(x) = val[k] for x in [x[k], x[k+1]).  x[0] = INT32_MIN, last x = INT32_MAX.
+#define MPA_PEN_MAX 64
+struct PenTable { int32_t n; int32_t x[MPA_PEN_MAX]; int32_t val[MPA_PEN_MAX]; };
+
+struct GlobWave {
+	int32_t task[4];     // one call per group of G lanes; -1 = empty
+	int32_t max_nl;
+	int32_t pad_[3];
+};
+
+struct DpConst {         // scalar scoring parameters, passed by value
+	int32_t go, ge, fs, xdrop, end_bonus;
+	int32_t sp[6];
+};
+
+struct DevGenome {
+	const uint8_t *seq;      // 4-bit packed genome
+	const int64_t *ctg_off;  // [n_ctg]
+	const int64_t *ctg_len;  // [n_ctg]
+};
+
+} // namespace mpa

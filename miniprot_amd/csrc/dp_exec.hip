@@ -1,0 +1,473 @@
+// dp_exec.hip -- host-side executor of the batched spliced DP: the implementation of mpa_dp_run().
+//
+// A batch of ns_global_gs16b() calls (nasw.h:135; call sites align.c:73,288,293,322,327) is turned into
+//   1. one k_prep_rows / k_prep_prof launch (per-row records + query profiles, written once to HBM),
+//   2. one k_ext<G,NB> launch per shape class for the score-only extension calls, with up to 8 calls
+//      packed per wavefront and calls sorted by window length so that co-resident calls finish together,
+//   3. k_glob<G> launches for the calls that need a CIGAR, chunked by traceback memory, each followed by
+//      k_backtrack,
+// all on the context's own HIP stream, bracketed by HIP events (mpa_dp_last_stats feeds bench.py's
+// roofline record).  There is no CPU fallback here by design.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "mpa_internal.h"
+#include "dp_device.h"
+#include "dp_kernels.hip"
+
+namespace mpa {
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return MPA_ERR_HIP; } } while (0)
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return MPA_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr, cap = 0;
+		size_t want = bytes + (bytes >> 3) + 4096;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
+		cap = want;
+		return MPA_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }
+	template<typename T> T *as() { return (T*)p; }
+};
+
+struct DeviceIndex {
+	int device = -1;
+	uint8_t *seq = nullptr;
+	int64_t *ctg_off = nullptr, *ctg_len = nullptr;
+};
+
+} // namespace mpa
+
+using namespace mpa;
+
+struct mpa_ctx_s {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[6] = {};
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list;
+	mpa_dp_stats_t stats = {};
+	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
+};
+
+namespace mpa {
+
+int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
+{
+	if (mi->dev && mi->dev->device == ctx->device) return MPA_OK;
+	if (mi->dev) dev_free_index(mi);
+	HIP_TRY(hipSetDevice(ctx->device));
+	DeviceIndex *d = new DeviceIndex();
+	d->device = ctx->device;
+	const size_t n = mi->ctg.size();
+	std::vector<int64_t> off(n), len(n);
+	for (size_t i = 0; i < n; ++i) off[i] = mi->ctg[i].off, len[i] = mi->ctg[i].len;
+	HIP_TRY(hipMalloc((void**)&d->seq, mi->seq.size() + 16));
+	HIP_TRY(hipMalloc((void**)&d->ctg_off, n * 8 + 8));
+	HIP_TRY(hipMalloc((void**)&d->ctg_len, n * 8 + 8));
+	HIP_TRY(hipMemcpy(d->seq, mi->seq.data(), mi->seq.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d->ctg_off, off.data(), n * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d->ctg_len, len.data(), n * 8, hipMemcpyHostToDevice));
+	mi->dev = d;
+	return MPA_OK;
+}
+
+void dev_free_index(mpa_idx_s *mi)
+{
+	if (!mi->dev) return;
+	(void)hipSetDevice(mi->dev->device);
+	(void)hipFree(mi->dev->seq); (void)hipFree(mi->dev->ctg_off); (void)hipFree(mi->dev->ctg_len);
+	delete mi->dev;
+	mi->dev = nullptr;
+}
+
+// ns_log2 (nasw-sse.c:330-338) and the extension-length penalty of nasw-sse.c:426 tabulated as a step
+// function.  Evaluated on the host with the same float operations as the reference (no FMA contraction),
+// so the kernel needs no floating point at all.
+static float log2_poly(float x)
+{
+	union { float f; uint32_t i; } z = { x };
+	float r = (float)((int32_t)((z.i >> 23) & 255) - 128);
+	z.i &= ~(255u << 23);
+	z.i += 127u << 23;
+	r += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+	return r;
+}
+
+static int build_pen_table(float coef, int32_t max_x, PenTable *pt)
+{
+	int32_t n = 0, cur = 0;
+	pt->x[n] = INT32_MIN, pt->val[n] = 0, ++n;
+	for (int32_t x = 2; x <= max_x; ++x) {
+		int32_t v = (int32_t)(coef * log2_poly((float)x) + .5f);
+		if (v != cur) {
+			if (n >= MPA_PEN_MAX - 1) return -1;
+			pt->x[n] = x, pt->val[n] = v, ++n, cur = v;
+		}
+	}
+	pt->n = n;
+	for (int32_t k = n; k < MPA_PEN_MAX; ++k) pt->x[k] = INT32_MAX, pt->val[k] = cur;
+	return 0;
+}
+
+struct ExtClass { int G, NB; };
+static const ExtClass kExtClasses[] = { {16, 1}, {32, 1}, {64, 1}, {64, 2}, {64, 4}, {64, 8} };
+static const int kNumExtClasses = 6;
+
+static int ext_class_of(int32_t ncol)
+{
+	for (int k = 0; k < kNumExtClasses; ++k)
+		if (ncol <= kExtClasses[k].G * kExtClasses[k].NB) return k;
+	return -1;
+}
+
+template<int G, int NB> static hipError_t launch_ext(const ExtArgs &a, int n_waves, hipStream_t s)
+{
+	const size_t lds = (size_t)2 * (64 / G) * 22 * G * NB * 2 + 2 * MPA_PEN_MAX * 4;
+	if (lds > 48 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void*)k_ext<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL((k_ext<G, NB>), dim3(n_waves), dim3(64), lds, s, a);
+	return hipGetLastError();
+}
+
+static hipError_t launch_ext_class(int k, const ExtArgs &a, int n_waves, hipStream_t s)
+{
+	switch (k) {
+	case 0: return launch_ext<16, 1>(a, n_waves, s);
+	case 1: return launch_ext<32, 1>(a, n_waves, s);
+	case 2: return launch_ext<64, 1>(a, n_waves, s);
+	case 3: return launch_ext<64, 2>(a, n_waves, s);
+	case 4: return launch_ext<64, 4>(a, n_waves, s);
+	default: return launch_ext<64, 8>(a, n_waves, s);
+	}
+}
+
+template<int G> static hipError_t launch_glob(const GlobArgs &a, int n_waves, hipStream_t s)
+{
+	const size_t lds = (size_t)(64 / G) * 22 * G * 2;
+	hipLaunchKernelGGL((k_glob<G>), dim3(n_waves), dim3(64), lds, s, a);
+	return hipGetLastError();
+}
+
+} // namespace mpa
+
+extern "C" {
+
+int mpa_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+mpa_ctx_t *mpa_ctx_create(int device)
+{
+	int n = mpa_device_count();
+	if (n <= 0 || device < 0 || device >= n) {
+		set_error("no usable HIP device (the MI355X DP kernels have no CPU fallback)");
+		return nullptr;
+	}
+	if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+	mpa_ctx_s *ctx = new mpa_ctx_s();
+	ctx->device = device;
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
+	for (auto &e : ctx->ev) (void)hipEventCreate(&e);
+	if (const char *s = getenv("MPA_TB_BUDGET_MB")) ctx->tb_budget = (size_t)atoll(s) << 20;
+	return ctx;
+}
+
+void mpa_ctx_destroy(mpa_ctx_t *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list }) b->release();
+	for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+	(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi) { return dev_upload_index(ctx, mi); }
+
+void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st) { *st = ctx->stats; }
+
+int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
+               int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
+{
+	if (cigar_pool) *cigar_pool = nullptr;
+	if (n_pool) *n_pool = 0;
+	if (!ctx) { set_error("no device context"); return MPA_ERR_NO_DEVICE; }
+	if (!mi->dev || mi->dev->device != ctx->device) { set_error("index is not resident on this context's device (call mpa_idx_to_device)"); return MPA_ERR_ARG; }
+	ctx->stats = mpa_dp_stats_t();
+	if (n <= 0) return MPA_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->stream;
+
+	// ---- parameter guards: outside these the packed-int16 kernels would not be bit-exact
+	int32_t max_mat = 0;
+	for (int k = 0; k < 484; ++k) max_mat = std::max<int32_t>(max_mat, opt->mat[k]);
+	if (opt->go < 0 || opt->go > 32000 || opt->ge < 0 || opt->ge > 255 || opt->fs < 0 || opt->fs > 255 || opt->xdrop < 0 || opt->xdrop > 32000 ||
+	    opt->end_bonus < -128 || opt->end_bonus > 1000) {
+		set_error("DP parameters outside the supported range (go<=32000, ge/fs<=255, 0<=xdrop<=32000)"); return MPA_ERR_UNSUPPORTED;
+	}
+
+	// ---- classify, order and lay out the calls
+	std::vector<DTask> T(n);
+	std::vector<int32_t> ext_ids, glob_ids;
+	int32_t max_nl_ext = 0;
+	for (int64_t k = 0; k < n; ++k) {
+		const mpa_dp_task_t &x = in[k];
+		DTask &t = T[k];
+		memset(&t, 0, sizeof(t));
+		if (x.nl < 0 || x.al <= 0 || x.qid < 0 || x.qid >= q->n_seq || x.io < 0 || x.io > 32000) { set_error("malformed DP task"); return MPA_ERR_ARG; }
+		t.nt_off = x.nt_off, t.vid = x.vid, t.nl = x.nl, t.al = x.al, t.flag = x.flag, t.io = x.io;
+		t.q_off = q->q_off[x.qid] + x.aa_off;
+		t.ncol = (x.al + 7) / 8 * 8;
+		t.out_idx = (int32_t)k;
+		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
+		if (is_ext) {
+			const int cls = ext_class_of(t.ncol);
+			if (cls < 0) { set_error("extension call wider than 512 columns is not supported yet (al=" + std::to_string(x.al) + ")"); return MPA_ERR_UNSUPPORTED; }
+			if ((int64_t)x.al * max_mat + (int64_t)t.ncol * opt->ge + std::max(0, opt->end_bonus) > 32000 || opt->go + (int64_t)t.ncol * opt->ge > 32000) {
+				set_error("extension call could saturate int16; not supported"); return MPA_ERR_UNSUPPORTED;
+			}
+			t.pw = kExtClasses[cls].G * kExtClasses[cls].NB;
+			t.pad_ = cls;
+			ext_ids.push_back((int32_t)k);
+			max_nl_ext = std::max(max_nl_ext, x.nl);
+		} else {
+			if (!(x.flag & MPA_F_CIGAR)) { set_error("global DP without CIGAR is not part of miniprot's path"); return MPA_ERR_UNSUPPORTED; }
+			t.pw = t.ncol;
+			t.pad_ = t.ncol <= 16 ? 0 : t.ncol <= 32 ? 1 : 2;
+			glob_ids.push_back((int32_t)k);
+		}
+	}
+	auto by_class_then_len = [&](int32_t a, int32_t b) {
+		if (T[a].pad_ != T[b].pad_) return T[a].pad_ < T[b].pad_;
+		if (T[a].nl != T[b].nl) return T[a].nl > T[b].nl;
+		return a < b;
+	};
+	std::sort(ext_ids.begin(), ext_ids.end(), by_class_then_len);
+	std::sort(glob_ids.begin(), glob_ids.end(), by_class_then_len);
+
+	int64_t rec_total = 0, prof_total = 0, cig_total = 0, bnd_total = 0;
+	int32_t max_nl = 0;
+	std::vector<PrepChunk> chunks;
+	auto layout = [&](int32_t id) {
+		DTask &t = T[id];
+		t.rec_off = rec_total, rec_total += t.nl;
+		t.prof_off = prof_total, prof_total += (int64_t)22 * t.pw;
+		max_nl = std::max(max_nl, t.nl);
+		for (int32_t r = 0; r < t.nl; r += 256) chunks.push_back(PrepChunk{ id, r });
+	};
+	for (int32_t id : ext_ids) layout(id);
+	for (int32_t id : glob_ids) {
+		layout(id);
+		DTask &t = T[id];
+		t.cig_cap = t.nl + t.al + 4;
+		t.cig_off = cig_total, cig_total += t.cig_cap;
+		if (t.ncol > 64) t.bnd_off = bnd_total, bnd_total += t.nl;
+	}
+	rec_total += max_nl + 16;                               // kernels read a few records past a call's end
+
+	// ---- waves of the extension kernel
+	std::vector<ExtWave> ewaves;
+	std::vector<int> ewave_cnt(kNumExtClasses, 0), ewave_first(kNumExtClasses, 0);
+	{
+		size_t p = 0;
+		for (int cls = 0; cls < kNumExtClasses; ++cls) {
+			const int slots = 2 * (64 / kExtClasses[cls].G);
+			ewave_first[cls] = (int)ewaves.size();
+			while (p < ext_ids.size() && T[ext_ids[p]].pad_ == cls) {
+				ExtWave w;
+				memset(&w, 0, sizeof(w));
+				for (int k = 0; k < 8; ++k) w.task[k] = -1;
+				w.rec_base = T[ext_ids[p]].rec_off;
+				for (int k = 0; k < slots && p < ext_ids.size() && T[ext_ids[p]].pad_ == cls; ++k, ++p) {
+					w.task[k] = ext_ids[p];
+					w.max_nl = std::max(w.max_nl, T[ext_ids[p]].nl);
+				}
+				ewaves.push_back(w);
+			}
+			ewave_cnt[cls] = (int)ewaves.size() - ewave_first[cls];
+		}
+	}
+	PenTable pen;
+	if (build_pen_table(opt->ie_coef, std::max(max_nl_ext, 2), &pen) < 0) { set_error("ie_coef produces too many penalty steps"); return MPA_ERR_UNSUPPORTED; }
+
+	// ---- rounds of the traceback kernel, bounded by traceback memory
+	struct GlobRound { size_t first, last; int64_t tb_words; };
+	std::vector<GlobRound> rounds;
+	{
+		size_t p = 0;
+		while (p < glob_ids.size()) {
+			GlobRound r{ p, p, 0 };
+			while (r.last < glob_ids.size()) {
+				DTask &t = T[glob_ids[r.last]];
+				int64_t wds = (int64_t)t.nl * t.ncol;
+				if (r.last > r.first && (size_t)(r.tb_words + wds) * 2 > ctx->tb_budget) break;
+				t.tb_off = r.tb_words, r.tb_words += wds, ++r.last;
+			}
+			rounds.push_back(r);
+			p = r.last;
+		}
+	}
+	int64_t tb_max = 0;
+	for (auto &r : rounds) tb_max = std::max(tb_max, r.tb_words);
+
+	// ---- device memory
+	const int64_t q_bytes = q->q_off[q->n_seq];
+	int rc;
+	if ((rc = ctx->tasks.ensure(sizeof(DTask) * n)) || (rc = ctx->chunks.ensure(sizeof(PrepChunk) * (chunks.size() + 1))) ||
+	    (rc = ctx->qseq.ensure(q_bytes + 16)) || (rc = ctx->rec.ensure((size_t)rec_total * 4)) || (rc = ctx->prof.ensure((size_t)prof_total * 2 + 16)) ||
+	    (rc = ctx->waves.ensure(sizeof(ExtWave) * (ewaves.size() + 1))) || (rc = ctx->extout.ensure(sizeof(ExtOut) * n)) ||
+	    (rc = ctx->tb.ensure((size_t)tb_max * 2 + 16)) || (rc = ctx->cig.ensure((size_t)cig_total * 4 + 16)) || (rc = ctx->ncig.ensure(n * 4)) ||
+	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, T.data(), sizeof(DTask) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, chunks.data(), sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, q->seqs, q_bytes, hipMemcpyHostToDevice, s));
+	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
+
+	DevTables tabs;
+	memcpy(tabs.aa20, tab_aa20(), 256);
+	memcpy(tabs.codon, tab_codon(), 64);
+	memcpy(tabs.mat, opt->mat, 484);
+	DpConst dc;
+	dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
+	for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
+	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len };
+
+	// ---- K3: per-row records and profiles
+	HIP_TRY(hipEventRecord(ctx->ev[0], s));
+	if (!chunks.empty())
+		hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, s, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
+	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(ctx->ev[1], s));
+
+	// ---- K1: extension calls
+	ExtArgs ea;
+	ea.tasks = ctx->tasks.as<DTask>(), ea.rec = ctx->rec.as<uint32_t>(), ea.prof = ctx->prof.as<int16_t>(), ea.out = ctx->extout.as<ExtOut>();
+	ea.c = dc, ea.pen = pen;
+	for (int cls = 0; cls < kNumExtClasses; ++cls) {
+		if (ewave_cnt[cls] == 0) continue;
+		ea.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
+		HIP_TRY(launch_ext_class(cls, ea, ewave_cnt[cls], s));
+		ctx->stats.launches_ext++;
+	}
+	HIP_TRY(hipEventRecord(ctx->ev[2], s));
+
+	// ---- K2 + traceback walk
+	float ms_glob = 0, ms_bt = 0;
+	std::vector<GlobWave> gwaves;
+	std::vector<int32_t> glist;
+	for (auto &r : rounds) {
+		if (r.last == r.first) continue;
+		gwaves.clear(), glist.clear();
+		int cnt[3] = { 0, 0, 0 }, first[3] = { 0, 0, 0 };
+		size_t p = r.first;
+		for (int cls = 0; cls < 3; ++cls) {
+			const int per = cls == 0 ? 4 : cls == 1 ? 2 : 1;
+			first[cls] = (int)gwaves.size();
+			while (p < r.last && T[glob_ids[p]].pad_ == cls) {
+				GlobWave w;
+				memset(&w, 0, sizeof(w));
+				for (int k = 0; k < 4; ++k) w.task[k] = -1;
+				for (int k = 0; k < per && p < r.last && T[glob_ids[p]].pad_ == cls; ++k, ++p) {
+					w.task[k] = glob_ids[p];
+					w.max_nl = std::max(w.max_nl, T[glob_ids[p]].nl);
+					glist.push_back(glob_ids[p]);
+				}
+				gwaves.push_back(w);
+			}
+			cnt[cls] = (int)gwaves.size() - first[cls];
+		}
+		int32_t *d_list = ctx->list.as<int32_t>();
+		GlobWave *d_gw = (GlobWave*)((char*)ctx->list.p + (((size_t)n * 4 + 63) & ~(size_t)63));
+		HIP_TRY(hipMemcpyAsync(d_list, glist.data(), glist.size() * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_gw, gwaves.data(), gwaves.size() * sizeof(GlobWave), hipMemcpyHostToDevice, s));
+		GlobArgs ga;
+		ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
+		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc;
+		HIP_TRY(hipEventRecord(ctx->ev[3], s));
+		if (cnt[0]) { ga.waves = d_gw + first[0]; HIP_TRY(launch_glob<16>(ga, cnt[0], s)); ctx->stats.launches_glob++; }
+		if (cnt[1]) { ga.waves = d_gw + first[1]; HIP_TRY(launch_glob<32>(ga, cnt[1], s)); ctx->stats.launches_glob++; }
+		if (cnt[2]) { ga.waves = d_gw + first[2]; HIP_TRY(launch_glob<64>(ga, cnt[2], s)); ctx->stats.launches_glob++; }
+		HIP_TRY(hipEventRecord(ctx->ev[4], s));
+		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((glist.size() + 63) / 64)), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_list, (int32_t)glist.size(),
+		                   ctx->tb.as<uint16_t>(), ctx->cig.as<uint32_t>(), ctx->ncig.as<int32_t>());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(ctx->ev[5], s));
+		HIP_TRY(hipStreamSynchronize(s));
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
+		(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
+		ms_glob += a, ms_bt += b;
+	}
+	HIP_TRY(hipStreamSynchronize(s));
+
+	// ---- results
+	std::vector<ExtOut> eo;
+	std::vector<int32_t> sc, nc;
+	if (!ext_ids.empty()) { eo.resize(n); HIP_TRY(hipMemcpy(eo.data(), ctx->extout.p, sizeof(ExtOut) * n, hipMemcpyDeviceToHost)); }
+	std::vector<uint32_t> cig;
+	if (!glob_ids.empty()) {
+		sc.resize(n), nc.resize(n), cig.resize(cig_total);
+		HIP_TRY(hipMemcpy(sc.data(), ctx->score.p, n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(nc.data(), ctx->ncig.p, n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(cig.data(), ctx->cig.p, (size_t)cig_total * 4, hipMemcpyDeviceToHost));
+	}
+	int64_t pool_n = 0;
+	for (int32_t id : glob_ids) pool_n += nc[id];
+	uint32_t *pool = (uint32_t*)malloc((size_t)(pool_n > 0 ? pool_n : 1) * 4);
+	int64_t pp = 0;
+	for (int64_t k = 0; k < n; ++k) {
+		const DTask &t = T[k];
+		mpa_dp_rst_t &o = rst[k];
+		if (t.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) {
+			o.nt_len = eo[k].nt_len, o.aa_len = eo[k].aa_len, o.score = eo[k].score, o.n_cigar = 0, o.cigar_off = 0;
+		} else {
+			o.nt_len = t.nl, o.aa_len = t.al, o.score = sc[k], o.n_cigar = nc[k], o.cigar_off = pp;
+			memcpy(pool + pp, cig.data() + t.cig_off, (size_t)nc[k] * 4);
+			pp += nc[k];
+		}
+	}
+	if (cigar_pool) *cigar_pool = pool; else free(pool);
+	if (n_pool) *n_pool = pool_n;
+
+	// ---- statistics (cells = (nl-2) * 8*ceil(al/8); algorithmic bytes per call)
+	mpa_dp_stats_t &st = ctx->stats;
+	for (int32_t id : ext_ids) {
+		const DTask &t = T[id];
+		st.n_ext++, st.cells_ext += (int64_t)std::max(0, t.nl - 2) * t.ncol;
+		st.alg_bytes_ext += (t.nl + 1) / 2 + t.al + 12;
+	}
+	for (int32_t id : glob_ids) {
+		const DTask &t = T[id];
+		const int64_t cells = (int64_t)std::max(0, t.nl - 2) * t.ncol;
+		st.n_glob++, st.cells_glob += cells;
+		st.alg_bytes_glob += (t.nl + 1) / 2 + t.al + 12 + 2 * cells + 2 * ((int64_t)t.nl + t.al) + 4 * (int64_t)nc[id];
+	}
+	st.rows_prep = rec_total;
+	float ms = 0;
+	(void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); st.ms_prep = ms;
+	(void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); st.ms_ext = ms;
+	st.ms_glob = ms_glob, st.ms_backtrack = ms_bt;
+	st.ms_total = st.ms_prep + st.ms_ext + st.ms_glob + st.ms_backtrack;
+	return MPA_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,689 @@
+// dp_kernels.hip -- hand-written CDNA4 (gfx950) kernels for miniprot's spliced protein-to-genome DP.
+//
+// What they replace in the reference (lh3/miniprot v0.18-r281):
+//   k_prep_rows / k_prep_prof  ns_prep_seq, ns_prep_seq_left, ns_prep_nas, ns_gen_prof   nasw-sse.c:91-224
+//   k_ext<G,NB>                ns_global_gs16b score-only / extension loop               nasw-sse.c:349-443
+//   k_glob<G>                  ns_global_gs16b traceback loop                             nasw-sse.c:444-542
+//   k_backtrack                ns_backtrack + ns_fix_tiny_UV                              nasw-sse.c:30-89
+//
+// Mapping to the hardware (DESIGN.md has the full argument):
+//   * The DP matrix is tall and thin (rows = genomic window up to ~1e5, columns = the unaligned protein
+//     end, ~25 on average), rows are strictly sequential, so the parallelism of ONE call is its columns.
+//     A wavefront therefore sweeps rows with one column per lane ("row sweep"); the horizontal gap chain
+//     I(i,j) <- H(i,j-1) becomes a max-plus prefix scan done with DPP row_shr / row_bcast steps.
+//   * To fill 64 lanes x 2 int16 halves, k_ext packs up to 8 independent calls into one wave: lanes are
+//     split into 64/G groups of G columns and each 32-bit register carries two calls in its halves, all
+//     arithmetic being v_pk_{add,sub}_i16 clamp / v_pk_max_i16 -- the exact counterparts of the
+//     reference's _mm_adds/_mm_subs/_mm_max_epi16.
+//   * Per-row inputs (codon amino acid, donor/acceptor penalties) come from a 4-byte record per window row
+//     written once by k_prep_rows straight from the 4-bit packed genome in HBM (reverse-complement and
+//     reversal folded into the address), unpacked with v_perm_b32.  The 22 x ncol query profile sits in LDS.
+//   * The per-row "best row / x-drop" bookkeeping of the reference needs a row maximum; instead of a wave
+//     reduction per row the kernel compares every lane against two per-call thresholds and uses the
+//     64-bit VOPC result as a wave-wide vote; the exact update runs in a rare slow path.
+//   * k_glob has to reproduce artefacts of the reference's 8-lane striping in the traceback word
+//     (SURVEY.md A.3): it computes in int32, one column per lane, with a SEGMENTED scan for the first-pass
+//     I chain and a second scan for the cross-segment carry.  Matrices wider than 64 columns are processed
+//     in column blocks with a per-row boundary record.
+//
+// No MFMA: this is integer max-plus DP, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "dp_device.h"
+
+namespace mpa {
+
+struct DevTables { uint8_t aa20[256]; uint8_t codon[64]; int8_t mat[484]; };
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+#define NEGP 0x80008000u
+#define NEG16 (-32768)
+
+__device__ __forceinline__ v2s as_v(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t p_adds(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_v(a), as_v(b))); }
+__device__ __forceinline__ uint32_t p_subs(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_sub_sat(as_v(a), as_v(b))); }
+__device__ __forceinline__ uint32_t p_max(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_v(a), as_v(b))); }
+__device__ __forceinline__ uint32_t splat16(int32_t x) { return ((uint32_t)x & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ uint32_t pack16(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int32_t lo16(uint32_t x) { return (int32_t)(int16_t)(x & 0xffffu); }
+__device__ __forceinline__ int32_t hi16(uint32_t x) { return (int32_t)x >> 16; }
+__device__ __forceinline__ int32_t half16(uint32_t x, int h) { return h ? hi16(x) : lo16(x); }
+
+template<int CTRL, int RMASK> __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, RMASK, 0xf, false);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHR1  0x138
+#define DPP_BCAST15    0x142
+#define DPP_BCAST31    0x143
+
+// value of the left neighbour lane inside a group of G lanes; the first lane of each group gets `fill`
+template<int G> __device__ __forceinline__ uint32_t shift1(uint32_t x, uint32_t fill, int lane)
+{
+	if (G == 16) return dpp_mov<DPP_ROW_SHR(1), 0xf>(fill, x);
+	uint32_t r = dpp_mov<DPP_WAVE_SHR1, 0xf>(fill, x);
+	if (G == 32) r = lane == 32 ? fill : r;
+	return r;
+}
+
+// inclusive prefix max inside groups of G lanes, packed int16 (both halves at once)
+template<int G> __device__ __forceinline__ uint32_t scan_max_pk(uint32_t x)
+{
+	x = p_max(x, dpp_mov<DPP_ROW_SHR(1), 0xf>(NEGP, x));
+	x = p_max(x, dpp_mov<DPP_ROW_SHR(2), 0xf>(NEGP, x));
+	x = p_max(x, dpp_mov<DPP_ROW_SHR(4), 0xf>(NEGP, x));
+	x = p_max(x, dpp_mov<DPP_ROW_SHR(8), 0xf>(NEGP, x));
+	if (G >= 32) x = p_max(x, dpp_mov<DPP_BCAST15, 0xa>(NEGP, x));
+	if (G == 64) x = p_max(x, dpp_mov<DPP_BCAST31, 0xc>(NEGP, x));
+	return x;
+}
+
+#define NEG32 (-(1 << 29))
+__device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+template<int G> __device__ __forceinline__ int32_t scan_max_i32(int32_t x)
+{
+	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(1), 0xf>((uint32_t)NEG32, (uint32_t)x));
+	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(2), 0xf>((uint32_t)NEG32, (uint32_t)x));
+	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(4), 0xf>((uint32_t)NEG32, (uint32_t)x));
+	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(8), 0xf>((uint32_t)NEG32, (uint32_t)x));
+	if (G >= 32) x = imax(x, (int32_t)dpp_mov<DPP_BCAST15, 0xa>((uint32_t)NEG32, (uint32_t)x));
+	if (G == 64) x = imax(x, (int32_t)dpp_mov<DPP_BCAST31, 0xc>((uint32_t)NEG32, (uint32_t)x));
+	return x;
+}
+template<int G> __device__ __forceinline__ int32_t shift1_i32(int32_t x, int32_t fill, int lane)
+{
+	return (int32_t)shift1<G>((uint32_t)x, (uint32_t)fill, lane);
+}
+
+template<int G> __device__ __forceinline__ int32_t group_max(int32_t v)
+{
+#pragma unroll
+	for (int off = 1; off < G; off <<= 1) v = imax(v, __shfl_xor(v, off));
+	return v;
+}
+template<int G> __device__ __forceinline__ uint64_t group_mask(int lane)
+{
+	if (G == 64) return ~0ULL;
+	return ((1ULL << G) - 1) << (lane / G * G);
+}
+// does the 64-bit vote contain a group of G lanes with no bit set?
+template<int G> __device__ __forceinline__ bool has_empty_group(uint64_t m)
+{
+	if (G == 64) return m == 0;
+	if (G == 32) return (uint32_t)m == 0 || (uint32_t)(m >> 32) == 0;
+	return ((m - 0x0001000100010001ULL) & ~m & 0x8000800080008000ULL) != 0;
+}
+
+__device__ __forceinline__ int32_t sat16(int32_t x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
+__device__ __forceinline__ int32_t s_sub(int32_t a, int32_t b) { return sat16(a - b); }
+__device__ __forceinline__ int32_t s_add(int32_t a, int32_t b) { return sat16(a + b); }
+
+// ------------------------------------------------------------------------------------------------
+// K3: per-row records and query profiles
+// ------------------------------------------------------------------------------------------------
+struct PrepChunk { int32_t task; int32_t row0; };
+
+// base of the strand-oriented contig at strand-local position x (ntseq.c:89-106 folded into addressing)
+__device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off, int64_t len, int rev, int64_t x)
+{
+	int64_t p = rev ? off + len - 1 - x : off + x;
+	uint32_t b = (seq[p >> 1] >> ((p & 1) * 4)) & 0xf;
+	return rev && b < 4 ? 3 - b : b;
+}
+
+// donor/acceptor/nas of window row i.  Forward: ns_prep_seq (nasw-sse.c:106-155); left extension:
+// ns_prep_seq_left (nasw-sse.c:157-210).  int8 wrap-around of the reference's arrays is preserved.
+__global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tasks, const PrepChunk *chunks, uint32_t *rec, DpConst c, DevTables tb)
+{
+	const PrepChunk ch = chunks[blockIdx.x];
+	const DTask t = tasks[ch.task];
+	const int32_t i = ch.row0 + (int32_t)threadIdx.x, nl = t.nl;
+	if (i >= nl) return;
+	const int cid = t.vid >> 1, rev = t.vid & 1, left = (t.flag & 2) != 0;
+	const int64_t off = g.ctg_off[cid], len = g.ctg_len[cid];
+	// w[j] = b[i-6+j], j=0..15, where b[] is the (possibly reversed) window; 15 = outside the window
+	uint32_t w[16];
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		int32_t k = i - 6 + j;
+		w[j] = (k < 0 || k >= nl) ? 15u : strand_base(g.seq, off, len, rev, t.nt_off + (left ? nl - 1 - k : k));
+	}
+#define B_(d) w[6 + (d)]   /* b[i+d] */
+	uint32_t nas = 21;
+	int32_t don, acc;
+	const int32_t sp3 = (int8_t)c.sp[3];
+	if (!left) {
+		if (i >= 2 && B_(0) < 4 && B_(-1) < 4 && B_(-2) < 4) nas = tb.codon[B_(-2) << 4 | B_(-1) << 2 | B_(0)];
+		{ // donor[k], k = i+1
+			const int32_t k = i + 1;
+			don = sp3;
+			if (k < nl - 3) {
+				int tt = 3;
+				if (B_(2) == 2 && B_(3) == 3) tt = (B_(4) == 0 || B_(4) == 2) ? (B_(1) == 2 ? -1 : 4) : 0;
+				else if (B_(2) == 2 && B_(3) == 1 && B_(1) == 2) tt = 1;
+				else if (B_(2) == 0 && B_(3) == 3) tt = 2;
+				don = tt < 0 ? 0 : (int8_t)c.sp[tt];
+			}
+		}
+		{ // acceptor[i]
+			acc = sp3;
+			if (i >= 1) {
+				int tt = 3, pen_y = 0;
+				if (B_(-1) == 0 && B_(0) == 2) {
+					tt = (i >= 2 && (B_(-2) == 1 || B_(-2) == 3)) ? -1 : 0;
+#pragma unroll
+					for (int d = 4; d <= 6; ++d)
+						if (i - d >= 0 && B_(-d) != 1 && B_(-d) != 3) pen_y += c.sp[5];
+				} else if (B_(-1) == 0 && B_(0) == 1) tt = 2;
+				acc = tt < 0 ? 0 : (int8_t)c.sp[tt];
+				if (tt == -1 || tt == 0) acc = (int8_t)(acc + pen_y);
+			}
+		}
+	} else {
+		if (i >= 2 && B_(0) < 4 && B_(-1) < 4 && B_(-2) < 4) nas = tb.codon[B_(0) << 4 | B_(-1) << 2 | B_(-2)];
+		{ // "donor"[k] of the reversed string, k = i+1 (really the acceptor signal read backwards)
+			const int32_t k = i + 1;
+			don = sp3;
+			if (k < nl - 3) {
+				int tt = 3, pen_y = 0;
+				if (B_(2) == 2 && B_(3) == 0) {
+					tt = (B_(4) == 1 || B_(4) == 3) ? -1 : 0;
+#pragma unroll
+					for (int d = 6; d <= 8; ++d)       // j = k+5 .. k+7  ->  b[i+6 .. i+8]
+						if (i + d < nl && B_(d) != 1 && B_(d) != 3) pen_y += c.sp[5];
+				} else if (B_(2) == 1 && B_(3) == 0) tt = 2;
+				don = tt < 0 ? 0 : (int8_t)c.sp[tt];
+				if (tt == -1 || tt == 0) don = (int8_t)(don + pen_y);
+			}
+		}
+		{ // "acceptor"[i] of the reversed string (really the donor signal read backwards)
+			acc = sp3;
+			if (i >= 1) {
+				int tt = 3;
+				if (B_(-1) == 3 && B_(0) == 2)
+					tt = (i >= 2 && (B_(-2) == 0 || B_(-2) == 2)) ? ((i + 1 < nl && B_(1) == 2) ? -1 : 4) : 0;
+				else if (B_(-1) == 1 && B_(0) == 2 && i + 1 < nl && B_(1) == 1) tt = 1;
+				else if (B_(-1) == 3 && B_(0) == 0) tt = 2;
+				acc = tt < 0 ? 0 : (int8_t)c.sp[tt];
+			}
+		}
+	}
+#undef B_
+	rec[t.rec_off + i] = make_rec(nas, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
+}
+
+// query profile prof[a][col] = mat[a][aa(col)] (ns_gen_prof nasw-sse.c:212-224); columns >= al score -32768
+__global__ __launch_bounds__(256) void k_prep_prof(const DTask *tasks, const char *qseq, int16_t *prof, DevTables tb)
+{
+	const DTask t = tasks[blockIdx.x];
+	const int left = (t.flag & 2) != 0;
+	for (int idx = threadIdx.x; idx < 22 * t.pw; idx += blockDim.x) {
+		int a = idx / t.pw, col = idx - a * t.pw;
+		int16_t v = NEG16;
+		if (col < t.al) {
+			uint8_t ch = (uint8_t)qseq[t.q_off + (left ? t.al - 1 - col : col)];
+			v = tb.mat[a * 22 + tb.aa20[ch]];
+		}
+		prof[t.prof_off + idx] = v;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: extension (score only).  See file header.
+// ------------------------------------------------------------------------------------------------
+struct ExtArgs {
+	const DTask *tasks;
+	const ExtWave *waves;
+	const uint32_t *rec;
+	const int16_t *prof;
+	ExtOut *out;
+	DpConst c;
+	PenTable pen;
+};
+
+template<int G, int NB>
+__global__ __launch_bounds__(64) void k_ext(ExtArgs a)
+{
+	constexpr int NG = 64 / G;             // lane groups
+	constexpr int PW = G * NB;             // profile row width (columns)
+	extern __shared__ uint32_t lds_raw[];
+	int16_t *lds_prof = (int16_t*)lds_raw; // [2*NG slots][22][PW]
+	int32_t *lds_pen = (int32_t*)(lds_prof + 2 * NG * 22 * PW); // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
+
+	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
+	const ExtWave wv = a.waves[blockIdx.x];
+	const DpConst c = a.c;
+	const uint32_t *recbase = a.rec + wv.rec_base;
+
+	int32_t tid[2], nl[2], al[2], ncol[2];
+	uint32_t roff[2];
+	bool done[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		tid[h] = wv.task[h * NG + grp];
+		if (tid[h] >= 0) {
+			const DTask *t = &a.tasks[tid[h]];
+			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol;
+			roff[h] = (uint32_t)(t->rec_off - wv.rec_base);
+			done[h] = false;
+		} else nl[h] = 0, al[h] = 1, ncol[h] = G, roff[h] = 0, done[h] = true;
+	}
+	// stage profiles and the penalty table in LDS
+	for (int s = 0; s < 2 * NG; ++s) {
+		int t = wv.task[s];
+		if (t < 0) continue;
+		const int16_t *src = a.prof + a.tasks[t].prof_off;
+		for (int k = lane; k < 22 * PW; k += 64) lds_prof[s * 22 * PW + k] = src[k];
+	}
+	for (int k = lane; k < MPA_PEN_MAX; k += 64) lds_pen[k] = a.pen.x[k], lds_pen[MPA_PEN_MAX + k] = a.pen.val[k];
+	__syncthreads();
+
+	// ---- per-lane constants
+	uint32_t jge[NB], gojge[NB], ebv[NB];
+	uint64_t vm[2][NB];
+#pragma unroll
+	for (int b = 0; b < NB; ++b) {
+		const int gc = b * G + col;
+		jge[b] = splat16(gc * c.ge);
+		gojge[b] = splat16(c.go + gc * c.ge);
+		const int32_t ebp = c.end_bonus > 0 ? c.end_bonus : 0;
+		ebv[b] = pack16(gc == al[0] - 1 ? ebp : 0, gc == al[1] - 1 ? ebp : 0);
+		vm[0][b] = __ballot(gc < ncol[0]);
+		vm[1][b] = __ballot(gc < ncol[1]);
+	}
+	const uint32_t goP = splat16(c.go), ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0), fsP = splat16(c.fs);
+	const int pbase0 = ((0 * NG + grp) * 22 * PW + col) * 2, pbase1 = ((1 * NG + grp) * 22 * PW + col) * 2; // byte offsets
+	const char *ldsb = (const char*)lds_prof;
+
+	// ---- DP state: rings of 3 rows for H (and its left-shifted copy) and D; A/B/C persist
+	uint32_t Hr[3][NB], Hs[3][NB], Dr[3][NB], A[NB], B[NB], C[NB], Hbest[NB];
+#pragma unroll
+	for (int b = 0; b < NB; ++b) {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) Hr[k][b] = Hs[k][b] = Dr[k][b] = NEGP;
+		A[b] = B[b] = C[b] = Hbest[b] = NEGP;
+	}
+	// virtual column -1 as row 2 sees it (nasw-sse.c:256-258): H(-1,-1)=0, H(0,-1)=H(1,-1)=-fs
+	if (col == 0) Hs[2][0] = 0u, Hs[1][0] = splat16(-c.fs), Hs[0][0] = splat16(-c.fs);
+
+	// ---- bookkeeping of the reference's score-only loop (nasw-sse.c:423-433), per half
+	int32_t Gs[2] = { NEG16, NEG16 }, maxi[2] = { -1, -1 }, maxsc[2] = { INT32_MIN, INT32_MIN };
+	int32_t pk[2] = { 0, 0 }, pen[2] = { 0, 0 };
+	uint32_t Gv = NEGP, Tv = NEGP, penP = 0;
+	int32_t next_event = 2, n_active = 0;
+
+	// ---- row constants: sliding windows donor[i-1..i+1], acceptor[i-2..i]
+	uint32_t rA0 = recbase[roff[0] + 0], rB0 = recbase[roff[1] + 0];
+	uint32_t rA1 = recbase[roff[0] + 1], rB1 = recbase[roff[1] + 1];
+	uint32_t dim1, di = __builtin_amdgcn_perm(rB0, rA0, 0x0a050801u), dip1 = __builtin_amdgcn_perm(rB1, rA1, 0x0a050801u);
+	uint32_t aim2, aim1 = __builtin_amdgcn_perm(rB0, rA0, 0x0b070903u), ai = __builtin_amdgcn_perm(rB1, rA1, 0x0b070903u);
+	// software pipeline: records of rows i and i+1 in registers, profile scores of row i in registers
+	uint32_t r0A = recbase[roff[0] + 2], r0B = recbase[roff[1] + 2];
+	uint32_t r1A = recbase[roff[0] + 3], r1B = recbase[roff[1] + 3];
+	uint32_t S[NB];
+	{
+		const int o0 = pbase0 + (int)(r0A & 0xff) * (PW * 2), o1 = pbase1 + (int)(r0B & 0xff) * (PW * 2);
+#pragma unroll
+		for (int b = 0; b < NB; ++b)
+			S[b] = pack16(*(const int16_t*)(ldsb + o0 + b * G * 2), *(const int16_t*)(ldsb + o1 + b * G * 2));
+	}
+
+	auto repack = [&]() {
+		Gv = pack16(done[0] ? 32767 : Gs[0], done[1] ? 32767 : Gs[1]);
+		Tv = pack16(done[0] ? NEG16 : sat16(Gs[0] - c.xdrop), done[1] ? NEG16 : sat16(Gs[1] - c.xdrop));
+		penP = pack16(pen[0], pen[1]);
+		n_active = __popcll(__ballot(!done[0] && col == 0)) + __popcll(__ballot(!done[1] && col == 0));
+	};
+
+	// task ends and changes of the length penalty: rare, handled before the row is computed
+	auto events = [&](int32_t i) {
+		int32_t nx = INT32_MAX;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			if (!done[h] && i >= nl[h]) done[h] = true;
+			if (!done[h]) {
+				const int64_t x = (int64_t)i - 3 * (int64_t)al[h];
+				while (x >= (int64_t)lds_pen[pk[h] + 1]) ++pk[h];
+				pen[h] = lds_pen[MPA_PEN_MAX + pk[h]];
+				int64_t e = (int64_t)lds_pen[pk[h] + 1] + 3 * (int64_t)al[h];
+				if (e > nl[h]) e = nl[h];
+				nx = nx < (int32_t)e ? nx : (int32_t)e;
+			}
+		}
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { int32_t o = __shfl_xor(nx, off); nx = nx < o ? nx : o; }
+		next_event = nx;
+		repack();
+	};
+
+	int32_t i = 2;
+	const int32_t max_nl = wv.max_nl;
+
+	auto row = [&](auto kc) {
+		constexpr int K = decltype(kc)::value;
+		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;   // ring slots of rows i-1, i-2, i-3
+		// prefetch the record of row i+2
+		const uint32_t r2A = recbase[roff[0] + (uint32_t)i + 2], r2B = recbase[roff[1] + (uint32_t)i + 2];
+		// unpack the record of row i
+		const uint32_t dnew = __builtin_amdgcn_perm(r0B, r0A, 0x0a050801u);
+		const uint32_t anew = __builtin_amdgcn_perm(r0B, r0A, 0x0b070903u);
+		const uint32_t gei = __builtin_amdgcn_perm(r0B, r0A, 0x0c060c02u);
+		dim1 = di, di = dip1, dip1 = dnew;
+		aim2 = aim1, aim1 = ai, ai = anew;
+		// profile scores of row i+1 (LDS latency overlaps this row's arithmetic)
+		uint32_t Sn[NB];
+		{
+			const int o0 = pbase0 + (int)(r1A & 0xff) * (PW * 2), o1 = pbase1 + (int)(r1B & 0xff) * (PW * 2);
+#pragma unroll
+			for (int b = 0; b < NB; ++b)
+				Sn[b] = pack16(*(const int16_t*)(ldsb + o0 + b * G * 2), *(const int16_t*)(ldsb + o1 + b * G * 2));
+		}
+		uint32_t carry = NEGP, prev_last = NEGP;
+		uint32_t Hn[NB];
+		uint64_t impm = 0, alv0 = 0, alv1 = 0;
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			uint32_t h, t, u;
+			h = p_adds(Hs[R3][b], S[b]);                                    // H(i-3,j-1) + s(i,j)
+			u = p_subs(Hr[R3][b], goP); t = p_max(u, Dr[R3][b]);            // D
+			t = p_subs(t, gei); Dr[R3][b] = t; h = p_max(h, t);
+			u = p_subs(Hr[R1][b], ioP); t = p_subs(u, dim1);                // A: phase-0 intron
+			t = p_max(t, A[b]); A[b] = t; h = p_max(h, p_subs(t, ai));
+			u = p_subs(Hs[R1][b], ioP); t = p_subs(u, di);                  // B: phase-1 intron
+			t = p_max(t, B[b]); B[b] = t; h = p_max(h, p_subs(t, aim2));
+			t = p_subs(u, dip1);                                            // C: phase-2 intron
+			t = p_max(t, C[b]); C[b] = t; h = p_max(h, p_subs(t, aim1));
+			t = p_max(p_max(Hr[R1][b], Hr[R2][b]), p_max(Hs[R1][b], Hs[R2][b])); // four frameshift moves
+			h = p_max(h, p_subs(t, fsP));
+			// horizontal gap chain as a prefix max of h + j*ge
+			uint32_t y = scan_max_pk<G>(p_adds(h, jge[b]));
+			uint32_t ex = shift1<G>(y, NEGP, lane);
+			if (NB > 1) {
+				ex = p_max(ex, carry);
+				carry = p_max(carry, (uint32_t)__builtin_amdgcn_readlane((int)y, 63));
+			}
+			h = p_max(h, p_subs(ex, gojge[b]));
+			Hn[b] = h;
+			// left-shifted copy for the next rows
+			uint32_t hs = shift1<G>(h, (NB > 1 && b > 0) ? prev_last : NEGP, lane);
+			if (NB > 1) prev_last = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
+			Hr[R3][b] = h, Hs[R3][b] = hs;
+			// votes against the per-call thresholds
+			const uint32_t cand = p_subs(p_adds(h, ebv[b]), penP);
+			impm |= (__ballot(lo16(cand) > lo16(Gv)) & vm[0][b]) | (__ballot(hi16(cand) > hi16(Gv)) & vm[1][b]);
+			alv0 |= __ballot(!(lo16(cand) < lo16(Tv))) & vm[0][b];
+			alv1 |= __ballot(!(hi16(cand) < hi16(Tv))) & vm[1][b];
+		}
+		if (impm != 0 || has_empty_group<G>(alv0) || has_empty_group<G>(alv1)) {
+			// slow path: exact restatement of nasw-sse.c:423-433 for the calls that need it
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				int32_t m = NEG16;
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const int32_t cv = half16(p_subs(p_adds(Hn[b], ebv[b]), penP), h);
+					if (b * G + col < ncol[h]) m = imax(m, cv);
+				}
+				m = group_max<G>(m);
+				if (!done[h] && m > Gs[h]) {                                 // new best row
+					Gs[h] = m, maxi[h] = i, maxsc[h] = m + pen[h];
+#pragma unroll
+					for (int b = 0; b < NB; ++b)
+						Hbest[b] = h ? ((Hbest[b] & 0xffffu) | (Hn[b] & 0xffff0000u)) : ((Hbest[b] & 0xffff0000u) | (Hn[b] & 0xffffu));
+				}
+				if (!done[h] && Gs[h] - m > c.xdrop) done[h] = true;        // x-drop
+			}
+			repack();
+		}
+		if (i == 2 && col == 0) Hs[R1][0] = NEGP, Hs[R2][0] = NEGP;        // column -1 is -inf from row 3 on
+#pragma unroll
+		for (int b = 0; b < NB; ++b) S[b] = Sn[b];
+		r0A = r1A, r0B = r1B, r1A = r2A, r1B = r2B;
+		++i;
+	};
+
+	while (i < max_nl) {
+		if (i >= next_event) events(i);
+		if (n_active == 0) break;
+		row(std::integral_constant<int, 0>());
+		if (i >= max_nl) break;
+		if (i >= next_event) events(i);
+		if (n_active == 0) break;
+		row(std::integral_constant<int, 1>());
+		if (i >= max_nl) break;
+		if (i >= next_event) events(i);
+		if (n_active == 0) break;
+		row(std::integral_constant<int, 2>());
+	}
+
+	// ---- results (nasw-sse.c:435-443): first column of the best row that attains the best score
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		if (tid[h] < 0) continue;
+		int32_t first = INT32_MAX;
+		if (maxi[h] >= 0) {
+#pragma unroll
+			for (int b = 0; b < NB; ++b) {
+				const int gc = b * G + col;
+				int32_t v = half16(Hbest[b], h);
+				if (gc == al[h] - 1) v += c.end_bonus;
+				uint64_t m = __ballot(gc < al[h] && v == maxsc[h]) & group_mask<G>(lane);
+				if (m != 0 && first == INT32_MAX) first = b * G + (__ffsll((unsigned long long)m) - 1) % G;
+			}
+		}
+		if (col == 0) {
+			ExtOut o;
+			o.nt_len = maxi[h] + 1;
+			o.aa_len = maxi[h] < 0 ? 0 : (first == INT32_MAX ? al[h] + 1 : first + 1);
+			o.score = maxsc[h];
+			o.flags = (maxi[h] >= 0 && first == INT32_MAX) ? 1 : 0;       // the reference assert()s here
+			a.out[tid[h]] = o;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: global alignment with traceback.  int32 arithmetic, one column per lane, one call per group of
+// G lanes; matrices wider than 64 columns are swept in column blocks (block-major), each block leaving
+// a 16-byte boundary record per row for its right neighbour.
+// ------------------------------------------------------------------------------------------------
+struct GlobArgs {
+	const DTask *tasks;
+	const GlobWave *waves;
+	const uint32_t *rec;
+	const int16_t *prof;
+	uint16_t *tb;
+	int4 *bnd;            // {prefix of the I scan, prefix of the carry scan, H | h1<<16 (int16 each), I1}
+	int32_t *score;       // per task
+	DpConst c;
+};
+
+#define SEG_BIG (1 << 20)
+
+template<int G>
+__global__ __launch_bounds__(64) void k_glob(GlobArgs a)
+{
+	constexpr int NG = 64 / G;
+	extern __shared__ uint32_t lds_raw[];
+	int16_t *lds_prof = (int16_t*)lds_raw;           // [NG][22][G] for the current column block
+	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
+	const GlobWave wv = a.waves[blockIdx.x];
+	const DpConst c = a.c;
+	const int32_t tid = wv.task[grp];
+	DTask t;
+	if (tid >= 0) t = a.tasks[tid];
+	else { t.nl = 0, t.al = 1, t.ncol = 8, t.pw = G, t.rec_off = 0, t.prof_off = 0, t.tb_off = 0, t.bnd_off = 0, t.io = 0; }
+	const int32_t nl = t.nl, ncol = t.ncol, slen = ncol >> 3;
+	const int32_t nblk = G == 64 ? (ncol + 63) / 64 : 1;
+	const int32_t go = c.go, ge = c.ge, goe = (int16_t)(c.go + c.ge), io = t.io, fs = c.fs;
+	const uint32_t *rec = a.rec + t.rec_off;
+	uint16_t *tb = a.tb + t.tb_off;
+	int4 *bnd = a.bnd + t.bnd_off;
+
+	for (int32_t blk = 0; blk < nblk; ++blk) {
+		const int32_t gc = blk * G + col;                 // global column of this lane
+		const bool live = tid >= 0 && gc < ncol;
+		// the previous block's boundary records were written by this wave: make them visible (and drop L1)
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+		// stage this block's profile columns
+		__syncthreads();
+		for (int s = 0; s < NG; ++s) {
+			const int ts = wv.task[s];
+			if (ts < 0) continue;
+			const DTask *tt = &a.tasks[ts];
+			const int16_t *src = a.prof + tt->prof_off;
+			for (int k = lane; k < 22 * G; k += 64) {
+				int aidx = k / G, cc = k - aidx * G, gcc = blk * G + cc;
+				lds_prof[s * 22 * G + k] = gcc < tt->pw ? src[aidx * tt->pw + gcc] : (int16_t)NEG16;
+			}
+		}
+		__syncthreads();
+		const int16_t *myprof = lds_prof + grp * 22 * G + col;
+		const int32_t seg = slen > 0 ? gc / slen : 0;
+		const bool seg_start = slen > 0 && gc % slen == 0;
+		const int32_t cge = gc * ge, yoff = seg * SEG_BIG + cge;
+		const bool first_blk = blk == 0, last_blk = blk == nblk - 1;
+
+		int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
+		int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
+		if (first_blk && col == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
+		// donor/acceptor sliding windows
+		uint32_t q0 = nl > 0 ? rec[0] : 0, q1 = nl > 1 ? rec[1] : 0;
+		int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
+		int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
+		uint32_t rcur = nl > 2 ? rec[2] : 0;
+
+		for (int32_t i = 2; i < wv.max_nl; ++i) {
+			const bool rowlive = i < nl;
+			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
+			const int32_t nas = rcur & 0xff, gei = (rcur >> 16) & 0xff;
+			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
+			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
+			const int32_t S = myprof[nas * G];
+			// boundary record of the block to the left
+			int4 bin = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
+			if (!first_blk && rowlive) bin = bnd[i];
+			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
+
+			int32_t w = 0, st = 0, h, tt, u;
+			// candidates other than I
+			const int32_t M = s_add(H3s, S);
+			u = s_sub(H3, go); if (D3 > u) w |= 1 << 5;
+			const int32_t Dn = s_sub(imax(u, D3), gei);
+			tt = s_sub(s_sub(H1, io), dm1); if (A > tt) w |= 1 << 6;
+			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
+			u = s_sub(H1s, io);
+			tt = s_sub(u, d0); if (B > tt) w |= 1 << 7;
+			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
+			tt = s_sub(u, dp1); if (C > tt) w |= 1 << 8;
+			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
+			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
+			const int32_t nonI = imax(imax(imax(M, Dn), imax(Av, Bv)), imax(imax(Cv, F6), imax(imax(F7, F8), F9)));
+			// first-pass I: the chain restarts at every lane start of the striped reference (segments of slen columns)
+			const int32_t py = scan_max_i32<G>(nonI + yoff);
+			int32_t pex = shift1_i32<G>(py, NEG32, lane);
+			pex = imax(pex, bin.x);
+			const int32_t py_tot = imax(bin.x, __shfl(py, grp * G + G - 1));
+			const int32_t I1 = imax(pex - yoff - go, NEG16);
+			// ordered choice of the state, strict '>' keeps the earlier one (nasw-sse.c:451-519)
+			h = M;
+			if (I1 > h) st = 1, h = I1;
+			if (Dn > h) st = 2, h = Dn;
+			if (Av > h) st = 3, h = Av;
+			if (Bv > h) st = 4, h = Bv;
+			if (Cv > h) st = 5, h = Cv;
+			if (F6 > h) st = 6, h = F6;
+			if (F7 > h) st = 7, h = F7;
+			if (F8 > h) st = 8, h = F8;
+			if (F9 > h) st = 9, h = F9;
+			const int32_t h1 = h;
+			// left neighbour's first-pass (h, I)
+			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
+			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
+			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
+			if (il > s_sub(hl, go)) w |= 1 << 4;
+			// carry of I across lane starts (the reference's lazy-F loop) as a second prefix max
+			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
+			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
+			int32_t pz = scan_max_i32<G>(z);
+			pz = imax(pz, bin.y);
+			const int32_t Gc = imax(pz - cge, NEG16);
+			if (Gc > h1) w |= 1 << 9, h = Gc;
+			if (live && rowlive) tb[(int64_t)i * ncol + gc] = (uint16_t)(w | st);
+			// boundary record for the block to the right
+			if (!last_blk && rowlive && col == G - 1 && tid >= 0)
+				bnd[i] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
+			if (rowlive && i == nl - 1 && gc == t.al - 1 && tid >= 0) a.score[tid] = h;
+			// rotate
+			const int32_t hs = shift1_i32<G>(h, first_blk ? NEG16 : Hb, lane);
+			H3 = H2, H2 = H1, H1 = h;
+			H3s = H2s, H2s = H1s, H1s = hs;
+			D3 = D2, D2 = D1, D1 = Dn;
+			A = An, B = Bn, C = Cn;
+			if (i == 2 && first_blk && col == 0) H2s = NEG16, H3s = NEG16;
+			rcur = rnext;
+		}
+	}
+	if (tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
+}
+
+// ------------------------------------------------------------------------------------------------
+// traceback walk (ns_backtrack nasw-sse.c:40-89), one thread per call
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cig_push(uint32_t *cig, int32_t &n, int32_t cap, uint32_t op, int32_t len)
+{
+	if (n > 0 && (cig[n - 1] & 0xf) == op && op != 10 && op != 11) cig[n - 1] += (uint32_t)len << 4;
+	else if (n < cap) cig[n++] = (uint32_t)len << 4 | op;
+}
+
+__global__ void k_backtrack(const DTask *tasks, const int32_t *list, int32_t n_list, const uint16_t *tbpool, uint32_t *cigpool, int32_t *n_cigar)
+{
+	const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_list) return;
+	const int32_t tid = list[k];
+	const DTask t = tasks[tid];
+	const uint16_t *tb = tbpool + t.tb_off;
+	uint32_t *cig = cigpool + t.cig_off;
+	const int32_t ncol = t.ncol, cap = t.cig_cap;
+	int32_t i = t.nl - 1, j = t.al - 1, carry = 0, n = 0;
+	while (i >= 2 && j >= 0) {
+		int32_t w = tb[(int64_t)i * ncol + j], st, ext;
+		if (w >> 9 & 1) w = 1 | (w >> 4 << 4);
+		st = carry ? carry : (w & 0xf);
+		ext = (st >= 1 && st <= 5) ? (w >> (st + 3) & 1) : 0;
+		switch (st) {
+		case 0: cig_push(cig, n, cap, 0, 1); i -= 3; --j; break;
+		case 1: cig_push(cig, n, cap, 1, 1); --j; break;
+		case 2: cig_push(cig, n, cap, 2, 1); i -= 3; break;
+		case 3: cig_push(cig, n, cap, 3, 1); --i; break;
+		case 4: cig_push(cig, n, cap, 12, 1); --i; if (!ext) --j; break;
+		case 5: cig_push(cig, n, cap, 13, 1); --i; if (!ext) --j; break;
+		case 6: cig_push(cig, n, cap, 10, 1); --i; break;
+		case 7: cig_push(cig, n, cap, 10, 2); i -= 2; break;
+		case 8: cig_push(cig, n, cap, 11, 1); --i; --j; break;
+		case 9: cig_push(cig, n, cap, 11, 2); i -= 2; --j; break;
+		default: break;
+		}
+		carry = (st >= 1 && st <= 5 && ext) ? st : 0;
+	}
+	if (j > 0) cig_push(cig, n, cap, 1, j);
+	if (i >= 0) {
+		const int32_t l = (i + 1) / 3 * 3, r = (i + 1) % 3;
+		if (l > 0) cig_push(cig, n, cap, 2, l);
+		if (r != 0) cig_push(cig, n, cap, 10, r);
+	}
+	for (int32_t x = 0; x < n >> 1; ++x) { uint32_t tmp = cig[x]; cig[x] = cig[n - 1 - x], cig[n - 1 - x] = tmp; }
+	for (int32_t x = 0; x < n; ++x) {                                   // ns_fix_tiny_UV
+		const uint32_t op = cig[x] & 0xf;
+		if ((op == 12 || op == 13) && cig[x] >> 4 < 3) cig[x] = cig[x] >> 4 << 4 | 11;
+	}
+	n_cigar[tid] = n;
+}
+
+} // namespace mpa

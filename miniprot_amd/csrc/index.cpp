@@ -1,0 +1,165 @@
+// index.cpp -- the .mpi index on the host: load, dump, window fetch.
+//
+// Replaces index.c:11-44 (block offsets, block->contig lookup), index.c:189-229 (dump/restore) and
+// ntseq.c:89-114,163-205 (4-bit genome store) of the reference.  File layout:
+//   "MPI\3" | idxopt (20 B) | int64 n_kb | int32 n_ctg | int32 l_name | int64 l_seq | int64 len[n_ctg]
+//   | uint8 seq[(l_seq+1)/2] | char name[l_name] | int64 ki[1<<(4k-m)] | uint32 kb[n_kb]
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include "mpa_internal.h"
+
+namespace mpa {
+
+static const char kMagic[4] = { 'M', 'P', 'I', 3 };
+
+static void compute_block_offsets(mpa_idx_s *mi)
+{
+	const int32_t bbit = mi->opt.bbit;
+	const size_t n = mi->ctg.size();
+	int64_t acc = 0;
+	mi->bo.assign(2 * n + 1, 0);
+	for (size_t i = 0; i < n; ++i) {
+		int64_t nb = (mi->ctg[i].len + (1LL << bbit) - 1) >> bbit;
+		mi->bo[2 * i] = (uint32_t)acc, acc += nb;      // forward strand
+		mi->bo[2 * i + 1] = (uint32_t)acc, acc += nb;  // reverse strand
+	}
+	mi->bo[2 * n] = mi->n_block = (uint32_t)acc;
+}
+
+int32_t block2vid(const mpa_idx_s *mi, uint32_t blk)
+{
+	// largest v with bo[v] <= blk; -1 when blk is past the last block
+	const int32_t n = (int32_t)mi->bo.size() - 1;
+	if (n <= 0 || blk >= mi->bo[n]) return -1;
+	int32_t lo = 0, hi = n - 1;
+	while (lo < hi) {
+		int32_t mid = (lo + hi + 1) >> 1;
+		if (mi->bo[mid] <= blk) lo = mid; else hi = mid - 1;
+	}
+	// contigs shorter than a block cannot exist (len>0 gives >=1 block), but strands of equal offset could
+	// only arise for len==0; walk forward to the interval that really contains blk
+	while (lo + 1 < n && mi->bo[lo + 1] <= blk) ++lo;
+	return lo;
+}
+
+int64_t fetch_nt(const mpa_idx_s *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out)
+{
+	const int32_t cid = vid >> 1;
+	if (cid < 0 || cid >= (int32_t)mi->ctg.size()) return -1;
+	const Contig &c = mi->ctg[cid];
+	if (st < 0 || en < 0 || st >= c.len) return -1;
+	if (en > c.len) en = c.len;
+	int64_t k = 0;
+	if (!(vid & 1)) {
+		for (int64_t p = c.off + st; p < c.off + en; ++p) out[k++] = nt_at(mi, p);
+	} else {                                          // reverse strand: walk the forward strand backwards, complement
+		for (int64_t p = c.off + c.len - 1 - st; p >= c.off + c.len - en; --p) {
+			uint8_t b = nt_at(mi, p);
+			out[k++] = b >= 4 ? b : (uint8_t)(3 - b);
+		}
+	}
+	return k;
+}
+
+template<typename T> static bool rd(FILE *fp, T *dst, size_t n) { return fread(dst, sizeof(T), n, fp) == n; }
+
+} // namespace mpa
+
+using namespace mpa;
+
+extern "C" {
+
+mpa_idx_t *mpa_idx_restore(const char *fn)
+{
+	FILE *fp = fopen(fn, "rb");
+	if (!fp) { set_error(std::string("cannot open ") + fn); return nullptr; }
+	char magic[4];
+	mpa_idx_s *mi = new mpa_idx_s();
+	int32_t hdr[2];
+	bool ok = rd(fp, magic, 4) && memcmp(magic, kMagic, 4) == 0;
+	ok = ok && rd(fp, &mi->opt, 1) && rd(fp, &mi->n_kb, 1) && rd(fp, hdr, 2) && rd(fp, &mi->l_seq, 1);
+	if (ok && set_trans_code((int)mi->opt.trans_code) < 0) ok = false;
+	if (ok) {
+		const int32_t n_ctg = hdr[0], l_name = hdr[1];
+		mi->ctg.resize(n_ctg);
+		int64_t off = 0;
+		for (int32_t i = 0; i < n_ctg && ok; ++i) {
+			ok = rd(fp, &mi->ctg[i].len, 1);
+			mi->ctg[i].off = off, off += mi->ctg[i].len;
+		}
+		mi->seq.resize((size_t)((mi->l_seq + 1) >> 1));
+		mi->names.resize(l_name);
+		ok = ok && rd(fp, mi->seq.data(), mi->seq.size()) && rd(fp, mi->names.data(), mi->names.size());
+		const char *p = mi->names.data(), *end = p + mi->names.size();
+		for (int32_t i = 0; i < n_ctg && ok; ++i) {
+			if (p >= end) { ok = false; break; }
+			mi->ctg[i].name = p;
+			p += mi->ctg[i].name.size() + 1;
+		}
+		const size_t n_bucket = (size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit);
+		mi->ki.resize(n_bucket);
+		mi->kb.resize((size_t)mi->n_kb);
+		ok = ok && rd(fp, mi->ki.data(), n_bucket) && rd(fp, mi->kb.data(), mi->kb.size());
+	}
+	fclose(fp);
+	if (!ok) { set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
+	compute_block_offsets(mi);
+	return mi;
+}
+
+int mpa_idx_dump(const char *fn, const mpa_idx_t *mi)
+{
+	FILE *fp = fopen(fn, "wb");
+	if (!fp) { set_error(std::string("cannot write ") + fn); return MPA_ERR_IO; }
+	int32_t hdr[2] = { (int32_t)mi->ctg.size(), (int32_t)mi->names.size() };
+	fwrite(kMagic, 1, 4, fp);
+	fwrite(&mi->opt, sizeof(mi->opt), 1, fp);
+	fwrite(&mi->n_kb, 8, 1, fp);
+	fwrite(hdr, 4, 2, fp);
+	fwrite(&mi->l_seq, 8, 1, fp);
+	for (const Contig &c : mi->ctg) fwrite(&c.len, 8, 1, fp);
+	fwrite(mi->seq.data(), 1, mi->seq.size(), fp);
+	fwrite(mi->names.data(), 1, mi->names.size(), fp);
+	fwrite(mi->ki.data(), 8, mi->ki.size(), fp);
+	fwrite(mi->kb.data(), 4, mi->kb.size(), fp);
+	fclose(fp);
+	return MPA_OK;
+}
+
+// Genome-only index built from nt4 codes in memory (no k-mer table): enough for the DP operator
+// (mpa_dp_run) and used by the operator-level parity tests.  Packing follows ntseq.c:56-70.
+mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4)
+{
+	mpa_idx_s *mi = new mpa_idx_s();
+	mpa_idxopt_init(&mi->opt);
+	int64_t off = 0;
+	mi->ctg.resize(n_ctg);
+	for (int32_t i = 0; i < n_ctg; ++i) {
+		mi->ctg[i].off = off, mi->ctg[i].len = lens[i], mi->ctg[i].name = names[i];
+		off += lens[i];
+		mi->names.insert(mi->names.end(), names[i], names[i] + strlen(names[i]) + 1);
+	}
+	mi->l_seq = off;
+	mi->seq.assign((size_t)((off + 1) >> 1), 0);
+	for (int64_t p = 0; p < off; ++p) mi->seq[p >> 1] |= (uint8_t)((nt4[p] > 4 ? 4 : nt4[p]) << ((p & 1) * 4));
+	mi->ki.assign((size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit), 0);
+	compute_block_offsets(mi);
+	return mi;
+}
+
+void mpa_idx_destroy(mpa_idx_t *mi)
+{
+	if (!mi) return;
+	dev_free_index(mi);
+	delete mi;
+}
+
+int32_t mpa_idx_n_ctg(const mpa_idx_t *mi) { return (int32_t)mi->ctg.size(); }
+int64_t mpa_idx_ctg_len(const mpa_idx_t *mi, int32_t cid) { return mi->ctg[cid].len; }
+const char *mpa_idx_ctg_name(const mpa_idx_t *mi, int32_t cid) { return mi->ctg[cid].name.c_str(); }
+int64_t mpa_idx_genome_len(const mpa_idx_t *mi) { return mi->l_seq; }
+const mpa_idxopt_t *mpa_idx_opt(const mpa_idx_t *mi) { return &mi->opt; }
+int64_t mpa_idx_get_nt(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out) { return fetch_nt(mi, vid, st, en, out); }
+
+} // extern "C"

@@ -1,0 +1,58 @@
+// mpa_internal.h -- internal declarations shared by the host pipeline and the HIP executor.
+// Not part of the C ABI (that is include/mpamd.h).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "../../include/mpamd.h"
+
+namespace mpa {
+
+// ---- tables (tables.cpp) -------------------------------------------------------------------------
+// Alphabets follow the reference so that scores, hashes and output text are identical:
+// nt4: A0 C1 G2 T3 N4 (nasw-tab.c:6); aa20: ARNDCQEGHILKMFPSTWYV*X (nasw-tab.c:9); aa13: nasw-tab.c:12.
+extern const uint8_t *tab_nt4();     // [256]
+extern const uint8_t *tab_aa20();    // [256]
+extern const uint8_t *tab_aa13();    // [256]
+extern const uint8_t *tab_codon();   // [64]  codon -> aa20 for the active translation table
+extern const uint8_t *tab_codon13(); // [64]  codon -> reduced alphabet
+extern const int8_t *blosum62();     // [484]
+int set_trans_code(int code);        // ns_make_tables (nasw-tab.c:85); returns <0 if undefined
+extern const char *const kAA;        // "ARNDCQEGHILKMFPSTWYV*X"
+
+void set_error(const std::string &msg);
+
+// ---- index (index.cpp) ---------------------------------------------------------------------------
+struct Contig { int64_t off, len; std::string name; };
+
+struct DeviceIndex;                  // opaque, owned by dp executor (mpa_dp.hip)
+
+} // namespace mpa
+
+struct mpa_idx_s {
+	mpa_idxopt_t opt;
+	int64_t n_kb = 0;
+	int64_t l_seq = 0;
+	std::vector<mpa::Contig> ctg;
+	std::vector<uint8_t> seq;        // 4-bit packed, low nibble = even offset (ntseq.c:64-67)
+	std::vector<char> names;         // NUL separated, exactly as stored in the .mpi
+	std::vector<int64_t> ki;         // bucket offsets, 1<<(4*kmer-mod_bit) entries
+	std::vector<uint32_t> kb;        // global block ids
+	std::vector<uint32_t> bo;        // per (contig,strand) block offset, 2*n_ctg+1 entries (index.c:11-26)
+	uint32_t n_block = 0;
+	mpa::DeviceIndex *dev = nullptr; // genome resident in HBM (set by mpa_idx_to_device)
+};
+
+namespace mpa {
+
+inline uint8_t nt_at(const mpa_idx_s *mi, int64_t p) { return mi->seq[p >> 1] >> ((p & 1) * 4) & 0xf; }
+// strand-local window fetch; same contract as mp_ntseq_get_by_v (ntseq.c:108-114)
+int64_t fetch_nt(const mpa_idx_s *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out);
+int32_t block2vid(const mpa_idx_s *mi, uint32_t blk);        // mp_idx_block2pos (index.c:28-44)
+
+// ---- device executor (mpa_dp.hip) ----------------------------------------------------------------
+int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi);
+void dev_free_index(mpa_idx_s *mi);
+
+} // namespace mpa

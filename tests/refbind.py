@@ -114,8 +114,10 @@ def mapping_matrix(fs=23):
         m = (C.c_int8 * 484).in_dll(ref(), "ns_mat_blosum62")
         mat = np.frombuffer(m, dtype=np.int8).copy().reshape(22, 22)
     else:
-        from miniprot_amd import tables
-        mat = tables.blosum62().copy()
+        import miniprot_amd as mpa   # the product's own copy of the table (only the table is used)
+        mo = mpa.default_mapopt()
+        mpa.lib().mpa_mapopt_set_fs(C.byref(mo), 4)   # the untouched BLOSUM62 has -4 in the stop row/column
+        mat = np.array(list(mo.mat), dtype=np.int8).reshape(22, 22)
     sc = mat[20, 20]
     mat[20, :] = -fs
     mat[:, 20] = -fs

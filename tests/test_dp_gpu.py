@@ -1,0 +1,78 @@
+"""Operator-level parity on the GPU: mpa_dp_run() (HIP kernels, through the C ABI) vs the oracle, bit-exact
+on (nt_len, aa_len, score, CIGAR) for all three modes of ns_global_gs16b (nasw.h:135)."""
+import numpy as np
+import pytest
+import miniprot_amd as mpa
+import refbind
+from dpgen import make_task
+from dputil import build_workload, oracle_eval, dpopt_from_params, compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mpa.Context(0)
+    yield c
+    c.close()
+
+
+def run_case(ctx, pairs, P, rng, modes=("cigar", "left", "right")):
+    contigs, queries, tasks, meta = build_workload(pairs, rng, modes=modes, io=P.io)
+    idx = mpa.Index.from_nt4(contigs)
+    idx.to_device(ctx)
+    rst, cig = mpa.dp_run(ctx, idx, dpopt_from_params(P), queries, tasks)
+    expect = oracle_eval(pairs, meta, P)
+    bad, msg = compare(rst, cig, expect, meta, pairs)
+    idx.close()
+    assert not bad, "%d/%d DP calls differ from the oracle\n%s" % (len(bad), len(tasks), msg)
+    return len(tasks)
+
+
+def test_mixed_small(ctx, oracle_built):
+    rng = np.random.default_rng(11)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = [make_task(rng) for _ in range(600)]
+    run_case(ctx, pairs, P, rng)
+
+
+def test_shape_classes(ctx, oracle_built):
+    """al right at the lane-group boundaries of the kernels (8,16,17,32,33,64,65,128,129,250)."""
+    rng = np.random.default_rng(12)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = []
+    for al in (1, 2, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 57, 63, 64, 65, 72, 120, 128, 129, 200, 250, 300, 500):
+        for _ in range(3):
+            pairs.append(make_task(rng, al=al, p_indel=0.0))
+    run_case(ctx, pairs, P, rng)
+
+
+def test_long_windows(ctx, oracle_built):
+    """extension windows with long flanks/introns (thousands of rows), as in mp_align (align.c:259-267)."""
+    rng = np.random.default_rng(13)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = [make_task(rng, max_intron=6000, flank=5000) for _ in range(60)]
+    run_case(ctx, pairs, P, rng)
+
+
+def test_xdrop_and_params(ctx, oracle_built):
+    """non-default scoring: small x-drop (so the extension really stops), other gap/intron/frameshift costs,
+    the mammalian splice model, no length penalty."""
+    rng = np.random.default_rng(14)
+    for (go, ge, io, fs, xd, eb, sp, coef) in [(11, 1, 29, 23, 20, 5, (8, 15, 21, 30, 0, 0), 0.5),
+                                                (5, 2, 40, 17, 50, 0, (8, 15, 21, 30, 4, 4), 1.0),
+                                                (13, 1, 60, 10, 100, 10, (0, 0, 0, 0, 0, 0), 0.0)]:
+        P = refbind.DpParams(refbind.mapping_matrix(fs), go=go, ge=ge, io=io, fs=fs, xdrop=xd, end_bonus=eb, sp=sp, ie_coef=coef)
+        pairs = [make_task(rng, flank=300) for _ in range(150)]
+        run_case(ctx, pairs, P, rng)
+
+
+def test_traceback_rounds(ctx, oracle_built, monkeypatch):
+    """force several k_glob rounds by shrinking the traceback budget"""
+    monkeypatch.setenv("MPA_TB_BUDGET_MB", "1")
+    c2 = mpa.Context(0)
+    rng = np.random.default_rng(15)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = [make_task(rng, max_intron=2000) for _ in range(200)]
+    run_case(c2, pairs, P, rng, modes=("cigar",))
+    c2.close()
