@@ -1,0 +1,334 @@
+// host_core.cpp -- sorting, sketching and chaining on the host.  See host_core.h.
+//
+// Reference behaviour reproduced here:
+//   sort_pairs_by_x     radix_sort_mp128x  ksort.h:109-162 (tie order is part of the behaviour)
+//   sketch_protein      mp_sketch_prot     sketch.c:18-38
+//   sketch_nt4          mp_sketch_nt4 + mp_sketch_clean_orf  sketch.c:40-100
+//   chain_anchors       mp_chain + mp_chain_backtrack + compact_a  chain.c:8-219
+#include <algorithm>
+#include <cstdlib>
+#include "host_core.h"
+
+namespace mpa {
+
+// ------------------------------------------------------------------------------------------------
+// sorting
+// ------------------------------------------------------------------------------------------------
+// Full-key sort of 64-bit words.  Equal keys are indistinguishable, so any correct algorithm gives the
+// reference's result; this is an LSD radix sort that skips constant digits.
+void sort_u64(uint64_t *beg, uint64_t *end)
+{
+	const size_t n = (size_t)(end - beg);
+	if (n < 2) return;
+	if (n <= 256) { std::sort(beg, end); return; }
+	uint64_t all_or = 0, all_and = ~0ULL;
+	for (size_t i = 0; i < n; ++i) all_or |= beg[i], all_and &= beg[i];
+	const uint64_t varying = all_or ^ all_and;
+	std::vector<uint64_t> tmp(n);
+	uint64_t *src = beg, *dst = tmp.data();
+	for (int shift = 0; shift < 64; shift += 11) {
+		if (((varying >> shift) & 0x7ff) == 0) continue;
+		size_t cnt[2048];
+		memset(cnt, 0, sizeof(cnt));
+		for (size_t i = 0; i < n; ++i) ++cnt[(src[i] >> shift) & 0x7ff];
+		size_t acc = 0;
+		for (int d = 0; d < 2048; ++d) { size_t c = cnt[d]; cnt[d] = acc, acc += c; }
+		for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & 0x7ff]++] = src[i];
+		std::swap(src, dst);
+	}
+	if (src != beg) memcpy(beg, src, n * sizeof(uint64_t));
+}
+
+// Sort of (x,y) pairs by x whose treatment of EQUAL x must match the reference's in-place MSD radix sort
+// (it is unstable, and chain extraction / region order / extension limits consume the resulting order).
+// Runs of <= 64 elements use a stable insertion sort; longer runs are permuted digit by digit with the
+// same cycle-leader walk.
+static void pairs_insertion(Pair64 *beg, Pair64 *end)
+{
+	for (Pair64 *i = beg + 1; i < end; ++i) {
+		if (i->x >= (i - 1)->x) continue;
+		Pair64 v = *i, *j = i;
+		for (; j > beg && v.x < (j - 1)->x; --j) *j = *(j - 1);
+		*j = v;
+	}
+}
+
+static void pairs_digit_pass(Pair64 *beg, Pair64 *end, int shift)
+{
+	Pair64 *cursor[256], *limit[256];
+	size_t cnt[256];
+	memset(cnt, 0, sizeof(cnt));
+	for (Pair64 *p = beg; p != end; ++p) ++cnt[p->x >> shift & 0xff];
+	{
+		Pair64 *p = beg;
+		for (int d = 0; d < 256; ++d) cursor[d] = p, p += cnt[d], limit[d] = p;
+	}
+	for (int k = 0; k < 256;) {
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(cursor[k]->x >> shift & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = *cursor[k];             // follow the displacement cycle until an element of bucket k turns up
+		do {
+			Pair64 placed = carried;
+			carried = *cursor[d];
+			*cursor[d]++ = placed;
+			d = (int)(carried.x >> shift & 0xff);
+		} while (d != k);
+		*cursor[k]++ = carried;
+	}
+	if (shift == 0) return;
+	const int next = shift > 8 ? shift - 8 : 0;
+	Pair64 *p = beg;
+	for (int d = 0; d < 256; ++d) {
+		Pair64 *e = p + cnt[d];
+		if (cnt[d] > 64) pairs_digit_pass(p, e, next);
+		else if (cnt[d] > 1) pairs_insertion(p, e);
+		p = e;
+	}
+}
+
+void sort_pairs_by_x(Pair64 *beg, Pair64 *end)
+{
+	if (end - beg <= 64) pairs_insertion(beg, end);
+	else pairs_digit_pass(beg, end, 56);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sketching
+// ------------------------------------------------------------------------------------------------
+uint32_t hash32_mask(uint32_t key, uint32_t mask)
+{
+	key = (key + ~(key << 15)) & mask;
+	key ^= key >> 10;
+	key = (key + (key << 3)) & mask;
+	key ^= key >> 6;
+	key = (key + ~(key << 11)) & mask;
+	key ^= key >> 16;
+	return key;
+}
+
+// A rolling k-mer over the 4-bit reduced alphabet with modimizer selection (keep iff hash & (2^m - 1) == 0).
+struct KmerRoller {
+	uint32_t mask_k, mask_mod, word = 0;
+	int32_t kmer, mod_bit, run = 0;
+	KmerRoller(int32_t k, int32_t m) : mask_k((1U << k * 4) - 1), mask_mod((1U << m) - 1), kmer(k), mod_bit(m) {}
+	void reset() { word = 0, run = 0; }
+	// feeds one reduced residue; returns true and sets `bucket` when a selected k-mer ends here
+	bool feed(uint32_t c, uint32_t *bucket) {
+		word = (word << 4 | c) & mask_k;
+		if (++run < kmer) return false;
+		uint32_t h = hash32_mask(word, mask_k);
+		if (h & mask_mod) return false;
+		*bucket = h >> mod_bit;
+		return true;
+	}
+};
+
+void sketch_protein(const char *seq, int32_t len, int32_t kmer, int32_t mod_bit, std::vector<uint64_t> &out)
+{
+	const uint8_t *aa13 = tab_aa13();
+	KmerRoller roll(kmer, mod_bit);
+	out.clear();
+	for (int32_t i = 0; i < len; ++i) {
+		uint32_t c = aa13[(uint8_t)seq[i]], bucket;
+		if (c >= 14) { roll.reset(); continue; }        // stop codon / unknown residue
+		if (roll.feed(c, &bucket)) out.push_back((uint64_t)bucket << 32 | (uint32_t)i);
+	}
+}
+
+static void orf_kmers(const uint8_t *seq, int64_t st, int64_t en, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out)
+{
+	const uint8_t *c13 = tab_codon13();
+	KmerRoller roll(kmer, mod_bit);
+	for (int64_t i = st; i < en; i += 3) {
+		uint32_t bucket;
+		if (roll.feed(c13[seq[i] << 4 | seq[i + 1] << 2 | seq[i + 2]], &bucket))
+			out.push_back((uint64_t)bucket << 32 | (uint64_t)(((i + 2) >> bbit) + boff));
+	}
+}
+
+void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out)
+{
+	const uint8_t *codon_tab = tab_codon();
+	// one open reading frame per codon phase: its number of codons so far and the position of its last base
+	int64_t orf_len[3] = { 0, 0, 0 }, orf_end[3] = { -1, -1, -1 };
+	auto close = [&](int f) {
+		if (orf_len[f] >= min_aa_len) orf_kmers(seq, orf_end[f] + 1 - orf_len[f] * 3, orf_end[f] + 1, kmer, mod_bit, bbit, boff, out);
+		orf_len[f] = 0, orf_end[f] = -1;
+	};
+	out.clear();
+	int32_t valid = 0;
+	uint32_t codon = 0;
+	for (int64_t i = 0; i < len; ++i) {
+		const int f = (int)((i + 1) % 3);              // phase label of the codon that ends at i
+		if (seq[i] < 4) {
+			codon = (codon << 2 | seq[i]) & 0x3f;
+			if (++valid >= 3) {
+				if (codon_tab[codon] >= 20) close(f);     // stop codon
+				else orf_end[f] = i, ++orf_len[f];
+			}
+		} else {                                       // ambiguous base ends everything
+			close(0), close(1), close(2);
+			valid = 0, codon = 0;
+		}
+	}
+	close(0), close(1), close(2);
+	if (out.size() <= 1) return;
+	sort_u64(out.data(), out.data() + out.size());
+	out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+// ------------------------------------------------------------------------------------------------
+// chaining
+// ------------------------------------------------------------------------------------------------
+static inline float log2_poly(float x)                 // mp_log2, mppriv.h:91-99 (valid for x >= 2)
+{
+	union { float f; uint32_t i; } z = { x };
+	float r = (float)((int32_t)((z.i >> 23) & 255) - 128);
+	z.i &= ~(255u << 23);
+	z.i += 127u << 23;
+	r += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+	return r;
+}
+
+static const int32_t kIncompatible = INT32_MIN;
+
+// score of appending anchor `cur` after anchor `prev` (chain.c:112-151)
+static inline int32_t link_score(uint64_t cur, uint64_t prev, const ChainParams &p, int32_t max_dist_x, int32_t max_dist_y)
+{
+	const int32_t dq = (int32_t)cur - (int32_t)prev, dq3 = dq * 3;
+	if (dq <= 0 || dq3 > max_dist_x || dq > max_dist_y) return kIncompatible;
+	int32_t dr3, gap, gap_signed, sc;
+	if (p.bbit > 0) {
+		const int32_t bs = 1 << p.bbit;
+		dr3 = (int32_t)(((cur >> 32) - (prev >> 32)) << p.bbit);
+		if (dq3 < dr3 - bs) gap = dr3 - bs - dq3, gap_signed = -gap;
+		else if (dq3 > dr3 + bs) gap = dq3 - dr3 - bs, gap_signed = gap;
+		else gap = gap_signed = 0;
+	} else {
+		dr3 = (int32_t)((cur >> 32) - (prev >> 32));
+		if (dr3 == 0) return kIncompatible;
+		gap_signed = dq3 - dr3;
+		gap = gap_signed < 0 ? -gap_signed : gap_signed;
+	}
+	if (gap > p.bw) return kIncompatible;
+	if (p.bbit > 0) sc = std::min(p.kmer, dq);
+	else if (p.kmer <= dq && p.kmer * 3 <= dr3) sc = p.kmer;
+	else {
+		const int32_t dr = dr3 / 3;
+		sc = std::min(std::min(dr, dq), p.kmer);
+		if (dr3 != dr * 3) --sc;                        // the two anchors are in different frames
+	}
+	if (gap > 0) {
+		const float lin = (float)gap * .33334f;
+		const float lg = gap >= 2 ? p.coef_log * (log2_poly((float)(gap + 1)) - 1.0f) + 1.0f : (float)gap;
+		if (p.is_spliced && gap_signed < 0) sc -= (int)(lin < lg ? lin : lg);   // genomic side longer: possibly an intron
+		else sc -= (int)(lin + lg);
+	}
+	if (p.bbit > 0 && cur >> 32 == prev >> 32 && gap == 0) sc += 2;             // MP_BLOCK_BONUS
+	return sc;
+}
+
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
+{
+	u.clear();
+	const int64_t n = (int64_t)a.size();
+	if (n == 0) return;
+	int32_t max_dist_x = std::max(p.max_dist_x, p.bw), max_dist_y = p.max_dist_y;
+	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
+	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
+
+	std::vector<int32_t> f(n), mark(n, 0), peak(n);
+	std::vector<int64_t> pred(n);
+
+	// ---- forward pass: best predecessor of every anchor (chain.c:181-209)
+	int64_t win = 0, hot = -1;         // start of the target-distance window; anchor with the best score so far
+	int32_t hot_f = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (int64_t)(((a[i] >> 32) - (a[win] >> 32)) << p.bbit) > max_dist_x) ++win;
+		if (hot >= 0 && hot >= win) {                   // always try the best anchor seen so far, whatever max_skip does below
+			int32_t sc = hot_f + link_score(a[i], a[hot], p, max_dist_x, max_dist_y);
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		for (int64_t j = i - 1; j >= win; --j) {
+			int32_t sc = link_score(a[i], a[j], p, max_dist_x, max_dist_y);
+			if (sc == kIncompatible) continue;
+			sc += f[j];
+			if (sc > best) {
+				best = sc, best_j = j;
+				if (skipped > 0) --skipped;
+			} else if (mark[j] == (int32_t)i) {         // j is already a predecessor of a better-placed anchor
+				if (++skipped > p.max_skip) break;
+			}
+			if (pred[j] >= 0) mark[pred[j]] = (int32_t)i;
+		}
+		f[i] = best, pred[i] = best_j;
+		peak[i] = best_j >= 0 && peak[best_j] > best ? peak[best_j] : best;
+		if (hot_f < best) hot_f = best, hot = i;
+	}
+
+	// ---- extraction, best chain end first (chain.c:8-75)
+	std::vector<Pair64> ends;
+	for (int64_t i = 0; i < n; ++i)
+		if (f[i] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[i], (uint64_t)i });
+	if (ends.empty()) { a.clear(); return; }
+	sort_pairs_by_x(ends.data(), ends.data() + ends.size());
+	std::fill(mark.begin(), mark.end(), 0);
+	std::vector<int32_t> order;                        // anchor indices of the kept chains, each chain from its END backwards
+	order.reserve(n);
+	for (int64_t k = (int64_t)ends.size() - 1; k >= 0; --k) {
+		const int64_t tail = (int64_t)ends[k].y;
+		const int32_t tail_f = (int32_t)ends[k].x;
+		if (mark[tail] != 0) continue;
+		// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
+		int64_t cut = tail, walk = tail, stop = -1;
+		int32_t best_suffix = 0;
+		do {
+			mark[walk] = 2;
+			stop = walk = pred[walk];
+			const int32_t s = walk < 0 ? tail_f : tail_f - f[walk];
+			if (s > best_suffix) best_suffix = s, cut = walk;
+			else if (best_suffix - s > max_drop) break;
+		} while (walk >= 0 && mark[walk] == 0);
+		for (int64_t x = tail; x >= 0 && x != stop; x = pred[x]) mark[x] = 0;
+		// claim the anchors of the suffix
+		const size_t before = order.size();
+		int64_t x = tail;
+		for (; x != cut; x = pred[x]) order.push_back((int32_t)x), mark[x] = 1;
+		const int32_t sc = x < 0 ? tail_f : tail_f - f[x];
+		const int64_t cnt = (int64_t)(order.size() - before);
+		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u.push_back((uint64_t)sc << 32 | (uint64_t)cnt);
+		else order.resize(before);                       // rejected chains keep their anchors claimed
+	}
+	if (u.empty()) { a.clear(); return; }
+
+	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
+	std::vector<uint64_t> packed(order.size());
+	std::vector<Pair64> first(u.size());
+	{
+		size_t k = 0;
+		for (size_t c = 0; c < u.size(); ++c) {
+			const size_t cnt = (uint32_t)u[c];
+			for (size_t j = 0; j < cnt; ++j) packed[k + j] = a[order[k + cnt - 1 - j]];
+			first[c] = Pair64{ packed[k] >> 32, (uint64_t)k << 32 | (uint64_t)c };
+			k += cnt;
+		}
+	}
+	sort_pairs_by_x(first.data(), first.data() + first.size());
+	std::vector<uint64_t> u_sorted(u.size());
+	a.resize(packed.size());
+	size_t k = 0;
+	for (size_t c = 0; c < u.size(); ++c) {
+		const uint32_t which = (uint32_t)first[c].y;
+		const size_t cnt = (uint32_t)u[which], from = (size_t)(first[c].y >> 32);
+		u_sorted[c] = u[which];
+		memcpy(&a[k], &packed[from], cnt * sizeof(uint64_t));
+		k += cnt;
+	}
+	u.swap(u_sorted);
+}
+
+} // namespace mpa

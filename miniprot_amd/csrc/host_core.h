@@ -1,0 +1,68 @@
+// host_core.h -- host-side building blocks of the mapping pipeline (sorting, sketching, chaining,
+// region bookkeeping).  These are the stages the GPU does not own yet (SURVEY.md section 8 rows a1-a11,
+// a16-a19); they are written from scratch but must reproduce the reference's observable behaviour
+// exactly, including the tie order of its unstable radix sort.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "mpa_internal.h"
+
+namespace mpa {
+
+struct Pair64 { uint64_t x, y; };     // mp128_t (miniprot.h:32)
+
+// ---- sorting (ksort.h:109-162 semantics) ---------------------------------------------------------
+void sort_u64(uint64_t *beg, uint64_t *end);          // radix_sort_mp64: ties are identical values
+void sort_pairs_by_x(Pair64 *beg, Pair64 *end);        // radix_sort_mp128x: tie order is algorithm-defined
+
+// ---- sketching (sketch.c) ---------------------------------------------------------------------------
+uint32_t hash32_mask(uint32_t key, uint32_t mask);
+void sketch_protein(const char *seq, int32_t len, int32_t kmer, int32_t mod_bit, std::vector<uint64_t> &out);
+void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit,
+                int64_t boff, std::vector<uint64_t> &out);
+
+// ---- chaining (chain.c) -----------------------------------------------------------------------------
+struct ChainParams {
+	int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;
+	float coef_log;
+	int32_t is_spliced, kmer, bbit;
+};
+// a: sorted anchors, rewritten with the anchors of the kept chains (chain by chain, ascending);
+// u: one entry per chain, score<<32 | n_anchors
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u);
+
+// ---- regions (miniprot.h:119-145, hit.c) --------------------------------------------------------------
+struct Feat {
+	int64_t vs = 0, ve = 0;
+	int32_t qs = 0, qe = 0;
+	int16_t type = 0, phase = 0;
+	int32_t n_fs = 0, n_stop = 0, score = 0, n_iden = 0, blen = 0;
+	char donor[2] = { 0, 0 }, acceptor[2] = { 0, 0 };
+};
+
+struct Region {
+	int32_t off = 0, cnt = 0, id = 0, parent = 0, n_sub = 0, subsc = 0;
+	int32_t n_exon = 0, chn_sc = 0, chn_sc_ungap = 0;
+	uint32_t hash = 0, vid = 0;
+	int32_t qs = 0, qe = 0;
+	int64_t vs = 0, ve = 0;
+	std::vector<uint64_t> a;          // this region's anchors after refinement (window-relative x)
+	// alignment (mp_extra_t)
+	bool aligned = false;
+	int32_t dp_score = 0, dp_max = 0, dp_max2 = 0, blen = 0, n_fs = 0, n_stop = 0, dist_stop = 0, dist_start = 0, n_iden = 0, n_plus = 0;
+	std::vector<uint32_t> cigar;
+	std::vector<Feat> feat;
+};
+
+int32_t chain_score_ungapped(const uint64_t *a, int32_t n, int32_t kmer);                  // hit.c:18-30
+void regions_from_chains(const mpa_idx_s *mi, const std::vector<uint64_t> &u, const std::vector<uint64_t> &a, std::vector<Region> &out); // hit.c:32-76
+void sort_regions(std::vector<Region> &r);                                                  // hit.c:97-126
+void assign_parents(float mask_level, int mask_len, std::vector<Region> &r, int sub_diff);  // hit.c:128-187
+void select_secondary(float pri_ratio, int min_diff, int best_n, std::vector<Region> &r);   // hit.c:189-236
+void prefer_multi_exon(std::vector<Region> &r, int32_t single_penalty);                     // hit.c:238-250
+// hit.c:252-287: per region (left<<32 | right) extension limits; anchors==nullptr means "use genome coordinates"
+void extension_limits(const mpa_idx_s *mi_or_null, const std::vector<Region> &r, const std::vector<uint64_t> *first_anchor_x,
+                      int32_t min_ext, int32_t max_ext, std::vector<uint64_t> &ext);
+
+} // namespace mpa

@@ -1,0 +1,655 @@
+// host_map.cpp -- the batched replacement of mp_map() (map.c:143-240) and mp_align() (align.c:239-342).
+//
+// The reference maps one protein per thread from seeding to CIGAR.  Here a whole batch of proteins moves
+// through the pipeline stage by stage so that every spliced-DP call of the batch can be issued to the GPU
+// together:
+//
+//   stage A (host, threaded over queries)   sketch -> index lookup -> sort -> pre-chain -> chain ->
+//                                           regions -> refine (k=5 re-seeding + re-chaining) -> select ->
+//                                           extension limits -> per-region alignment plan
+//   DP round 1 (GPU)   left + right extensions of every region            ns_global_gs16b EXT_LEFT/EXT_RIGHT
+//   DP round 2 (GPU)   the io_end retries of align.c:290-296,324-330
+//   DP round 3 (GPU)   every gap between kept anchors, plus the two extension spans, with traceback
+//   stage B (host, threaded)                CIGAR assembly, mp_extra_* statistics, final ranking
+//
+// The object is a plain stage machine (mpa_batch_*): it hands out DP tasks and takes DP results, and does
+// not care who executes them.  mpa_map_batch() drives it with the HIP executor; the CPU-only tests drive
+// it with the oracle to check the host logic against the reference's output.
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <cstring>
+#include <thread>
+#include "host_core.h"
+
+namespace mpa {
+
+struct Segment {                     // one mp_align_seq() call (align.c:62-80)
+	int32_t ne0, ne1, ae0, ae1;      // window-relative nt span (w.r.t. vs0) and protein span
+	int32_t task = -1;               // DP task index of round 3, -1 = ungapped shortcut
+	int32_t score = 0;
+};
+
+struct AlignPlan {                   // the state of one mp_align() call
+	int32_t reg = -1;
+	int64_t as = 0, ae = 0, vs0 = 0, vs1 = 0;
+	int32_t i0 = 0, as1 = 0;
+	int32_t t_left = -1, t_left2 = -1, t_right = -1, t_right2 = -1;
+	int32_t l_nt = 0, l_aa = 0, r_nt = 0, r_aa = 0;
+	int64_t mid_ve = 0;              // r->ve / r->qe after the gap-patching loop
+	int32_t mid_qe = 0;
+	bool has_right = false;
+	std::vector<Segment> segs;
+};
+
+struct QueryState {
+	int32_t qid = 0, qlen = 0;
+	const char *seq = nullptr;
+	std::vector<Region> regs;
+	std::vector<AlignPlan> plans;
+};
+
+} // namespace mpa
+
+using namespace mpa;
+
+struct mpa_result_s {
+	int32_t n_seq = 0;
+	std::vector<mpa_hit_t> hits;
+	std::vector<int64_t> hit_off;
+	std::vector<uint32_t> cigars;
+	std::vector<mpa_feat_t> feats;
+};
+
+struct mpa_batch_s {
+	const mpa_idx_s *mi = nullptr;
+	mpa_mapopt_t opt;
+	mpa_dpopt_t dpopt;
+	mpa_qbatch_t q;
+	int n_threads = 1;
+	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
+	std::vector<QueryState> qs;
+	std::vector<mpa_dp_task_t> tasks;
+	std::vector<std::pair<int32_t, int32_t>> task_owner;   // (query, plan) of every task
+};
+
+namespace mpa {
+
+template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
+{
+	if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+	std::atomic<int64_t> next(0);
+	std::vector<std::thread> pool;
+	const int nt = (int)std::min<int64_t>(n_threads, n);
+	for (int t = 0; t < nt; ++t)
+		pool.emplace_back([&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } });
+	for (auto &th : pool) th.join();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage A
+// ------------------------------------------------------------------------------------------------
+
+// mp_cal_max_occ (map.c:126-141): boxplot-style cutoff on the occurrence counts of the query's seeds
+static int32_t occurrence_cutoff(const mpa_idx_s *mi, const std::vector<uint64_t> &seeds)
+{
+	const int64_t n = (int64_t)seeds.size(), n_bucket = (int64_t)mi->ki.size();
+	std::vector<uint64_t> cnt(n);
+	for (int64_t i = 0; i < n; ++i) {
+		const int64_t b = (int64_t)(seeds[i] >> 32);
+		const int64_t en = b + 1 < n_bucket ? mi->ki[b + 1] : mi->n_kb;
+		cnt[i] = (uint64_t)(en - mi->ki[b]);
+	}
+	sort_u64(cnt.data(), cnt.data() + n);
+	const uint64_t q25 = cnt[(int64_t)(n * .25 + .499)], q75 = cnt[(int64_t)(n * .75 + .499)];
+	return (int32_t)(q75 + (q75 - q25) * 1.5 + 10.);
+}
+
+// mp_refine_reg (map.c:32-111): re-seed the region's window with all 5-mers at base resolution, re-chain
+static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const char *aa, int32_t l_aa, Region &r, int32_t extl, int32_t extr)
+{
+	const int32_t kmer = opt.kmer2, is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
+	const int64_t ctg_len = mi->ctg[r.vid >> 1].len;
+	const int64_t as = r.vs > extl ? r.vs - extl : 0;
+	const int64_t ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
+	std::vector<uint8_t> nt((size_t)(ae - as));
+	fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data());
+	std::vector<uint64_t> sd, sq;
+	sketch_nt4(nt.data(), ae - as, mi->opt.min_aa_len, kmer, 0, 0, 0, sd);
+	sketch_protein(aa, l_aa, kmer, 0, sq);
+	sd.reserve(sd.size() + sq.size());
+	for (uint64_t x : sq) sd.push_back(x | 1ULL << 31);       // tag query k-mers; they sort after reference ones of the same hash
+	sort_u64(sd.data(), sd.data() + sd.size());
+	// all (reference position, query position) pairs of k-mers sharing a hash, unless there are too many
+	std::vector<uint64_t> a;
+	const size_t n = sd.size();
+	for (size_t k = 0, i = 1; i <= n; ++i) {
+		if (i < n && sd[k] >> 32 == sd[i] >> 32) continue;
+		size_t j = k;
+		while (j < i && !(sd[j] >> 31 & 1)) ++j;
+		const int64_t n1 = (int64_t)(j - k), n2 = (int64_t)(i - j);
+		if (n1 > 0 && n2 > 0 && (int32_t)n1 * (int32_t)n2 <= opt.max_ava)
+			for (size_t i1 = k; i1 < j; ++i1)
+				for (size_t i2 = j; i2 < i; ++i2)
+					a.push_back((uint64_t)(uint32_t)sd[i1] << 32 | ((uint32_t)sd[i2] << 1 >> 1));
+		k = i;
+	}
+	sort_u64(a.data(), a.data() + a.size());
+	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
+	                opt.chn_coef_log, is_splice, kmer, 0 };
+	std::vector<uint64_t> u;
+	chain_anchors(cp, a, u);
+	if (u.empty()) { r.cnt = 0, r.off = -1, r.a.clear(); return; }
+	// the first chain with the highest score
+	size_t best = 0, skip = 0;
+	for (size_t i = 1; i < u.size(); ++i) if ((int32_t)(u[best] >> 32) < (int32_t)(u[i] >> 32)) best = i;
+	for (size_t i = 0; i < best; ++i) skip += (uint32_t)u[i];
+	const size_t n_a = (uint32_t)u[best];
+	r.a.assign(a.begin() + skip, a.begin() + skip + n_a);
+	r.chn_sc = (int32_t)(u[best] >> 32);
+	r.cnt = (int32_t)n_a, r.off = 0;
+	r.qs = (int32_t)(uint32_t)r.a[0] - (kmer - 1);
+	r.qe = (int32_t)(uint32_t)r.a[n_a - 1] + 1;
+	r.vs = as + (int64_t)(r.a[0] >> 32) + 1 - 3 * kmer;
+	r.ve = as + (int64_t)(r.a[n_a - 1] >> 32) + 1;
+	for (uint64_t &x : r.a) x = (uint64_t)((int64_t)(x >> 32) + as - r.vs) << 32 | (x << 32 >> 32);
+	r.chn_sc_ungap = chain_score_ungapped(r.a.data(), r.cnt, kmer);
+}
+
+// mp_filter_seed (align.c:6-31): mark (bit 31) anchors inside tight, in-frame runs, trimmed at both ends
+static void mark_reliable_anchors(std::vector<uint64_t> &a, int32_t max_aa_dist, int32_t min_cnt, int32_t kmer2, int32_t trim)
+{
+	const int32_t cnt = (int32_t)a.size();
+	for (int32_t i = 0; i < cnt; ++i) {
+		int32_t j = i + 1;
+		for (; j < cnt; ++j) {
+			const int32_t dx = (int32_t)(a[j] >> 32) - (int32_t)(a[j - 1] >> 32), dy = (int32_t)a[j] - (int32_t)a[j - 1];
+			if (dx % 3 != 0 || dx > max_aa_dist * 3 || dy > max_aa_dist) break;
+		}
+		if (j - i < min_cnt) continue;
+		int32_t k = j - 2, t = (int32_t)a[j - 1];
+		while (k >= i && t - (int32_t)a[k] < trim) --k;
+		t = (int32_t)a[i] + 1 - kmer2;
+		while (i < k && (int32_t)a[i] + 1 - t < trim) ++i;
+		for (; i <= k; ++i) a[i] |= 1ULL << 31;
+		i = j - 1;
+	}
+}
+
+static inline uint8_t codon_aa(const uint8_t *nt)
+{
+	return nt[0] > 3 || nt[1] > 3 || nt[2] > 3 ? 21 : tab_codon()[nt[0] << 4 | nt[1] << 2 | nt[2]];
+}
+
+// first half of mp_align (align.c:239-301,316-323): window, left/right extension tasks
+static bool plan_alignment(const mpa_batch_s *b, QueryState &qs, int32_t ridx, int32_t extl0, int32_t extr0, AlignPlan &pl)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	Region &r = qs.regs[ridx];
+	mark_reliable_anchors(r.a, 6, 3, opt.kmer2, opt.kmer2 + 1);
+	int32_t i0 = 0;
+	while (i0 < r.cnt && !(r.a[i0] >> 31 & 1)) ++i0;
+	if (i0 == r.cnt) { r.cnt = 0; return false; }
+	int32_t extl = opt.max_ext, extr = opt.max_ext;
+	if (r.qs >= 10) extl = opt.max_intron / 2;
+	if (qs.qlen - r.qe >= 10) extr = opt.max_intron / 2;
+	if (extl0 > 0) extl = std::min(extl, extl0);
+	if (extr0 > 0) extr = std::min(extr, extr0);
+	const int64_t ctg_len = b->mi->ctg[r.vid >> 1].len;
+	pl.reg = ridx, pl.i0 = i0;
+	pl.as = r.vs > extl ? r.vs - extl : 0;
+	pl.ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
+	pl.vs0 = r.vs;
+	pl.vs1 = pl.vs0 + (int64_t)(r.a[i0] >> 32) + 1;
+	pl.as1 = (int32_t)((uint32_t)r.a[i0] << 1 >> 1) + 1;
+	// where the gap-patching loop will leave r->ve / r->qe: the end of the last kept anchor
+	int32_t ne = 0, ae = 0;
+	for (int32_t i = i0; i < r.cnt; ++i)
+		if (r.a[i] >> 31 & 1) ne = (int32_t)(r.a[i] >> 32) + 1, ae = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
+	pl.mid_ve = ne + pl.vs0, pl.mid_qe = ae;
+	pl.has_right = pl.mid_qe < qs.qlen && pl.mid_ve < pl.ae;
+	return true;
+}
+
+static mpa_dp_task_t make_task(const QueryState &qs, const Region &r, int64_t nt_off, int64_t nl, int32_t aa_off, int32_t al, int32_t flag, int32_t io)
+{
+	mpa_dp_task_t t;
+	t.nt_off = nt_off, t.vid = (int32_t)r.vid, t.nl = (int32_t)nl, t.qid = qs.qid, t.aa_off = aa_off, t.al = al, t.flag = flag, t.io = io, t.tag = 0;
+	return t;
+}
+
+// mp_extra_stop / mp_extra_start (align.c:214-237)
+static int32_t dist_to_stop(const mpa_idx_s *mi, const Region &r, int64_t ae)
+{
+	uint8_t c[3];
+	for (int64_t j = r.ve; j + 2 < ae; j += 3) {
+		fetch_nt(mi, (int32_t)r.vid, j, j + 3, c);
+		if (codon_aa(c) == 20) return (int32_t)(j - r.ve);
+	}
+	return -1;
+}
+
+static int32_t dist_to_start(const mpa_idx_s *mi, const Region &r, int64_t as, int64_t ae)
+{
+	uint8_t c[3];
+	for (int64_t j = r.vs; j >= as && j + 2 < ae; j -= 3) {
+		fetch_nt(mi, (int32_t)r.vid, j, j + 3, c);
+		const uint8_t aa = codon_aa(c);
+		if (aa == 20) break;
+		if (aa == 12) return (int32_t)(r.vs - j);
+	}
+	return -1;
+}
+
+// mp_extra_cal (align.c:82-201): walk the CIGAR once, accumulate identity/score statistics and exon features
+static void summarize_alignment(const mpa_idx_s *mi, const mpa_mapopt_t &opt, Region &r, const char *aa_full, int32_t qlen, int64_t win_end)
+{
+	const int64_t l_nt = win_end - r.vs;
+	std::vector<uint8_t> ntv((size_t)std::max<int64_t>(l_nt, 1));
+	fetch_nt(mi, (int32_t)r.vid, r.vs, win_end, ntv.data());
+	const uint8_t *nt = ntv.data(), *aa20 = tab_aa20();
+	const char *aa = aa_full + r.qs;
+	const char *nt_char = "ACGTN";
+	const bool has_stop = r.qe == qlen && r.dist_stop == 0;
+	int32_t n_intron = 0;
+	for (uint32_t c : r.cigar) { uint32_t op = c & 0xf; n_intron += (op == 3 || op == 12 || op == 13); }
+	r.n_exon = n_intron + 1;
+	r.feat.assign((size_t)r.n_exon + (has_stop ? 1 : 0), Feat());
+	r.blen = r.n_iden = r.n_plus = r.n_fs = r.n_stop = r.dp_max = 0;
+	int32_t nl = 0, al = 0, ft = 0;
+	int32_t blen0 = 0, iden0 = 0, score0 = 0, fs0 = 0, stop0 = 0, phase0 = 0, qs0 = r.qs;
+	int64_t vs0 = r.vs;
+	char acc0[2] = { 0, 0 };
+	auto score_codon = [&](uint8_t nt_aa, int32_t aa_idx) {
+		const uint8_t q = aa20[(uint8_t)aa[aa_idx]];
+		const int32_t s = opt.mat[nt_aa * opt.asize + q];
+		r.n_stop += nt_aa == 20, r.n_iden += nt_aa == q, r.n_plus += s > 0, r.dp_max += s;
+	};
+	auto close_exon = [&](Feat &f, int64_t ve) {
+		f.type = 0, f.vs = vs0, f.ve = ve, f.qs = qs0, f.qe = r.qs + al, f.phase = (int16_t)phase0;
+		f.blen = r.blen - blen0, f.n_iden = r.n_iden - iden0, f.n_fs = r.n_fs - fs0, f.n_stop = r.n_stop - stop0, f.score = r.dp_max - score0;
+		if (ft > 0) f.acceptor[0] = acc0[0], f.acceptor[1] = acc0[1];
+	};
+	for (uint32_t c : r.cigar) {
+		const int32_t op = c & 0xf, len = (int32_t)(c >> 4);
+		if (op == 0) {                                             // M
+			for (int32_t l = 0; l < len; ++l) score_codon(codon_aa(nt + nl + 3 * l), al + l);
+			nl += len * 3, al += len, r.blen += len * 3;
+		} else if (op == 1) {                                      // I
+			r.dp_max -= opt.go + opt.ge * len;
+			al += len, r.blen += len * 3;
+		} else if (op == 2) {                                      // D: in-frame stop codons inside deletions count
+			for (int32_t l = 0; l < len; ++l) r.n_stop += codon_aa(nt + nl + 3 * l) == 20;
+			r.dp_max -= opt.go + opt.ge * len;
+			nl += len * 3, r.blen += len * 3;
+		} else if (op == 10) {                                     // F
+			r.dp_max -= opt.fs;
+			nl += len, r.blen += len, r.n_fs++;
+		} else if (op == 11) {                                     // G
+			r.dp_max -= opt.fs;
+			nl += len, ++al, r.blen += 3, r.n_fs++;
+		} else if (op == 3 || op == 12 || op == 13) {              // N / U / V introns
+			if (op != 3) {                                         // the codon split by a phase-1/2 intron
+				uint8_t cod[3];
+				if (op == 12) cod[0] = nt[nl], cod[1] = nt[nl + len - 2], cod[2] = nt[nl + len - 1];
+				else cod[0] = nt[nl], cod[1] = nt[nl + 1], cod[2] = nt[nl + len - 1];
+				score_codon(codon_aa(cod), al);
+				r.blen += 3;
+			}
+			Feat &f = r.feat[ft];
+			int64_t ve;
+			if (op == 3) ve = r.vs + nl;
+			else if (op == 12) ve = r.vs + nl + 1;
+			else ve = r.vs + nl + 2;
+			close_exon(f, ve);
+			++ft;
+			if (op == 3) vs0 = r.vs + nl + len, phase0 = 0;
+			else if (op == 12) vs0 = r.vs + nl + len - 2, phase0 = 2;
+			else vs0 = r.vs + nl + len - 1, phase0 = 1;
+			f.donor[0] = f.ve - r.vs < l_nt ? nt_char[nt[f.ve - r.vs]] : '.';
+			f.donor[1] = f.ve - r.vs + 1 < l_nt ? nt_char[nt[f.ve - r.vs + 1]] : '.';
+			qs0 = f.qe, fs0 = r.n_fs, stop0 = r.n_stop, score0 = r.dp_max, blen0 = r.blen, iden0 = r.n_iden;
+			acc0[0] = vs0 - r.vs >= 2 ? nt_char[nt[vs0 - r.vs - 2]] : '.';
+			acc0[1] = vs0 - r.vs >= 1 ? nt_char[nt[vs0 - r.vs - 1]] : '.';
+			nl += len, al += op != 3;
+		}
+	}
+	close_exon(r.feat[ft], r.vs + nl);
+	++ft;
+	if (has_stop) {
+		Feat &f = r.feat[ft++];
+		f.type = 1, f.vs = r.ve, f.ve = r.ve + 3, f.qs = f.qe = r.qe + al, f.phase = 0, f.n_fs = 0, f.blen = 3, f.n_iden = 0;
+	}
+	assert(nl == r.ve - r.vs && al == r.qe - r.qs);
+}
+
+static void append_cigar(std::vector<uint32_t> &cig, uint32_t op, int32_t len)   // ns_push_cigar, nasw.h:141-152
+{
+	if (!cig.empty() && (cig.back() & 0xf) == op && op != 10 && op != 11) cig.back() += (uint32_t)len << 4;
+	else cig.push_back((uint32_t)len << 4 | op);
+}
+
+// everything of mp_map() up to and including the alignment plans (map.c:143-226)
+static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
+{
+	const mpa_idx_s *mi = b->mi;
+	const mpa_mapopt_t &opt = b->opt;
+	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
+	const int64_t n_bucket = (int64_t)mi->ki.size();
+	std::vector<uint64_t> sd, a, u;
+	sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
+	sort_u64(sd.data(), sd.data() + sd.size());
+	int32_t max_occ = opt.max_occ;
+	if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
+	// anchors: every occurrence of every seed that is not too frequent (map.c:163-177)
+	for (uint64_t s : sd) {
+		const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+		if (en - st > max_occ) continue;
+		for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | (uint32_t)s);
+	}
+	sort_u64(a.data(), a.data() + a.size());
+	if (!(opt.flag & MPA_MF_NO_PRE_CHAIN) && is_splice) {         // keep anchors that have a neighbour within one block
+		const int32_t w = 1 << mi->opt.bbit;
+		ChainParams pre{ w, w, w, opt.max_chn_max_skip, opt.max_chn_iter, 2, 0, opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
+		chain_anchors(pre, a, u);
+		sort_u64(a.data(), a.data() + a.size());
+	}
+	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
+	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
+	chain_anchors(cp, a, u);
+	std::vector<Region> &regs = qs.regs;
+	regions_from_chains(mi, u, a, regs);
+	sort_regions(regs);
+	assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
+	select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
+	// refinement at base resolution (map.c:205-222)
+	std::vector<uint64_t> ext;
+	extension_limits(nullptr, regs, &a, 100, opt.max_ext, ext);
+	{
+		std::vector<Region> kept;
+		for (size_t i = 0; i < regs.size(); ++i) {
+			refine_region(mi, opt, qs.seq, qs.qlen, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
+			if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
+		}
+		regs.swap(kept);
+	}
+	sort_regions(regs);
+	assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
+	select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
+	if (opt.flag & MPA_MF_NO_ALIGN) return;
+	// alignment plans (map.c:223-227, align.c:239-267)
+	extension_limits(mi, regs, nullptr, 100, opt.max_intron / 2, ext);
+	for (size_t i = 0; i < regs.size(); ++i) {
+		AlignPlan pl;
+		if (plan_alignment(b, qs, (int32_t)i, (int32_t)(ext[i] >> 32), (int32_t)ext[i], pl)) qs.plans.push_back(std::move(pl));
+	}
+}
+
+// the tail of mp_map() after mp_align() (map.c:228-237)
+static void stage_finish(mpa_batch_s *b, QueryState &qs)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	if (opt.flag & MPA_MF_NO_ALIGN) return;
+	std::vector<Region> kept;
+	for (Region &r : qs.regs) if (r.aligned) kept.push_back(std::move(r));
+	qs.regs.swap(kept);
+	sort_regions(qs.regs);
+	prefer_multi_exon(qs.regs, opt.io);
+	assign_parents(opt.mask_level, opt.mask_len, qs.regs, b->mi->opt.kmer);
+	select_secondary(opt.pri_ratio, b->mi->opt.kmer * 2, opt.best_n, qs.regs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DP rounds
+// ------------------------------------------------------------------------------------------------
+static void emit_round1(mpa_batch_s *b)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
+		QueryState &qs = b->qs[qi];
+		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
+			AlignPlan &pl = qs.plans[pi];
+			const Region &r = qs.regs[pl.reg];
+			pl.t_left = (int32_t)b->tasks.size();
+			b->tasks.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT, opt.io));
+			b->task_owner.emplace_back((int32_t)qi, (int32_t)pi);
+			if (pl.has_right) {
+				pl.t_right = (int32_t)b->tasks.size();
+				b->tasks.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
+				b->task_owner.emplace_back((int32_t)qi, (int32_t)pi);
+			}
+		}
+	}
+}
+
+static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	std::vector<mpa_dp_task_t> next;
+	std::vector<std::pair<int32_t, int32_t>> owner;
+	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
+		QueryState &qs = b->qs[qi];
+		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
+			AlignPlan &pl = qs.plans[pi];
+			const Region &r = qs.regs[pl.reg];
+			pl.l_nt = rst[pl.t_left].nt_len, pl.l_aa = rst[pl.t_left].aa_len;
+			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
+				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
+				pl.t_left2 = (int32_t)next.size();
+				next.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT, opt.io_end));
+				owner.emplace_back((int32_t)qi, (int32_t)pi);
+			}
+			if (pl.has_right) {
+				pl.r_nt = rst[pl.t_right].nt_len, pl.r_aa = rst[pl.t_right].aa_len;
+				if (pl.r_aa < qs.qlen - pl.mid_qe && pl.r_nt < opt.max_ext && opt.io > opt.io_end) {
+					const int64_t l_ext = std::min<int64_t>(pl.ae - pl.mid_ve, opt.max_ext);
+					pl.t_right2 = (int32_t)next.size();
+					next.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
+					owner.emplace_back((int32_t)qi, (int32_t)pi);
+				}
+			}
+		}
+	}
+	b->tasks.swap(next);
+	b->task_owner.swap(owner);
+}
+
+static int32_t ungapped_score(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Region &r, int64_t nt_off, int32_t alen, const char *aa)
+{
+	std::vector<uint8_t> nt((size_t)alen * 3);
+	fetch_nt(mi, (int32_t)r.vid, nt_off, nt_off + (int64_t)alen * 3, nt.data());
+	const uint8_t *aa20 = tab_aa20();
+	int32_t sc = 0;
+	for (int32_t j = 0; j < alen; ++j) sc += opt.mat[codon_aa(&nt[j * 3]) * opt.asize + aa20[(uint8_t)aa[j]]];
+	return sc;
+}
+
+static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	std::vector<mpa_dp_task_t> next;
+	std::vector<std::pair<int32_t, int32_t>> owner;
+	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
+		QueryState &qs = b->qs[qi];
+		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
+			AlignPlan &pl = qs.plans[pi];
+			Region &r = qs.regs[pl.reg];
+			if (pl.t_left2 >= 0 && rst[pl.t_left2].aa_len == pl.as1) pl.l_nt = rst[pl.t_left2].nt_len, pl.l_aa = rst[pl.t_left2].aa_len;
+			if (pl.t_right2 >= 0 && rst[pl.t_right2].aa_len == qs.qlen - pl.mid_qe) pl.r_nt = rst[pl.t_right2].nt_len, pl.r_aa = rst[pl.t_right2].aa_len;
+			// region start after the left extension (align.c:297-300)
+			r.vs = pl.vs1 - pl.l_nt;
+			r.qs = pl.as1 - pl.l_aa;
+			int32_t ne0 = (int32_t)(r.vs - pl.vs0), ae0 = r.qs;
+			auto add_segment = [&](int32_t ne1, int32_t ae1) {
+				Segment s;
+				s.ne0 = ne0, s.ne1 = ne1, s.ae0 = ae0, s.ae1 = ae1;
+				const int32_t nlen = ne1 - ne0, alen = ae1 - ae0;
+				if (nlen == alen * 3 && alen <= opt.kmer2) {
+					s.task = -1;
+					s.score = ungapped_score(b->mi, opt, r, pl.vs0 + ne0, alen, qs.seq + ae0);
+				} else {
+					s.task = (int32_t)next.size();
+					next.push_back(make_task(qs, r, pl.vs0 + ne0, nlen, ae0, alen, MPA_F_CIGAR, opt.io));
+					owner.emplace_back((int32_t)qi, (int32_t)pi);
+				}
+				pl.segs.push_back(s);
+			};
+			for (int32_t i = pl.i0; i < r.cnt; ++i) {                 // gaps between kept anchors (align.c:305-313)
+				if (!(r.a[i] >> 31 & 1)) continue;
+				const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
+				add_segment(ne1, ae1);
+				ne0 = ne1, ae0 = ae1;
+			}
+			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0)              // the accepted right-extension span (align.c:331)
+				add_segment(ne0 + pl.r_nt, ae0 + pl.r_aa);
+		}
+	}
+	b->tasks.swap(next);
+	b->task_owner.swap(owner);
+}
+
+static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
+{
+	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t qi) {
+		QueryState &qs = b->qs[qi];
+		for (AlignPlan &pl : qs.plans) {
+			Region &r = qs.regs[pl.reg];
+			int32_t score = 0;
+			r.cigar.clear();
+			for (Segment &s : pl.segs) {
+				if (s.task < 0) append_cigar(r.cigar, 0, s.ae1 - s.ae0), score += s.score;
+				else {
+					const mpa_dp_rst_t &o = rst[s.task];
+					for (int32_t k = 0; k < o.n_cigar; ++k) append_cigar(r.cigar, pool[o.cigar_off + k] & 0xf, (int32_t)(pool[o.cigar_off + k] >> 4));
+					score += o.score;
+				}
+			}
+			r.ve = pl.mid_ve, r.qe = pl.mid_qe;
+			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0) r.ve += pl.r_nt, r.qe += pl.r_aa;
+			r.aligned = true;
+			r.dp_score = score, r.dp_max2 = 0;
+			r.dist_stop = dist_to_stop(b->mi, r, pl.ae);
+			r.dist_start = dist_to_start(b->mi, r, pl.as, pl.ae);
+			summarize_alignment(b->mi, b->opt, r, qs.seq, qs.qlen, pl.ae);
+		}
+		stage_finish(b, qs);
+	});
+}
+
+} // namespace mpa
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+{
+	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
+	mpa_batch_s *b = new mpa_batch_s();
+	b->mi = mi, b->opt = *opt, b->q = *q, b->n_threads = n_threads > 1 ? n_threads : 1;
+	mpa_dpopt_from_mapopt(opt, &b->dpopt);
+	b->qs.resize(q->n_seq);
+	for (int32_t i = 0; i < q->n_seq; ++i) {
+		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
+	}
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); });
+	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
+	return b;
+}
+
+int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpopt_t *opt)
+{
+	if (opt) *opt = b->dpopt;
+	if (b->round == 0) {
+		emit_round1(b);
+		b->round = 1;
+		if (b->tasks.empty()) { take_round3(b, nullptr, nullptr); b->round = 4; }   // nothing to align at all
+	}
+	// skip empty rounds (e.g. no retry needed anywhere)
+	while (b->round >= 1 && b->round <= 3 && b->tasks.empty()) {
+		if (b->round == 1) break;
+		if (b->round == 2) { take_round2_emit_round3(b, nullptr); b->round = 3; }
+		else { take_round3(b, nullptr, nullptr); b->round = 4; }
+	}
+	if (b->round >= 4) { *tasks = nullptr; return 0; }
+	*tasks = b->tasks.data();
+	return (int64_t)b->tasks.size();
+}
+
+int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool)
+{
+	if (b->round == 1) { take_round1_emit_round2(b, rst); b->round = 2; }
+	else if (b->round == 2) { take_round2_emit_round3(b, rst); b->round = 3; }
+	else if (b->round == 3) { take_round3(b, rst, cigar_pool); b->round = 4; b->tasks.clear(); }
+	else { set_error("mpa_batch_dp_results called out of sequence"); return MPA_ERR_ARG; }
+	return MPA_OK;
+}
+
+mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
+{
+	mpa_result_s *res = new mpa_result_s();
+	res->n_seq = (int32_t)b->qs.size();
+	res->hit_off.assign(b->qs.size() + 1, 0);
+	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
+		QueryState &qs = b->qs[qi];
+		res->hit_off[qi] = (int64_t)res->hits.size();
+		for (const Region &r : qs.regs) {
+			mpa_hit_t h;
+			memset(&h, 0, sizeof(h));
+			h.qid = qs.qid, h.id = r.id, h.parent = r.parent, h.n_sub = r.n_sub, h.subsc = r.subsc, h.cnt = r.cnt;
+			h.n_exon = r.n_exon, h.chn_sc = r.chn_sc, h.chn_sc_ungap = r.chn_sc_ungap, h.vid = r.vid;
+			h.qs = r.qs, h.qe = r.qe, h.vs = r.vs, h.ve = r.ve, h.has_aln = r.aligned;
+			h.dp_score = r.dp_score, h.dp_max = r.dp_max, h.dp_max2 = r.dp_max2, h.blen = r.blen, h.n_fs = r.n_fs, h.n_stop = r.n_stop;
+			h.dist_stop = r.dist_stop, h.dist_start = r.dist_start, h.n_iden = r.n_iden, h.n_plus = r.n_plus;
+			h.n_cigar = (int32_t)r.cigar.size(), h.n_feat = (int32_t)r.feat.size();
+			h.cigar_off = (int64_t)res->cigars.size(), h.feat_off = (int64_t)res->feats.size();
+			res->cigars.insert(res->cigars.end(), r.cigar.begin(), r.cigar.end());
+			for (const Feat &f : r.feat) {
+				mpa_feat_t o;
+				memset(&o, 0, sizeof(o));
+				o.vs = f.vs, o.ve = f.ve, o.qs = f.qs, o.qe = f.qe, o.type = f.type, o.phase = f.phase, o.n_fs = f.n_fs, o.n_stop = f.n_stop;
+				o.score = f.score, o.n_iden = f.n_iden, o.blen = f.blen;
+				memcpy(o.donor, f.donor, 2), memcpy(o.acceptor, f.acceptor, 2);
+				res->feats.push_back(o);
+			}
+			res->hits.push_back(h);
+		}
+	}
+	res->hit_off[b->qs.size()] = (int64_t)res->hits.size();
+	delete b;
+	return res;
+}
+
+int64_t mpa_result_n_hit(const mpa_result_t *r) { return (int64_t)r->hits.size(); }
+const mpa_hit_t *mpa_result_hits(const mpa_result_t *r) { return r->hits.data(); }
+const int64_t *mpa_result_hit_off(const mpa_result_t *r) { return r->hit_off.data(); }
+const uint32_t *mpa_result_cigars(const mpa_result_t *r) { return r->cigars.data(); }
+const mpa_feat_t *mpa_result_feats(const mpa_result_t *r) { return r->feats.data(); }
+void mpa_result_destroy(mpa_result_t *r) { delete r; }
+
+int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
+{
+	*out = nullptr;
+	if (!ctx) { set_error("mpa_map_batch needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
+	mpa_batch_t *b = mpa_batch_begin(mi, opt, q, n_threads);
+	if (!b) return MPA_ERR_ARG;
+	const mpa_dp_task_t *tasks;
+	mpa_dpopt_t dpopt;
+	int64_t n;
+	std::vector<mpa_dp_rst_t> rst;
+	while ((n = mpa_batch_dp_tasks(b, &tasks, &dpopt)) > 0) {
+		uint32_t *pool = nullptr;
+		int64_t n_pool = 0;
+		rst.resize((size_t)n);
+		int rc = mpa_dp_run(ctx, mi, &dpopt, q, n, tasks, rst.data(), &pool, &n_pool);
+		if (rc != MPA_OK) { free(pool); delete b; return rc; }
+		rc = mpa_batch_dp_results(b, rst.data(), pool);
+		free(pool);
+		if (rc != MPA_OK) { delete b; return rc; }
+	}
+	*out = mpa_batch_finish(b);
+	return MPA_OK;
+}
+
+} // extern "C"

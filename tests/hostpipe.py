@@ -1,0 +1,88 @@
+"""Drive the host stage machine (mpa_batch_*) with a pluggable DP executor.
+
+`oracle_executor` evaluates every DP task with the C restatement in oracle/ -- this is how the CPU-only
+tests check the HOST logic of the product against the reference's output.  The product's own path
+(mpa_map_batch) uses the HIP executor instead and never touches oracle/."""
+import ctypes as C
+import gzip
+import numpy as np
+import miniprot_amd as mpa
+import refbind
+
+
+def read_fasta(path):
+    op = gzip.open if path.endswith(".gz") else open
+    names, seqs, cur = [], [], []
+    with op(path, "rb") as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(b">"):
+                if names:
+                    seqs.append(b"".join(cur))
+                names.append(line[1:].split()[0].decode())
+                cur = []
+            elif line:
+                cur.append(line)
+    if names:
+        seqs.append(b"".join(cur))
+    return names, seqs
+
+
+def oracle_executor(idx, queries, dpopt, tasks):
+    mat = np.array(list(dpopt.mat), dtype=np.int8).reshape(22, 22)
+    rst = np.zeros(len(tasks), dtype=mpa.DP_RST)
+    pool = []
+    for k, t in enumerate(tasks):
+        nt = idx.get_nt(int(t["vid"]), int(t["nt_off"]), int(t["nt_off"]) + int(t["nl"]))
+        aa = queries.seqs[int(t["qid"])][int(t["aa_off"]): int(t["aa_off"]) + int(t["al"])]
+        P = refbind.DpParams(mat, go=dpopt.go, ge=dpopt.ge, io=int(t["io"]), fs=dpopt.fs, xdrop=dpopt.xdrop,
+                             end_bonus=dpopt.end_bonus, sp=tuple(dpopt.sp), ie_coef=dpopt.ie_coef)
+        nt_len, aa_len, score, cig = refbind.ora_nasw(bytes(nt), aa, P, int(t["flag"]))
+        rst[k] = (nt_len, aa_len, score, len(cig), len(pool))
+        pool.extend(cig)
+    return rst, np.array(pool if pool else [0], dtype=np.uint32)
+
+
+def gpu_executor(ctx):
+    def run(idx, queries, dpopt, tasks):
+        return mpa.dp_run(ctx, idx, dpopt, queries, tasks)
+    return run
+
+
+def map_batch(idx, mo, queries, executor, n_threads=1):
+    """Returns the PAF text (bytes) of the batch."""
+    L = mpa.lib()
+    b = L.mpa_batch_begin(idx.h, C.byref(mo), C.byref(queries.c), n_threads)
+    if not b:
+        raise mpa.MpaError(mpa.last_error())
+    dpopt = mpa.DpOpt()
+    while True:
+        ptr = C.c_void_p()
+        n = L.mpa_batch_dp_tasks(b, C.byref(ptr), C.byref(dpopt))
+        if n <= 0:
+            break
+        tasks = np.frombuffer((C.c_char * (n * mpa.DP_TASK.itemsize)).from_address(ptr.value), dtype=mpa.DP_TASK).copy()
+        rst, pool = executor(idx, queries, dpopt, tasks)
+        rst = np.ascontiguousarray(rst)
+        pool = np.ascontiguousarray(pool, dtype=np.uint32)
+        mpa._check(L.mpa_batch_dp_results(b, rst.ctypes.data, pool.ctypes.data))
+    res = L.mpa_batch_finish(b)
+    return format_paf(idx, mo, queries, res)
+
+
+def format_paf(idx, mo, queries, res):
+    L = mpa.lib()
+    names = (C.c_char_p * len(queries.names))(*[n.encode() for n in queries.names])
+    out = C.c_void_p()
+    n = L.mpa_format_paf(idx.h, C.byref(mo), C.byref(queries.c), names, res, C.byref(out))
+    txt = C.string_at(out.value, n)
+    L.mpa_free(out)
+    L.mpa_result_destroy(res)
+    return txt
+
+
+def map_batch_gpu(ctx, idx, mo, queries, n_threads=1):
+    L = mpa.lib()
+    res = C.c_void_p()
+    mpa._check(L.mpa_map_batch(ctx.h, idx.h, C.byref(mo), C.byref(queries.c), n_threads, C.byref(res)))
+    return format_paf(idx, mo, queries, res)
