@@ -87,6 +87,8 @@ typedef struct mpa_idx_s mpa_idx_t;
 mpa_idx_t *mpa_idx_restore(const char *fn);                     /* mp_idx_restore, index.c:204 */
 /* genome-only index from nt4 codes (A0 C1 G2 T3 N4) held in memory, contigs concatenated; no k-mer table */
 mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4);
+/* k-mer table of a genome-only index: build_worker + build_bidx (index.c:52-95) */
+int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads);
 int mpa_idx_dump(const char *fn, const mpa_idx_t *mi);          /* mp_idx_dump, index.c:189: byte-identical file */
 void mpa_idx_destroy(mpa_idx_t *mi);
 int32_t mpa_idx_n_ctg(const mpa_idx_t *mi);
@@ -151,6 +153,8 @@ typedef struct {
 	int32_t launches_ext, launches_glob;
 } mpa_dp_stats_t;
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
+/* sums over every mpa_dp_run() of this context since the last reset */
+void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset);
 
 /* ---- boundary #1: batched mp_map() ------------------------------------------------------------------------ */
 /* mp_feat_t / mp_extra_t / mp_reg1_t (miniprot.h:108-145) flattened for a C ABI */

@@ -85,6 +85,7 @@ def lib():
         L.mpa_idx_from_nt4.restype = C.c_void_p
         L.mpa_idx_from_nt4.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
         L.mpa_idx_dump.argtypes = [C.c_char_p, C.c_void_p]
+        L.mpa_idx_build_kmers.argtypes = [C.c_void_p, C.c_int]
         L.mpa_idx_destroy.argtypes = [C.c_void_p]
         L.mpa_idx_n_ctg.argtypes = [C.c_void_p]
         L.mpa_idx_ctg_len.restype = C.c_int64
@@ -103,6 +104,7 @@ def lib():
         L.mpa_dp_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(DpOpt), C.POINTER(QBatch), C.c_int64, C.c_void_p,
                                  C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         L.mpa_dp_last_stats.argtypes = [C.c_void_p, C.POINTER(DpStats)]
+        L.mpa_dp_total_stats.argtypes = [C.c_void_p, C.POINTER(DpStats), C.c_int]
         L.mpa_free.argtypes = [C.c_void_p]
         for name, res, args in [
             ("mpa_batch_begin", C.c_void_p, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int]),
@@ -152,9 +154,12 @@ class Context:
             lib().mpa_ctx_destroy(self.h)
             self.h = None
 
-    def dp_stats(self):
+    def dp_stats(self, total=False, reset=False):
         st = DpStats()
-        lib().mpa_dp_last_stats(self.h, C.byref(st))
+        if total:
+            lib().mpa_dp_total_stats(self.h, C.byref(st), 1 if reset else 0)
+        else:
+            lib().mpa_dp_last_stats(self.h, C.byref(st))
         return {k: getattr(st, k) for k, _ in DpStats._fields_}
 
     def __del__(self):
@@ -183,6 +188,30 @@ class Index:
         lens = np.array([len(c) for c in contigs], dtype=np.int64)
         cat = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint8) for c in contigs]))
         return cls(lib().mpa_idx_from_nt4(n, arr, lens.ctypes.data, cat.ctypes.data))
+
+    @classmethod
+    def from_fasta(cls, path, n_threads=4):
+        """Read a (possibly gzipped) FASTA, pack it and build the k-mer table on the host (index.c:97-136)."""
+        import gzip
+        op = gzip.open if path.endswith(".gz") else open
+        names, parts, cur = [], [], []
+        lut = np.full(256, 4, dtype=np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            lut[ch] = lut[ch | 0x20] = i
+        with op(path, "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if names:
+                        parts.append(np.concatenate(cur) if cur else np.zeros(0, np.uint8))
+                    names.append(line[1:].split()[0].decode())
+                    cur = []
+                else:
+                    cur.append(lut[np.frombuffer(line.rstrip(), dtype=np.uint8)])
+        if names:
+            parts.append(np.concatenate(cur) if cur else np.zeros(0, np.uint8))
+        idx = cls.from_nt4(parts, names)
+        _check(lib().mpa_idx_build_kmers(idx.h, n_threads))
+        return idx
 
     def to_device(self, ctx):
         _check(lib().mpa_idx_to_device(ctx.h, self.h))

@@ -56,6 +56,7 @@ struct mpa_ctx_s {
 	hipEvent_t ev[6] = {};
 	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list;
 	mpa_dp_stats_t stats = {};
+	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
 };
 
@@ -201,6 +202,11 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi) { return dev_upload_index(ctx, mi); }
 
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st) { *st = ctx->stats; }
+void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset)
+{
+	if (st) *st = ctx->total;
+	if (reset) ctx->total = mpa_dp_stats_t();
+}
 
 int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
                int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
@@ -467,6 +473,13 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	(void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); st.ms_ext = ms;
 	st.ms_glob = ms_glob, st.ms_backtrack = ms_bt;
 	st.ms_total = st.ms_prep + st.ms_ext + st.ms_glob + st.ms_backtrack;
+	{
+		mpa_dp_stats_t &t = ctx->total;
+		t.n_ext += st.n_ext, t.n_glob += st.n_glob, t.cells_ext += st.cells_ext, t.cells_glob += st.cells_glob, t.rows_prep += st.rows_prep;
+		t.alg_bytes_ext += st.alg_bytes_ext, t.alg_bytes_glob += st.alg_bytes_glob;
+		t.ms_prep += st.ms_prep, t.ms_ext += st.ms_ext, t.ms_glob += st.ms_glob, t.ms_backtrack += st.ms_backtrack, t.ms_total += st.ms_total;
+		t.launches_ext += st.launches_ext, t.launches_glob += st.launches_glob;
+	}
 	return MPA_OK;
 }
 

@@ -460,7 +460,9 @@ static int32_t ungapped_score(const mpa_idx_s *mi, const mpa_mapopt_t &opt, cons
 	fetch_nt(mi, (int32_t)r.vid, nt_off, nt_off + (int64_t)alen * 3, nt.data());
 	const uint8_t *aa20 = tab_aa20();
 	int32_t sc = 0;
-	for (int32_t j = 0; j < alen; ++j) sc += opt.mat[codon_aa(&nt[j * 3]) * opt.asize + aa20[(uint8_t)aa[j]]];
+	// NB: the reference's loop (align.c:36) advances its nucleotide index by 3 but bounds it by the AMINO-ACID
+	// length, so only the first ceil(alen/3) codons contribute to AS:i.  Reproduced for byte-identical output.
+	for (int32_t i = 0, j = 0; i < alen; i += 3, ++j) sc += opt.mat[codon_aa(&nt[i]) * opt.asize + aa20[(uint8_t)aa[j]]];
 	return sc;
 }
 

@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 #include "mpa_internal.h"
+#include "host_core.h"
 
 namespace mpa {
 
@@ -146,6 +149,41 @@ mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64
 	mi->ki.assign((size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit), 0);
 	compute_block_offsets(mi);
 	return mi;
+}
+
+// Build the k-mer -> block table of an index whose genome is already loaded.  Same result as
+// build_worker + build_bidx (index.c:52-95): every (contig,strand) is sketched in all three frames with
+// the index parameters, then a counting sort lays the block ids out bucket by bucket, strands in order.
+int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads)
+{
+	const int32_t n_strand = (int32_t)mi->ctg.size() * 2;
+	std::vector<std::vector<uint64_t>> sk(n_strand);
+	std::atomic<int32_t> next(0);
+	auto work = [&]() {
+		std::vector<uint8_t> seq;
+		for (;;) {
+			const int32_t j = next.fetch_add(1);
+			if (j >= n_strand) break;
+			const int64_t len = mi->ctg[j >> 1].len;
+			seq.resize((size_t)len);
+			fetch_nt(mi, j, 0, len, seq.data());
+			sketch_nt4(seq.data(), len, mi->opt.min_aa_len, mi->opt.kmer, mi->opt.mod_bit, mi->opt.bbit, mi->bo[j], sk[j]);
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < n_threads && t < n_strand; ++t) pool.emplace_back(work);
+	work();
+	for (auto &th : pool) th.join();
+	const size_t n_bucket = (size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit);
+	mi->ki.assign(n_bucket, 0);
+	for (const auto &v : sk) for (uint64_t x : v) ++mi->ki[x >> 32];
+	int64_t acc = 0;
+	for (size_t b = 0; b < n_bucket; ++b) { const int64_t c = mi->ki[b]; mi->ki[b] = acc, acc += c; }
+	mi->n_kb = acc;
+	mi->kb.assign((size_t)acc, 0);
+	std::vector<int64_t> fill(mi->ki);
+	for (const auto &v : sk) for (uint64_t x : v) mi->kb[fill[x >> 32]++] = (uint32_t)x;
+	return MPA_OK;
 }
 
 void mpa_idx_destroy(mpa_idx_t *mi)

@@ -1,0 +1,102 @@
+"""CPU-only checks of the product's HOST logic (no GPU, no compute calls into the HIP executor):
+the stage machine mpa_batch_* is driven with the oracle as DP executor and the resulting PAF must equal the
+golden output of the real reference; plus index build/dump parity and C-ABI hygiene."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+import miniprot_amd as mpa
+import refbind
+import golden
+from hostpipe import read_fasta, map_batch, oracle_executor
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(refbind.ROOT, "include", "mpamd.h")).read()
+    names = sorted(set(re.findall(r"\b(mpa_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 30
+    L = mpa.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, "declared in include/mpamd.h but not exported: %s" % missing
+
+
+def test_no_device_is_a_loud_error():
+    """there is no CPU fallback: without a GPU a context cannot be created and mapping refuses to run"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(mpa.MpaError):
+        mpa.Context(0)
+    idx = mpa.Index.from_fasta(golden.path("DPP3-hs.gen.fa.gz"))
+    q = mpa.Queries([b"MKTAYIAKQR"], ["x"])
+    res = C.c_void_p()
+    rc = mpa.lib().mpa_map_batch(None, idx.h, C.byref(mpa.default_mapopt()), C.byref(q.c), 1, C.byref(res))
+    assert rc == -1 and not res.value
+
+
+def test_product_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", mpa.LIB_PATH], capture_output=True, text=True).stdout
+    assert "mporacle" not in out and "miniprot_ref" not in out
+    syms = subprocess.run(["nm", "-D", mpa.LIB_PATH], capture_output=True, text=True).stdout
+    assert "mpo_" not in syms and "ns_global_gs16b" not in syms
+
+
+def test_mapopt_defaults_match_reference_layout():
+    mo = mpa.default_mapopt()
+    assert C.sizeof(mpa.MapOpt) == 656                      # sizeof(mp_mapopt_t), SURVEY.md 8(b)
+    assert (mo.max_intron, mo.max_ext, mo.io, mo.io_end, mo.fs, mo.kmer2, mo.best_n) == (200000, 10000, 29, 19, 23, 5, 30)
+    if refbind.have_ref():
+        buf = (C.c_char * 656)()
+        refbind.ref().mp_mapopt_init(buf)
+        assert bytes(buf)[:156] == bytes(mo)[:156]            # everything before gff_prefix
+        assert bytes(buf)[-484:] == bytes(mo)[-484:]          # scoring matrix incl. the stop row/column
+
+
+def test_index_build_is_byte_identical_to_golden_reference_index(tmp_path):
+    idx = mpa.Index.from_fasta(golden.path("DPP3-hs.gen.fa.gz"))
+    out = str(tmp_path / "x.mpi")
+    idx.dump(out)
+    # md5 of `miniprot -d` output for this genome with the reference (recorded by tools/make_golden.py run)
+    md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
+    if refbind.have_ref():
+        ref = str(tmp_path / "r.mpi")
+        subprocess.run([refbind.REF_BIN, "-t2", "-d", ref, golden.path("DPP3-hs.gen.fa.gz")], capture_output=True, check=True)
+        assert md5 == hashlib.md5(open(ref, "rb").read()).hexdigest()
+    back = mpa.Index.restore(out)
+    assert back.n_ctg() == 1 and back.ctg_len(0) == 27033 and back.ctg_name(0) == "chr11:66478458-66505490"
+
+
+def test_dpp3_paf_identical(oracle_built):
+    idx = mpa.Index.from_fasta(golden.path("DPP3-hs.gen.fa.gz"))
+    names, seqs = read_fasta(golden.path("DPP3-mm.pep.fa.gz"))
+    paf = map_batch(idx, mpa.default_mapopt(), mpa.Queries(seqs, names), oracle_executor)
+    assert paf == open(golden.path("dpp3.ref.paf"), "rb").read()
+    assert hashlib.md5(paf).hexdigest() == "74fd00200bda6c03380bb3062fb5178b"
+
+
+@pytest.mark.parametrize("case", golden.SYNTH_CASES, ids=[c["name"] for c in golden.SYNTH_CASES])
+def test_synthetic_paf_identical(oracle_built, case):
+    contigs, prots, names = golden.synth_inputs(case)
+    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
+    paf = map_batch(idx, golden.mapopt_for(case), mpa.Queries(prots, names), oracle_executor, n_threads=4)
+    ref = open(golden.path(case["name"] + ".ref.paf"), "rb").read()
+    if paf != ref:
+        for x, y in zip(paf.split(b"\n"), ref.split(b"\n")):
+            if x != y:
+                raise AssertionError("first differing line\n ours %r\n ref  %r" % (x[:300], y[:300]))
+    assert paf == ref
+
+
+def test_threads_do_not_change_output(oracle_built):
+    case = golden.SYNTH_CASES[0]
+    contigs, prots, names = golden.synth_inputs(case)
+    idx = mpa.Index.from_nt4(contigs, ["chr1"])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 2))
+    q = mpa.Queries(prots[:12], names[:12])
+    a = map_batch(idx, golden.mapopt_for(case), q, oracle_executor, n_threads=1)
+    b = map_batch(idx, golden.mapopt_for(case), q, oracle_executor, n_threads=5)
+    assert a == b

@@ -69,7 +69,7 @@ def mutate(rng, prot, p_sub=0.15, p_del=0.0075, p_ins=0.0075):
     return bytes(out) if out else b"M"
 
 
-def generate(genome_len, n_ctg, n_prot, seed, mu=7.5, sigma=1.5, imin=70, imax=50000, n_frac=0.0, min_exons=1, mean_len=400, sd_len=160):
+def generate(genome_len, n_ctg, n_prot, seed, mu=7.5, sigma=1.5, imin=70, imax=50000, n_frac=0.0, min_exons=1, mean_len=400, sd_len=160, return_planted=False):
     rng = np.random.default_rng(seed)
     ctg_len = genome_len // n_ctg
     contigs = []
@@ -81,7 +81,7 @@ def generate(genome_len, n_ctg, n_prot, seed, mu=7.5, sigma=1.5, imin=70, imax=5
             n_runs = max(1, int(ctg_len * n_frac / 50000))
             for s in rng.integers(0, ctg_len - 50000, n_runs):
                 g[s:s + 50000] = 4
-    prots, names = [], []
+    prots, names, planted = [], [], []
     # planted positions: split every contig into equal slots, one gene per slot
     per_ctg = (n_prot + n_ctg - 1) // n_ctg
     slot = ctg_len // max(per_ctg, 1)
@@ -99,9 +99,12 @@ def generate(genome_len, n_ctg, n_prot, seed, mu=7.5, sigma=1.5, imin=70, imax=5
             rev = rng.random() < 0.5
             seg = COMP[gene[::-1]] if rev else gene
             contigs[ci][start:start + len(seg)] = seg
+            planted.append(prot)
             prots.append(mutate(rng, prot))
             names.append("p%05d_c%d_%s_%d" % (k, ci, "-" if rev else "+", start))
             k += 1
+    if return_planted:
+        return contigs, prots, names, planted
     return contigs, prots, names
 
 
