@@ -10,6 +10,9 @@ import os
 import subprocess
 import numpy as np
 
+# one HIP stream per kernel class: give the runtime enough hardware queues (must be set before HIP initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpamd.so")
 

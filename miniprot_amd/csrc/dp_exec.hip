@@ -53,8 +53,12 @@ using namespace mpa;
 struct mpa_ctx_s {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	static const int kSide = 16;              // side streams: every kernel class of a batch runs concurrently
+	hipStream_t side[kSide] = {};
 	hipEvent_t ev[6] = {};
-	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list;
+	hipEvent_t fork_ev = nullptr;
+	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey;
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -121,8 +125,9 @@ static int build_pen_table(float coef, int32_t max_x, PenTable *pt)
 }
 
 struct ExtClass { int G, NB; };
-static const ExtClass kExtClasses[] = { {16, 1}, {32, 1}, {64, 1}, {64, 2}, {64, 4}, {64, 8} };
-static const int kNumExtClasses = 6;
+// classes 0..2: k_ext<G,1>, several calls per wave.  classes 3..6: k_ext_wide<NB>, NB waves per pair of calls.
+static const ExtClass kExtClasses[] = { {16, 1}, {32, 1}, {64, 1}, {64, 2}, {64, 4}, {64, 8}, {64, 16} };
+static const int kNumExtClasses = 7;
 
 static int ext_class_of(int32_t ncol)
 {
@@ -142,16 +147,35 @@ template<int G, int NB> static hipError_t launch_ext(const ExtArgs &a, int n_wav
 	return hipGetLastError();
 }
 
-static hipError_t launch_ext_class(int k, const ExtArgs &a, int n_waves, hipStream_t s)
+template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_groups, hipStream_t s)
+{
+	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 4 * NW * 4;
+	if (lds > 48 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void*)k_ext_wide<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL((k_ext_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
+	return hipGetLastError();
+}
+
+static hipError_t launch_ext_class(int k, const ExtArgs &a, const ExtWideArgs &wa, int n_waves, hipStream_t s)
 {
 	switch (k) {
 	case 0: return launch_ext<16, 1>(a, n_waves, s);
 	case 1: return launch_ext<32, 1>(a, n_waves, s);
 	case 2: return launch_ext<64, 1>(a, n_waves, s);
-	case 3: return launch_ext<64, 2>(a, n_waves, s);
-	case 4: return launch_ext<64, 4>(a, n_waves, s);
-	default: return launch_ext<64, 8>(a, n_waves, s);
+	case 3: return launch_ext_wide<2>(wa, n_waves, s);
+	case 4: return launch_ext_wide<4>(wa, n_waves, s);
+	case 5: return launch_ext_wide<8>(wa, n_waves, s);
+	default: return launch_ext_wide<16>(wa, n_waves, s);
 	}
+}
+
+template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s)
+{
+	const size_t lds = (size_t)NW * 22 * 64 * 2 + 2 * NW * 16;
+	hipLaunchKernelGGL((k_glob_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
+	return hipGetLastError();
 }
 
 template<int G> static hipError_t launch_glob(const GlobArgs &a, int n_waves, hipStream_t s)
@@ -184,6 +208,9 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	ctx->device = device;
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
 	for (auto &e : ctx->ev) (void)hipEventCreate(&e);
+	for (auto &st : ctx->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+	for (auto &e : ctx->lev) (void)hipEventCreate(&e);
+	(void)hipEventCreate(&ctx->fork_ev);
 	if (const char *s = getenv("MPA_TB_BUDGET_MB")) ctx->tb_budget = (size_t)atoll(s) << 20;
 	return ctx;
 }
@@ -193,8 +220,11 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list }) b->release();
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey }) b->release();
 	for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+	for (auto &e : ctx->lev) (void)hipEventDestroy(e);
+	(void)hipEventDestroy(ctx->fork_ev);
+	for (auto &st : ctx->side) (void)hipStreamDestroy(st);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -219,12 +249,13 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	if (n <= 0) return MPA_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->stream;
+	const double t_begin = now_ms();
 
 	// ---- parameter guards: outside these the packed-int16 kernels would not be bit-exact
 	int32_t max_mat = 0;
 	for (int k = 0; k < 484; ++k) max_mat = std::max<int32_t>(max_mat, opt->mat[k]);
 	if (opt->go < 0 || opt->go > 32000 || opt->ge < 0 || opt->ge > 255 || opt->fs < 0 || opt->fs > 255 || opt->xdrop < 0 || opt->xdrop > 32000 ||
-	    opt->end_bonus < -128 || opt->end_bonus > 1000) {
+	    opt->end_bonus < 0 || opt->end_bonus > 1000) {
 		set_error("DP parameters outside the supported range (go<=32000, ge/fs<=255, 0<=xdrop<=32000)"); return MPA_ERR_UNSUPPORTED;
 	}
 
@@ -244,7 +275,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
 			const int cls = ext_class_of(t.ncol);
-			if (cls < 0) { set_error("extension call wider than 512 columns is not supported yet (al=" + std::to_string(x.al) + ")"); return MPA_ERR_UNSUPPORTED; }
+			if (cls < 0) { set_error("extension call wider than 1024 columns is not supported yet (al=" + std::to_string(x.al) + ")"); return MPA_ERR_UNSUPPORTED; }
 			if ((int64_t)x.al * max_mat + (int64_t)t.ncol * opt->ge + std::max(0, opt->end_bonus) > 32000 || opt->go + (int64_t)t.ncol * opt->ge > 32000) {
 				set_error("extension call could saturate int16; not supported"); return MPA_ERR_UNSUPPORTED;
 			}
@@ -255,7 +286,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		} else {
 			if (!(x.flag & MPA_F_CIGAR)) { set_error("global DP without CIGAR is not part of miniprot's path"); return MPA_ERR_UNSUPPORTED; }
 			t.pw = t.ncol;
-			t.pad_ = t.ncol <= 16 ? 0 : t.ncol <= 32 ? 1 : 2;
+			t.pad_ = t.ncol <= 16 ? 0 : t.ncol <= 32 ? 1 : t.ncol <= 64 ? 2 : t.ncol <= 128 ? 3 : t.ncol <= 256 ? 4 : t.ncol <= 512 ? 5 : t.ncol <= 1024 ? 6 : 7;
 			glob_ids.push_back((int32_t)k);
 		}
 	}
@@ -283,7 +314,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		DTask &t = T[id];
 		t.cig_cap = t.nl + t.al + 4;
 		t.cig_off = cig_total, cig_total += t.cig_cap;
-		if (t.ncol > 64) t.bnd_off = bnd_total, bnd_total += t.nl;
+		if (t.pad_ == 7) t.bnd_off = bnd_total, bnd_total += t.nl;
 	}
 	rec_total += max_nl + 16;                               // kernels read a few records past a call's end
 
@@ -309,6 +340,11 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 			ewave_cnt[cls] = (int)ewaves.size() - ewave_first[cls];
 		}
 	}
+	// per-row keys of the wide extension kernels: [group][2 halves][key_stride]
+	int64_t key_stride = 0, n_wide_groups = 0;
+	for (int cls = 3; cls < kNumExtClasses; ++cls)
+		for (int k = 0; k < ewave_cnt[cls]; ++k) key_stride = std::max<int64_t>(key_stride, ewaves[ewave_first[cls] + k].max_nl), ++n_wide_groups;
+	key_stride = (key_stride + 64) & ~(int64_t)63;
 	PenTable pen;
 	if (build_pen_table(opt->ie_coef, std::max(max_nl_ext, 2), &pen) < 0) { set_error("ie_coef produces too many penalty steps"); return MPA_ERR_UNSUPPORTED; }
 
@@ -332,6 +368,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	int64_t tb_max = 0;
 	for (auto &r : rounds) tb_max = std::max(tb_max, r.tb_words);
 
+	timing_note("  dp: classify/sort/layout", now_ms() - t_begin);
 	// ---- device memory
 	const int64_t q_bytes = q->q_off[q->n_seq];
 	int rc;
@@ -339,13 +376,14 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	    (rc = ctx->qseq.ensure(q_bytes + 16)) || (rc = ctx->rec.ensure((size_t)rec_total * 4)) || (rc = ctx->prof.ensure((size_t)prof_total * 2 + 16)) ||
 	    (rc = ctx->waves.ensure(sizeof(ExtWave) * (ewaves.size() + 1))) || (rc = ctx->extout.ensure(sizeof(ExtOut) * n)) ||
 	    (rc = ctx->tb.ensure((size_t)tb_max * 2 + 16)) || (rc = ctx->cig.ensure((size_t)cig_total * 4 + 16)) || (rc = ctx->ncig.ensure(n * 4)) ||
-	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
+	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->rowkey.ensure((size_t)(n_wide_groups * 2 * key_stride * 4 + 64))) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
 		return rc;
 	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, T.data(), sizeof(DTask) * n, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, chunks.data(), sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, q->seqs, q_bytes, hipMemcpyHostToDevice, s));
 	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
+	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));
 
 	DevTables tabs;
 	memcpy(tabs.aa20, tab_aa20(), 256);
@@ -363,29 +401,52 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(ctx->ev[1], s));
+	// ---- fork: every kernel class (extension classes and the traceback classes of the first round) gets its
+	// own stream, so the long single-wave tails of the classes overlap instead of adding up
+	HIP_TRY(hipEventRecord(ctx->fork_ev, s));
+	int n_side = 0;
+	struct Launch { int side; bool is_ext; };
+	std::vector<Launch> launches;
+	auto begin_side = [&](bool is_ext) -> hipStream_t {
+		const int k = n_side++;
+		(void)hipStreamWaitEvent(ctx->side[k], ctx->fork_ev, 0);
+		(void)hipEventRecord(ctx->lev[2 * k], ctx->side[k]);
+		launches.push_back(Launch{ k, is_ext });
+		return ctx->side[k];
+	};
+	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[k]); };
 
 	// ---- K1: extension calls
 	ExtArgs ea;
 	ea.tasks = ctx->tasks.as<DTask>(), ea.rec = ctx->rec.as<uint32_t>(), ea.prof = ctx->prof.as<int16_t>(), ea.out = ctx->extout.as<ExtOut>();
 	ea.c = dc, ea.pen = pen;
-	for (int cls = 0; cls < kNumExtClasses; ++cls) {
+	ExtWideArgs wa;
+	wa.tasks = ea.tasks, wa.rec = ea.rec, wa.prof = ea.prof, wa.out = ea.out, wa.c = dc, wa.pen = pen, wa.key_stride = key_stride;
+	int64_t wide_groups_done = 0;
+	for (int cls = kNumExtClasses - 1; cls >= 0; --cls) {               // widest classes first
 		if (ewave_cnt[cls] == 0) continue;
-		ea.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
-		HIP_TRY(launch_ext_class(cls, ea, ewave_cnt[cls], s));
+		ea.waves = wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
+		wa.rowkey = ctx->rowkey.as<uint32_t>() + wide_groups_done * 2 * key_stride;
+		if (cls >= 3) wide_groups_done += ewave_cnt[cls];
+		hipStream_t st = begin_side(true);
+		HIP_TRY(launch_ext_class(cls, ea, wa, ewave_cnt[cls], st));
+		end_side();
 		ctx->stats.launches_ext++;
 	}
-	HIP_TRY(hipEventRecord(ctx->ev[2], s));
 
 	// ---- K2 + traceback walk
 	float ms_glob = 0, ms_bt = 0;
 	std::vector<GlobWave> gwaves;
 	std::vector<int32_t> glist;
-	for (auto &r : rounds) {
+	for (size_t ri = 0; ri < rounds.size(); ++ri) {
+		auto &r = rounds[ri];
 		if (r.last == r.first) continue;
+		const bool concurrent = ri == 0;                                  // later rounds reuse the traceback buffer: serial
 		gwaves.clear(), glist.clear();
-		int cnt[3] = { 0, 0, 0 }, first[3] = { 0, 0, 0 };
+		const int kNumGlobClasses = 8;
+		int cnt[kNumGlobClasses] = { 0 }, first[kNumGlobClasses] = { 0 };
 		size_t p = r.first;
-		for (int cls = 0; cls < 3; ++cls) {
+		for (int cls = 0; cls < kNumGlobClasses; ++cls) {
 			const int per = cls == 0 ? 4 : cls == 1 ? 2 : 1;
 			first[cls] = (int)gwaves.size();
 			while (p < r.last && T[glob_ids[p]].pad_ == cls) {
@@ -401,19 +462,48 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 			}
 			cnt[cls] = (int)gwaves.size() - first[cls];
 		}
+		if (!concurrent) {                                                // join everything before the buffers are reused
+			for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
+			HIP_TRY(hipStreamSynchronize(s));
+		}
 		int32_t *d_list = ctx->list.as<int32_t>();
 		GlobWave *d_gw = (GlobWave*)((char*)ctx->list.p + (((size_t)n * 4 + 63) & ~(size_t)63));
 		HIP_TRY(hipMemcpyAsync(d_list, glist.data(), glist.size() * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(d_gw, gwaves.data(), gwaves.size() * sizeof(GlobWave), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));                                 // gwaves/glist are reused by the next round
 		GlobArgs ga;
 		ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
 		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc;
+		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
+			ga.waves = d_gw + first[cls];
+			switch (cls) {
+			case 0: return launch_glob<16>(ga, cnt[cls], st);
+			case 1: return launch_glob<32>(ga, cnt[cls], st);
+			case 2: case 7: return launch_glob<64>(ga, cnt[cls], st);
+			case 3: return launch_glob_wide<2>(ga, cnt[cls], st);
+			case 4: return launch_glob_wide<4>(ga, cnt[cls], st);
+			case 5: return launch_glob_wide<8>(ga, cnt[cls], st);
+			default: return launch_glob_wide<16>(ga, cnt[cls], st);
+			}
+		};
 		HIP_TRY(hipEventRecord(ctx->ev[3], s));
-		if (cnt[0]) { ga.waves = d_gw + first[0]; HIP_TRY(launch_glob<16>(ga, cnt[0], s)); ctx->stats.launches_glob++; }
-		if (cnt[1]) { ga.waves = d_gw + first[1]; HIP_TRY(launch_glob<32>(ga, cnt[1], s)); ctx->stats.launches_glob++; }
-		if (cnt[2]) { ga.waves = d_gw + first[2]; HIP_TRY(launch_glob<64>(ga, cnt[2], s)); ctx->stats.launches_glob++; }
+		// every class on its own stream (next to the extension classes in the first round); the walk needs them all
+		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
+		const size_t first_glob_launch = launches.size();
+		for (int cls = kNumGlobClasses - 1; cls >= 0; --cls) {
+			if (!cnt[cls]) continue;
+			if (n_side >= mpa_ctx_s::kSide) {                                // out of side streams: run on the main stream
+				HIP_TRY(launch_glob_class(cls, s));
+			} else {
+				hipStream_t st = begin_side(false);
+				HIP_TRY(launch_glob_class(cls, st));
+				end_side();
+			}
+			ctx->stats.launches_glob++;
+		}
+		for (size_t k = first_glob_launch; k < launches.size(); ++k) (void)hipStreamWaitEvent(s, ctx->lev[2 * launches[k].side + 1], 0);
 		HIP_TRY(hipEventRecord(ctx->ev[4], s));
-		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)((glist.size() + 63) / 64)), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_list, (int32_t)glist.size(),
+		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)glist.size()), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_list, (int32_t)glist.size(),
 		                   ctx->tb.as<uint16_t>(), ctx->cig.as<uint32_t>(), ctx->ncig.as<int32_t>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(ctx->ev[5], s));
@@ -423,8 +513,19 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
 		ms_glob += a, ms_bt += b;
 	}
+	// ---- join
+	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
+	HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	HIP_TRY(hipStreamSynchronize(s));
+	float ms_ext_sum = 0;                                                 // sum of the per-launch durations of the extension kernels
+	for (auto &l : launches) {
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, ctx->lev[2 * l.side], ctx->lev[2 * l.side + 1]);
+		if (l.is_ext) ms_ext_sum += ms;
+	}
 
+	timing_note("  dp: upload+kernels (wall)", now_ms() - t_begin);
+	const double t_res = now_ms();
 	// ---- results
 	std::vector<ExtOut> eo;
 	std::vector<int32_t> sc, nc;
@@ -451,6 +552,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 			pp += nc[k];
 		}
 	}
+	timing_note("  dp: download+assemble", now_ms() - t_res);
 	if (cigar_pool) *cigar_pool = pool; else free(pool);
 	if (n_pool) *n_pool = pool_n;
 
@@ -470,9 +572,9 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	st.rows_prep = rec_total;
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); st.ms_prep = ms;
-	(void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); st.ms_ext = ms;
+	st.ms_ext = ms_ext_sum;
 	st.ms_glob = ms_glob, st.ms_backtrack = ms_bt;
-	st.ms_total = st.ms_prep + st.ms_ext + st.ms_glob + st.ms_backtrack;
+	{ float w = 0; (void)hipEventElapsedTime(&w, ctx->ev[0], ctx->ev[2]); st.ms_total = w; }   // wall time of the whole batch on the device
 	{
 		mpa_dp_stats_t &t = ctx->total;
 		t.n_ext += st.n_ext, t.n_glob += st.n_glob, t.cells_ext += st.cells_ext, t.cells_glob += st.cells_glob, t.rows_prep += st.rows_prep;

@@ -489,6 +489,204 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1-wide: extension calls wider than 64 columns.  One workgroup of NW waves per pair of calls (the two
+// int16 halves); wave w owns columns [64w, 64w+64) and runs ONE ROW BEHIND wave w-1 (a wavefront over
+// waves), so the horizontal carry and the left-neighbour column it needs were produced in the previous step
+// and arrive through LDS with a single barrier per step.  The critical path is nl + NW steps instead of
+// nl * NW block-rows of a single wave.
+//
+// Bookkeeping differs from k_ext: every (row, block) posts max(H + end bonus) together with the first
+// column attaining it into a per-row key (atomicMax), and the reference's sequential best-row / x-drop
+// logic (nasw-sse.c:423-433) is replayed over the keys afterwards -- exact, because the x-drop only ever
+// stops the sweep, it never changes a row that was computed.
+// ------------------------------------------------------------------------------------------------
+struct ExtWideArgs {
+	const DTask *tasks;
+	const ExtWave *waves;     // task[0], task[1] = the two halves
+	const uint32_t *rec;
+	const int16_t *prof;
+	ExtOut *out;
+	uint32_t *rowkey;         // [2][max_nl] per workgroup, zero-initialised; offset = blockIdx.x * 2 * key_stride
+	int64_t key_stride;
+	DpConst c;
+	PenTable pen;
+};
+
+template<int NW>
+__global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
+{
+	extern __shared__ uint32_t lds_raw[];
+	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots
+	int16_t *lds_prof = (int16_t*)lds_raw;
+	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 parities][NW] carry of the I scan
+	uint32_t *xH = xY + 2 * NW;                                  // [2 parities][NW] H of the block's last column
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const ExtWave wv = a.waves[blockIdx.x];
+	const DpConst c = a.c;
+	const uint32_t *recbase = a.rec + wv.rec_base;
+	uint32_t *rowkey = a.rowkey + (int64_t)blockIdx.x * 2 * a.key_stride;
+
+	int32_t tid[2], nl[2], al[2], ncol[2];
+	uint32_t roff[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		tid[h] = wv.task[h];
+		if (tid[h] >= 0) {
+			const DTask *t = &a.tasks[tid[h]];
+			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol, roff[h] = (uint32_t)(t->rec_off - wv.rec_base);
+		} else nl[h] = 0, al[h] = 1, ncol[h] = 0, roff[h] = 0;
+	}
+	// profile columns of this wave
+	for (int h = 0; h < 2; ++h) {
+		if (tid[h] < 0) continue;
+		const DTask *t = &a.tasks[tid[h]];
+		const int16_t *src = a.prof + t->prof_off;
+		for (int k = lane; k < 22 * 64; k += 64) {
+			const int aidx = k >> 6, cc = k & 63, gcc = w * 64 + cc;
+			lds_prof[(w * 2 + h) * 22 * 64 + k] = gcc < t->pw ? src[aidx * t->pw + gcc] : (int16_t)NEG16;
+		}
+	}
+	if (threadIdx.x < 4 * NW) xY[threadIdx.x] = NEGP;             // xY and xH are contiguous
+	__syncthreads();
+
+	const int gc = w * 64 + lane;
+	const uint32_t jge = splat16(gc * c.ge), gojge = splat16(c.go + gc * c.ge);
+	const int32_t ebp = c.end_bonus > 0 ? c.end_bonus : 0;
+	const uint32_t ebv = pack16(gc == al[0] - 1 ? ebp : 0, gc == al[1] - 1 ? ebp : 0);
+	const bool valid0 = gc < ncol[0], valid1 = gc < ncol[1];
+	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
+	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
+	const char *ldsb = (const char*)(lds_prof + (w * 2) * 22 * 64) + lane * 2;
+	const uint32_t keycol = 0xffffu - (uint32_t)gc;
+
+	uint32_t Hr[3], Hs[3], Dr[3], A = NEGP, B = NEGP, C = NEGP;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
+	if (w == 0 && lane == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
+
+	uint32_t rA0 = recbase[roff[0] + 0], rB0 = recbase[roff[1] + 0];
+	uint32_t rA1 = recbase[roff[0] + 1], rB1 = recbase[roff[1] + 1];
+	uint32_t dim1, di = __builtin_amdgcn_perm(rB0, rA0, 0x0a050801u), dip1 = __builtin_amdgcn_perm(rB1, rA1, 0x0a050801u);
+	uint32_t aim2, aim1 = __builtin_amdgcn_perm(rB0, rA0, 0x0b070903u), ai = __builtin_amdgcn_perm(rB1, rA1, 0x0b070903u);
+	uint32_t r0A = recbase[roff[0] + 2], r0B = recbase[roff[1] + 2];
+	uint32_t r1A = recbase[roff[0] + 3], r1B = recbase[roff[1] + 3];
+	const int32_t max_nl = wv.max_nl;
+
+	auto row = [&](auto kc, int32_t i, int par) {
+		constexpr int K = decltype(kc)::value;
+		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
+		const uint32_t r2A = recbase[roff[0] + (uint32_t)i + 2], r2B = recbase[roff[1] + (uint32_t)i + 2];
+		const uint32_t dnew = __builtin_amdgcn_perm(r0B, r0A, 0x0a050801u);
+		const uint32_t anew = __builtin_amdgcn_perm(r0B, r0A, 0x0b070903u);
+		const uint32_t gei = __builtin_amdgcn_perm(r0B, r0A, 0x0c060c02u);
+		dim1 = di, di = dip1, dip1 = dnew;
+		aim2 = aim1, aim1 = ai, ai = anew;
+		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(r0A & 0xff) * 128), *(const int16_t*)(ldsb + 22 * 128 + (int)(r0B & 0xff) * 128));
+		// what the wave to the left produced for this same row in the previous step
+		const uint32_t carry_in = w > 0 ? xY[(par ^ 1) * NW + w - 1] : NEGP;
+		const uint32_t left_h = w > 0 ? xH[(par ^ 1) * NW + w - 1] : NEGP;
+		uint32_t h, t, u;
+		h = p_adds(Hs[R3], S);
+		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
+		t = p_subs(t, gei); Dr[R3] = t; h = p_max(h, t);
+		u = p_subs(Hr[R1], ioP); t = p_subs(u, dim1);
+		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ai));
+		u = p_subs(Hs[R1], ioP); t = p_subs(u, di);
+		t = p_max(t, B); B = t; h = p_max(h, p_subs(t, aim2));
+		t = p_subs(u, dip1);
+		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, aim1));
+		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));
+		h = p_max(h, p_subs(t, fsP));
+		const uint32_t y = scan_max_pk<64>(p_adds(h, jge));
+		uint32_t ex = shift1<64>(y, NEGP, lane);
+		ex = p_max(ex, carry_in);
+		h = p_max(h, p_subs(ex, gojge));
+		const uint32_t hs = shift1<64>(h, left_h, lane);
+		Hr[R3] = h, Hs[R3] = hs;
+		if (lane == 63) xY[par * NW + w] = p_max(carry_in, y), xH[par * NW + w] = h;
+		// per-row key: (H + end bonus) of the best column of this block, ties to the smallest column
+		const uint32_t hx = p_adds(h, ebv);
+		uint32_t k0 = valid0 && i < nl[0] ? ((uint32_t)(lo16(hx) + 32768) << 16 | keycol) : 0u;
+		uint32_t k1 = valid1 && i < nl[1] ? ((uint32_t)(hi16(hx) + 32768) << 16 | keycol) : 0u;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, off), o1 = (uint32_t)__shfl_xor((int)k1, off);
+			k0 = k0 > o0 ? k0 : o0, k1 = k1 > o1 ? k1 : o1;
+		}
+		if (lane == 0) {
+			if (k0) atomicMax(&rowkey[i], k0);
+			if (k1) atomicMax(&rowkey[a.key_stride + i], k1);
+		}
+		if (i == 2 && w == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
+		r0A = r1A, r0B = r1B, r1A = r2A, r1B = r2B;
+	};
+
+	for (int32_t t = 2; t < max_nl + NW - 1; ++t) {
+		const int32_t i = t - w;
+		if (i >= 2 && i < max_nl) {
+			const int k = (i - 2) % 3;
+			if (k == 0) row(std::integral_constant<int, 0>(), i, t & 1);
+			else if (k == 1) row(std::integral_constant<int, 1>(), i, t & 1);
+			else row(std::integral_constant<int, 2>(), i, t & 1);
+		}
+		__syncthreads();
+	}
+	__threadfence();
+	__syncthreads();
+
+	// ---- replay of nasw-sse.c:423-443 over the per-row keys, one wave per half
+	if (w < 2 && tid[w] >= 0) {
+		const int h = w;
+		const uint32_t *key = rowkey + (int64_t)h * a.key_stride;
+		const int64_t pen_len = 3 * (int64_t)al[h];
+		int32_t G = INT32_MIN, best_i = -1, best_sc = INT32_MIN, best_col = -1;
+		bool stopped = false;
+		for (int32_t base = 2; base < nl[h] && !stopped; base += 64) {
+			const int32_t i = base + lane;
+			const bool ok = i < nl[h];
+			const uint32_t kv = ok ? __builtin_nontemporal_load(&key[i]) : 0u;
+			// tmp_sc_log of row i: row maximum minus the length penalty (looked up in the step table)
+			int32_t pen = 0;
+			{
+				const int64_t x = (int64_t)i - pen_len;
+				int k = 0;
+				while (k + 1 < MPA_PEN_MAX && x >= (int64_t)a.pen.x[k + 1]) ++k;
+				pen = a.pen.val[k];
+			}
+			const int32_t sc = (int32_t)(kv >> 16) - 32768;
+			const int32_t v = ok ? sc - pen : INT32_MIN;
+			// inclusive running maximum (over lanes, seeded with G)
+			int32_t m = v;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(m, off); if (lane >= off) m = imax(m, o); }
+			m = imax(m, G);
+			const int32_t up = __shfl_up(m, 1);                    // cross-lane reads must not sit inside a divergent select
+			const bool imp = ok && v > (lane == 0 ? G : up);
+			const bool brk = ok && (int64_t)m - (int64_t)v > c.xdrop;
+			const uint64_t bm = __ballot(brk);
+			const int first_brk = bm ? __ffsll((unsigned long long)bm) - 1 : 64;
+			const uint64_t im = __ballot(imp) & (first_brk >= 63 ? ~0ULL : ((2ULL << first_brk) - 1));
+			if (im) {
+				const int last = 63 - __clzll((long long)im);
+				best_i = base + last;
+				G = __shfl(v, last);
+				best_sc = __shfl(sc, last);
+				best_col = 0xffff - (int32_t)(__shfl((int)kv, last) & 0xffff);
+			}
+			if (bm) stopped = true;
+		}
+		if (lane == 0) {
+			ExtOut o;
+			o.nt_len = best_i + 1;
+			o.aa_len = best_i < 0 ? 0 : best_col + 1;
+			o.score = best_sc;
+			o.flags = (best_i >= 0 && best_col >= al[h]) ? 1 : 0;
+			a.out[tid[h]] = o;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: global alignment with traceback.  int32 arithmetic, one column per lane, one call per group of
 // G lanes; matrices wider than 64 columns are swept in column blocks (block-major), each block leaving
 // a 16-byte boundary record per row for its right neighbour.
@@ -634,56 +832,201 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// traceback walk (ns_backtrack nasw-sse.c:40-89), one thread per call
+// K2-wide: the same traceback DP for matrices of 65..64*NW columns with one wave per 64-column block, the
+// waves skewed by one row (see k_ext_wide); the boundary record travels through LDS instead of HBM and
+// the block-major passes of k_glob<64> collapse into one sweep of nl + NW steps.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cig_push(uint32_t *cig, int32_t &n, int32_t cap, uint32_t op, int32_t len)
+template<int NW>
+__global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 {
-	if (n > 0 && (cig[n - 1] & 0xf) == op && op != 10 && op != 11) cig[n - 1] += (uint32_t)len << 4;
-	else if (n < cap) cig[n++] = (uint32_t)len << 4 | op;
+	constexpr int G = 64;
+	extern __shared__ uint32_t lds_raw[];
+	int16_t *lds_prof = (int16_t*)lds_raw;                      // [NW][22][64]
+	int4 *xB = (int4*)(lds_prof + NW * 22 * 64);               // [2 parities][NW] boundary records
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const GlobWave wv = a.waves[blockIdx.x];
+	const DpConst c = a.c;
+	const int32_t tid = wv.task[0];
+	const DTask t = a.tasks[tid];
+	const int32_t nl = t.nl, ncol = t.ncol, slen = ncol >> 3;
+	const int32_t go = c.go, ge = c.ge, goe = (int16_t)(c.go + c.ge), io = t.io, fs = c.fs;
+	const uint32_t *rec = a.rec + t.rec_off;
+	uint16_t *tb = a.tb + t.tb_off;
+	const int32_t gc = w * 64 + lane;
+	const bool live = gc < ncol;
+	{
+		const int16_t *src = a.prof + t.prof_off;
+		for (int k = lane; k < 22 * 64; k += 64) {
+			const int aidx = k >> 6, cc = k & 63, gcc = w * 64 + cc;
+			lds_prof[w * 22 * 64 + k] = gcc < t.pw ? src[aidx * t.pw + gcc] : (int16_t)NEG16;
+		}
+		if (threadIdx.x < 2 * NW) xB[threadIdx.x] = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
+	}
+	__syncthreads();
+	const int16_t *myprof = lds_prof + w * 22 * 64 + lane;
+	const int32_t seg = slen > 0 ? gc / slen : 0;
+	const bool seg_start = slen > 0 && gc % slen == 0;
+	const int32_t cge = gc * ge, yoff = seg * SEG_BIG + cge;
+	const bool first_blk = w == 0;
+
+	int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
+	int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
+	if (first_blk && lane == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
+	uint32_t q0 = nl > 0 ? rec[0] : 0, q1 = nl > 1 ? rec[1] : 0;
+	int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
+	int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
+	uint32_t rcur = nl > 2 ? rec[2] : 0;
+
+	for (int32_t step = 2; step < nl + NW - 1; ++step) {
+		const int32_t i = step - w, par = step & 1;
+		if (i >= 2 && i < nl) {
+			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
+			const int32_t nas = rcur & 0xff, gei = (rcur >> 16) & 0xff;
+			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
+			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
+			const int32_t S = myprof[nas * G];
+			int4 bin = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
+			if (!first_blk) bin = xB[(par ^ 1) * NW + w - 1];
+			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
+			int32_t wd = 0, st = 0, h, tt, u;
+			const int32_t M = s_add(H3s, S);
+			u = s_sub(H3, go); if (D3 > u) wd |= 1 << 5;
+			const int32_t Dn = s_sub(imax(u, D3), gei);
+			tt = s_sub(s_sub(H1, io), dm1); if (A > tt) wd |= 1 << 6;
+			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
+			u = s_sub(H1s, io);
+			tt = s_sub(u, d0); if (B > tt) wd |= 1 << 7;
+			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
+			tt = s_sub(u, dp1); if (C > tt) wd |= 1 << 8;
+			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
+			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
+			const int32_t nonI = imax(imax(imax(M, Dn), imax(Av, Bv)), imax(imax(Cv, F6), imax(imax(F7, F8), F9)));
+			const int32_t py = scan_max_i32<G>(nonI + yoff);
+			int32_t pex = shift1_i32<G>(py, NEG32, lane);
+			pex = imax(pex, bin.x);
+			const int32_t py_tot = imax(bin.x, __shfl(py, 63));
+			const int32_t I1 = imax(pex - yoff - go, NEG16);
+			h = M;
+			if (I1 > h) st = 1, h = I1;
+			if (Dn > h) st = 2, h = Dn;
+			if (Av > h) st = 3, h = Av;
+			if (Bv > h) st = 4, h = Bv;
+			if (Cv > h) st = 5, h = Cv;
+			if (F6 > h) st = 6, h = F6;
+			if (F7 > h) st = 7, h = F7;
+			if (F8 > h) st = 8, h = F8;
+			if (F9 > h) st = 9, h = F9;
+			const int32_t h1 = h;
+			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
+			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
+			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
+			if (il > s_sub(hl, go)) wd |= 1 << 4;
+			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
+			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
+			int32_t pz = scan_max_i32<G>(z);
+			pz = imax(pz, bin.y);
+			const int32_t Gc = imax(pz - cge, NEG16);
+			if (Gc > h1) wd |= 1 << 9, h = Gc;
+			if (live) tb[(int64_t)i * ncol + gc] = (uint16_t)(wd | st);
+			if (lane == 63) xB[par * NW + w] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
+			if (i == nl - 1 && gc == t.al - 1) a.score[tid] = h;
+			const int32_t hs = shift1_i32<G>(h, first_blk ? NEG16 : Hb, lane);
+			H3 = H2, H2 = H1, H1 = h;
+			H3s = H2s, H2s = H1s, H1s = hs;
+			D3 = D2, D2 = D1, D1 = Dn;
+			A = An, B = Bn, C = Cn;
+			if (i == 2 && first_blk && lane == 0) H2s = NEG16, H3s = NEG16;
+			rcur = rnext;
+		}
+		__syncthreads();
+	}
+	if (nl < 3 && threadIdx.x == 0) a.score[tid] = NEG16;
 }
 
-__global__ void k_backtrack(const DTask *tasks, const int32_t *list, int32_t n_list, const uint16_t *tbpool, uint32_t *cigpool, int32_t *n_cigar)
+// ------------------------------------------------------------------------------------------------
+// traceback walk (ns_backtrack nasw-sse.c:40-89), one WAVE per call.
+//
+// The reference follows one cell per step.  The path is made of runs that move in a fixed direction while
+// a bit of the traceback word stays set (match runs on the diagonal, gap/intron extensions along a column
+// or a row), so the 64 lanes fetch the next 64 cells of the current direction at once, a ballot finds where
+// the run ends, and the whole run is emitted as one CIGAR operation.  A 50 kb intron costs ~800 dependent
+// memory round trips instead of 50 000.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_backtrack(const DTask *tasks, const int32_t *list, int32_t n_list, const uint16_t *tbpool, uint32_t *cigpool, int32_t *n_cigar)
 {
-	const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= n_list) return;
-	const int32_t tid = list[k];
+	if ((int32_t)blockIdx.x >= n_list) return;
+	const int32_t tid = list[blockIdx.x];
 	const DTask t = tasks[tid];
 	const uint16_t *tb = tbpool + t.tb_off;
 	uint32_t *cig = cigpool + t.cig_off;
-	const int32_t ncol = t.ncol, cap = t.cig_cap;
+	const int32_t ncol = t.ncol, cap = t.cig_cap, lane = threadIdx.x;
 	int32_t i = t.nl - 1, j = t.al - 1, carry = 0, n = 0;
+	// the CIGAR operation being accumulated (ns_push_cigar merges equal neighbours except F/G, nasw.h:141-152)
+	int32_t cur_op = -1, cur_len = 0;
+	auto push = [&](int32_t op, int32_t len) {
+		if (cur_op == op && op != 10 && op != 11) { cur_len += len; return; }
+		if (cur_op >= 0) { if (lane == 0 && n < cap) cig[n] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n; }
+		cur_op = op, cur_len = len;
+	};
+	auto state_of = [](int32_t w) { return (w >> 9 & 1) ? 1 : (w & 0xf); };   // a cell raised by the cross-lane I counts as I
 	while (i >= 2 && j >= 0) {
-		int32_t w = tb[(int64_t)i * ncol + j], st, ext;
-		if (w >> 9 & 1) w = 1 | (w >> 4 << 4);
-		st = carry ? carry : (w & 0xf);
-		ext = (st >= 1 && st <= 5) ? (w >> (st + 3) & 1) : 0;
-		switch (st) {
-		case 0: cig_push(cig, n, cap, 0, 1); i -= 3; --j; break;
-		case 1: cig_push(cig, n, cap, 1, 1); --j; break;
-		case 2: cig_push(cig, n, cap, 2, 1); i -= 3; break;
-		case 3: cig_push(cig, n, cap, 3, 1); --i; break;
-		case 4: cig_push(cig, n, cap, 12, 1); --i; if (!ext) --j; break;
-		case 5: cig_push(cig, n, cap, 13, 1); --i; if (!ext) --j; break;
-		case 6: cig_push(cig, n, cap, 10, 1); --i; break;
-		case 7: cig_push(cig, n, cap, 10, 2); i -= 2; break;
-		case 8: cig_push(cig, n, cap, 11, 1); --i; --j; break;
-		case 9: cig_push(cig, n, cap, 11, 2); i -= 2; --j; break;
-		default: break;
+		int32_t st = carry;
+		if (st == 0) {                                           // fresh cell: its own state decides the direction
+			const int32_t w0 = tb[(int64_t)i * ncol + j];
+			st = state_of(w0);
 		}
-		carry = (st >= 1 && st <= 5 && ext) ? st : 0;
+		if (st == 0) {                                           // run of matches on the diagonal (i-3l, j-l)
+			const int32_t ii = i - 3 * lane, jj = j - lane;
+			const bool ok = ii >= 2 && jj >= 0;
+			const int32_t w = ok ? tb[(int64_t)ii * ncol + jj] : 0xf;
+			const uint64_t stop = __ballot(!ok || state_of(w) != 0);
+			const int32_t run = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+			push(0, run), i -= 3 * run, j -= run, carry = 0;
+		} else if (st <= 5) {                                    // extension runs: I along the row, D/N/U/V along the column
+			const int32_t di = st == 1 ? 0 : st == 2 ? 3 : 1, dj = st == 1 ? 1 : 0;
+			const int32_t ii = i - di * lane, jj = j - dj * lane;
+			const bool ok = ii >= 2 && jj >= 0;
+			const int32_t w = ok ? tb[(int64_t)ii * ncol + jj] : 0;
+			const bool ext = ok && (w >> (st + 3) & 1);
+			const uint64_t inval = __ballot(!ok), noext = __ballot(!ext);
+			// cells are consumed up to and including the first one whose extension bit is clear; a cell outside
+			// the matrix ends the walk before it is consumed
+			const int32_t first_noext = noext ? __ffsll((unsigned long long)noext) - 1 : 64;
+			const int32_t first_inval = inval ? __ffsll((unsigned long long)inval) - 1 : 64;
+			int32_t run;
+			bool closed;                                          // did the run meet a cell with the extension bit clear?
+			if (first_noext < first_inval) run = first_noext + 1, closed = true;
+			else run = first_inval, closed = false;
+			static const int32_t op_of[6] = { 0, 1, 2, 3, 12, 13 };
+			push(op_of[st], run);
+			i -= di * run, j -= dj * run;
+			if (closed && (st == 4 || st == 5)) --j;               // the intron of phase 1/2 ends inside a codon
+			carry = closed ? 0 : st;
+			if (run == 0) break;                                  // cannot happen (the loop condition holds for lane 0)
+		} else {                                                 // frameshifts: one cell
+			if (st == 6) push(10, 1), i -= 1;
+			else if (st == 7) push(10, 2), i -= 2;
+			else if (st == 8) push(11, 1), i -= 1, j -= 1;
+			else push(11, 2), i -= 2, j -= 1;
+			carry = 0;
+		}
 	}
-	if (j > 0) cig_push(cig, n, cap, 1, j);
+	if (j > 0) push(1, j);
 	if (i >= 0) {
 		const int32_t l = (i + 1) / 3 * 3, r = (i + 1) % 3;
-		if (l > 0) cig_push(cig, n, cap, 2, l);
-		if (r != 0) cig_push(cig, n, cap, 10, r);
+		if (l > 0) push(2, l);
+		if (r != 0) push(10, r);
 	}
-	for (int32_t x = 0; x < n >> 1; ++x) { uint32_t tmp = cig[x]; cig[x] = cig[n - 1 - x], cig[n - 1 - x] = tmp; }
-	for (int32_t x = 0; x < n; ++x) {                                   // ns_fix_tiny_UV
+	push(-2, 0);                                                 // flush
+	if (n > cap) n = cap;
+	__syncthreads();
+	for (int32_t x = lane; x < n >> 1; x += 64) { uint32_t tmp = cig[x]; cig[x] = cig[n - 1 - x], cig[n - 1 - x] = tmp; }
+	__syncthreads();
+	for (int32_t x = lane; x < n; x += 64) {                      // ns_fix_tiny_UV
 		const uint32_t op = cig[x] & 0xf;
 		if ((op == 12 || op == 13) && cig[x] >> 4 < 3) cig[x] = cig[x] >> 4 << 4 | 11;
 	}
-	n_cigar[tid] = n;
+	if (lane == 0) n_cigar[tid] = n;
 }
 
 } // namespace mpa

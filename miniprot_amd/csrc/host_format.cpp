@@ -117,6 +117,7 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
                                   const mpa_result_t *r, char **out)
 {
 	std::string s;
+	double t0 = now_ms();
 	const mpa_hit_t *hits = mpa_result_hits(r);
 	const int64_t *off = mpa_result_hit_off(r);
 	const uint32_t *cig = mpa_result_cigars(r);
@@ -136,6 +137,7 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 		}
 		if (n_out == 0 && (opt->flag & MPA_MF_SHOW_UNMAP)) put_paf(s, mi, *opt, names[i], seq, qlen, nullptr, cig);
 	}
+	timing_note("format_paf", now_ms() - t0);
 	char *buf = (char*)malloc(s.size() + 1);
 	memcpy(buf, s.data(), s.size());
 	buf[s.size()] = 0;

@@ -8,8 +8,10 @@
 //                                           regions -> refine (k=5 re-seeding + re-chaining) -> select ->
 //                                           extension limits -> per-region alignment plan
 //   DP round 1 (GPU)   left + right extensions of every region            ns_global_gs16b EXT_LEFT/EXT_RIGHT
+//                      + every gap between kept anchors with traceback (they do not depend on the extensions,
+//                        so they run concurrently with the long extension windows)
 //   DP round 2 (GPU)   the io_end retries of align.c:290-296,324-330
-//   DP round 3 (GPU)   every gap between kept anchors, plus the two extension spans, with traceback
+//   DP round 3 (GPU)   the two spans accepted by the extensions, with traceback
 //   stage B (host, threaded)                CIGAR assembly, mp_extra_* statistics, final ranking
 //
 // The object is a plain stage machine (mpa_batch_*): it hands out DP tasks and takes DP results, and does
@@ -26,8 +28,9 @@ namespace mpa {
 
 struct Segment {                     // one mp_align_seq() call (align.c:62-80)
 	int32_t ne0, ne1, ae0, ae1;      // window-relative nt span (w.r.t. vs0) and protein span
-	int32_t task = -1;               // DP task index of round 3, -1 = ungapped shortcut
+	int32_t task = -1;               // DP task index within its round, -1 = ungapped shortcut
 	int32_t score = 0;
+	std::vector<uint32_t> cigar;     // filled when the DP result arrives
 };
 
 struct AlignPlan {                   // the state of one mp_align() call
@@ -39,7 +42,9 @@ struct AlignPlan {                   // the state of one mp_align() call
 	int64_t mid_ve = 0;              // r->ve / r->qe after the gap-patching loop
 	int32_t mid_qe = 0;
 	bool has_right = false;
-	std::vector<Segment> segs;
+	Segment left_span, right_span;   // the spans accepted by the two extensions, re-aligned with traceback (round 3)
+	bool has_left_span = false, has_right_span = false;
+	std::vector<Segment> gaps;       // gaps between consecutive kept anchors: independent of the extensions (round 1)
 };
 
 struct QueryState {
@@ -402,6 +407,44 @@ static void stage_finish(mpa_batch_s *b, QueryState &qs)
 // ------------------------------------------------------------------------------------------------
 // DP rounds
 // ------------------------------------------------------------------------------------------------
+static int32_t ungapped_score(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Region &r, int64_t nt_off, int32_t alen, const char *aa)
+{
+	std::vector<uint8_t> nt((size_t)alen * 3);
+	fetch_nt(mi, (int32_t)r.vid, nt_off, nt_off + (int64_t)alen * 3, nt.data());
+	const uint8_t *aa20 = tab_aa20();
+	int32_t sc = 0;
+	// NB: the reference's loop (align.c:36) advances its nucleotide index by 3 but bounds it by the AMINO-ACID
+	// length, so only the first ceil(alen/3) codons contribute to AS:i.  Reproduced for byte-identical output.
+	for (int32_t i = 0, j = 0; i < alen; i += 3, ++j) sc += opt.mat[codon_aa(&nt[i]) * opt.asize + aa20[(uint8_t)aa[j]]];
+	return sc;
+}
+
+// one mp_align_seq() call: either the ungapped shortcut (align.c:65-67) or a DP task with traceback
+static void make_segment(mpa_batch_s *b, const QueryState &qs, const Region &r, const AlignPlan &pl, int32_t ne0, int32_t ne1, int32_t ae0, int32_t ae1,
+                         int32_t qi, int32_t pi, std::vector<mpa_dp_task_t> &tasks, std::vector<std::pair<int32_t, int32_t>> &owner, Segment &s)
+{
+	const mpa_mapopt_t &opt = b->opt;
+	s.ne0 = ne0, s.ne1 = ne1, s.ae0 = ae0, s.ae1 = ae1;
+	const int32_t nlen = ne1 - ne0, alen = ae1 - ae0;
+	if (nlen == alen * 3 && alen <= opt.kmer2) {
+		s.task = -1;
+		s.score = ungapped_score(b->mi, opt, r, pl.vs0 + ne0, alen, qs.seq + ae0);
+		s.cigar.assign(1, (uint32_t)alen << 4);
+	} else {
+		s.task = (int32_t)tasks.size();
+		tasks.push_back(make_task(qs, r, pl.vs0 + ne0, nlen, ae0, alen, MPA_F_CIGAR, opt.io));
+		owner.emplace_back(qi, pi);
+	}
+}
+
+static void store_result(Segment &s, const mpa_dp_rst_t *rst, const uint32_t *pool)
+{
+	if (s.task < 0) return;
+	const mpa_dp_rst_t &o = rst[s.task];
+	s.score = o.score;
+	s.cigar.assign(pool + o.cigar_off, pool + o.cigar_off + o.n_cigar);
+}
+
 static void emit_round1(mpa_batch_s *b)
 {
 	const mpa_mapopt_t &opt = b->opt;
@@ -418,11 +461,20 @@ static void emit_round1(mpa_batch_s *b)
 				b->tasks.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
 				b->task_owner.emplace_back((int32_t)qi, (int32_t)pi);
 			}
+			// gaps between consecutive kept anchors (align.c:305-313, all iterations but the first)
+			int32_t ne0 = (int32_t)(pl.vs1 - pl.vs0), ae0 = pl.as1;
+			for (int32_t i = pl.i0 + 1; i < r.cnt; ++i) {
+				if (!(r.a[i] >> 31 & 1)) continue;
+				const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
+				pl.gaps.emplace_back();
+				make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, (int32_t)qi, (int32_t)pi, b->tasks, b->task_owner, pl.gaps.back());
+				ne0 = ne1, ae0 = ae1;
+			}
 		}
 	}
 }
 
-static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst)
+static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
 {
 	const mpa_mapopt_t &opt = b->opt;
 	std::vector<mpa_dp_task_t> next;
@@ -432,6 +484,7 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
 			const Region &r = qs.regs[pl.reg];
+			for (Segment &g : pl.gaps) store_result(g, rst, pool);
 			pl.l_nt = rst[pl.t_left].nt_len, pl.l_aa = rst[pl.t_left].aa_len;
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
@@ -454,18 +507,6 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 	b->task_owner.swap(owner);
 }
 
-static int32_t ungapped_score(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Region &r, int64_t nt_off, int32_t alen, const char *aa)
-{
-	std::vector<uint8_t> nt((size_t)alen * 3);
-	fetch_nt(mi, (int32_t)r.vid, nt_off, nt_off + (int64_t)alen * 3, nt.data());
-	const uint8_t *aa20 = tab_aa20();
-	int32_t sc = 0;
-	// NB: the reference's loop (align.c:36) advances its nucleotide index by 3 but bounds it by the AMINO-ACID
-	// length, so only the first ceil(alen/3) codons contribute to AS:i.  Reproduced for byte-identical output.
-	for (int32_t i = 0, j = 0; i < alen; i += 3, ++j) sc += opt.mat[codon_aa(&nt[i]) * opt.asize + aa20[(uint8_t)aa[j]]];
-	return sc;
-}
-
 static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 {
 	const mpa_mapopt_t &opt = b->opt;
@@ -478,32 +519,16 @@ static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 			Region &r = qs.regs[pl.reg];
 			if (pl.t_left2 >= 0 && rst[pl.t_left2].aa_len == pl.as1) pl.l_nt = rst[pl.t_left2].nt_len, pl.l_aa = rst[pl.t_left2].aa_len;
 			if (pl.t_right2 >= 0 && rst[pl.t_right2].aa_len == qs.qlen - pl.mid_qe) pl.r_nt = rst[pl.t_right2].nt_len, pl.r_aa = rst[pl.t_right2].aa_len;
-			// region start after the left extension (align.c:297-300)
+			// region start after the left extension (align.c:297-300); its span is the first mp_align_seq() call
 			r.vs = pl.vs1 - pl.l_nt;
 			r.qs = pl.as1 - pl.l_aa;
-			int32_t ne0 = (int32_t)(r.vs - pl.vs0), ae0 = r.qs;
-			auto add_segment = [&](int32_t ne1, int32_t ae1) {
-				Segment s;
-				s.ne0 = ne0, s.ne1 = ne1, s.ae0 = ae0, s.ae1 = ae1;
-				const int32_t nlen = ne1 - ne0, alen = ae1 - ae0;
-				if (nlen == alen * 3 && alen <= opt.kmer2) {
-					s.task = -1;
-					s.score = ungapped_score(b->mi, opt, r, pl.vs0 + ne0, alen, qs.seq + ae0);
-				} else {
-					s.task = (int32_t)next.size();
-					next.push_back(make_task(qs, r, pl.vs0 + ne0, nlen, ae0, alen, MPA_F_CIGAR, opt.io));
-					owner.emplace_back((int32_t)qi, (int32_t)pi);
-				}
-				pl.segs.push_back(s);
-			};
-			for (int32_t i = pl.i0; i < r.cnt; ++i) {                 // gaps between kept anchors (align.c:305-313)
-				if (!(r.a[i] >> 31 & 1)) continue;
-				const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
-				add_segment(ne1, ae1);
-				ne0 = ne1, ae0 = ae1;
+			pl.has_left_span = true;
+			make_segment(b, qs, r, pl, (int32_t)(r.vs - pl.vs0), (int32_t)(pl.vs1 - pl.vs0), r.qs, pl.as1, (int32_t)qi, (int32_t)pi, next, owner, pl.left_span);
+			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0) {             // the accepted right-extension span (align.c:331)
+				const int32_t ne0 = (int32_t)(pl.mid_ve - pl.vs0);
+				pl.has_right_span = true;
+				make_segment(b, qs, r, pl, ne0, ne0 + pl.r_nt, pl.mid_qe, pl.mid_qe + pl.r_aa, (int32_t)qi, (int32_t)pi, next, owner, pl.right_span);
 			}
-			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0)              // the accepted right-extension span (align.c:331)
-				add_segment(ne0 + pl.r_nt, ae0 + pl.r_aa);
 		}
 	}
 	b->tasks.swap(next);
@@ -518,14 +543,15 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 			Region &r = qs.regs[pl.reg];
 			int32_t score = 0;
 			r.cigar.clear();
-			for (Segment &s : pl.segs) {
-				if (s.task < 0) append_cigar(r.cigar, 0, s.ae1 - s.ae0), score += s.score;
-				else {
-					const mpa_dp_rst_t &o = rst[s.task];
-					for (int32_t k = 0; k < o.n_cigar; ++k) append_cigar(r.cigar, pool[o.cigar_off + k] & 0xf, (int32_t)(pool[o.cigar_off + k] >> 4));
-					score += o.score;
-				}
-			}
+			if (pl.has_left_span) store_result(pl.left_span, rst, pool);
+			if (pl.has_right_span) store_result(pl.right_span, rst, pool);
+			auto add = [&](const Segment &s) {
+				for (uint32_t c : s.cigar) append_cigar(r.cigar, c & 0xf, (int32_t)(c >> 4));
+				score += s.score;
+			};
+			if (pl.has_left_span) add(pl.left_span);
+			for (const Segment &g : pl.gaps) add(g);
+			if (pl.has_right_span) add(pl.right_span);
 			r.ve = pl.mid_ve, r.qe = pl.mid_qe;
 			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0) r.ve += pl.r_nt, r.qe += pl.r_aa;
 			r.aligned = true;
@@ -555,7 +581,9 @@ mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const
 	for (int32_t i = 0; i < q->n_seq; ++i) {
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 	}
+	double t0 = now_ms();
 	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); });
+	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
 	return b;
 }
@@ -564,7 +592,9 @@ int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpop
 {
 	if (opt) *opt = b->dpopt;
 	if (b->round == 0) {
+		double t0 = now_ms();
 		emit_round1(b);
+		timing_note("emit round 1", now_ms() - t0);
 		b->round = 1;
 		if (b->tasks.empty()) { take_round3(b, nullptr, nullptr); b->round = 4; }   // nothing to align at all
 	}
@@ -581,15 +611,17 @@ int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpop
 
 int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool)
 {
-	if (b->round == 1) { take_round1_emit_round2(b, rst); b->round = 2; }
-	else if (b->round == 2) { take_round2_emit_round3(b, rst); b->round = 3; }
-	else if (b->round == 3) { take_round3(b, rst, cigar_pool); b->round = 4; b->tasks.clear(); }
+	double t0 = now_ms();
+	if (b->round == 1) { take_round1_emit_round2(b, rst, cigar_pool); b->round = 2; timing_note("take 1 / emit 2", now_ms() - t0); }
+	else if (b->round == 2) { take_round2_emit_round3(b, rst); b->round = 3; timing_note("take 2 / emit 3", now_ms() - t0); }
+	else if (b->round == 3) { take_round3(b, rst, cigar_pool); b->round = 4; b->tasks.clear(); timing_note("take 3 + finish", now_ms() - t0); }
 	else { set_error("mpa_batch_dp_results called out of sequence"); return MPA_ERR_ARG; }
 	return MPA_OK;
 }
 
 mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
 {
+	double t_fin = now_ms();
 	mpa_result_s *res = new mpa_result_s();
 	res->n_seq = (int32_t)b->qs.size();
 	res->hit_off.assign(b->qs.size() + 1, 0);
@@ -620,6 +652,7 @@ mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
 	}
 	res->hit_off[b->qs.size()] = (int64_t)res->hits.size();
 	delete b;
+	timing_note("batch_finish (flatten)", now_ms() - t_fin);
 	return res;
 }
 
@@ -644,7 +677,9 @@ int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 		uint32_t *pool = nullptr;
 		int64_t n_pool = 0;
 		rst.resize((size_t)n);
+		double t0 = now_ms();
 		int rc = mpa_dp_run(ctx, mi, &dpopt, q, n, tasks, rst.data(), &pool, &n_pool);
+		timing_note("mpa_dp_run (total)", now_ms() - t0);
 		if (rc != MPA_OK) { free(pool); delete b; return rc; }
 		rc = mpa_batch_dp_results(b, rst.data(), pool);
 		free(pool);

@@ -23,6 +23,11 @@ extern const char *const kAA;        // "ARNDCQEGHILKMFPSTWYV*X"
 
 void set_error(const std::string &msg);
 
+// MPA_TIMING=1 prints wall-clock stage timings to stderr
+double now_ms();
+bool timing_on();
+void timing_note(const char *what, double ms);
+
 // ---- index (index.cpp) ---------------------------------------------------------------------------
 struct Contig { int64_t off, len; std::string name; };
 

@@ -6,6 +6,9 @@
 #include <cstring>
 #include <cmath>
 #include <mutex>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "mpa_internal.h"
 
 namespace mpa {
@@ -104,6 +107,10 @@ static const int8_t kBlosum62[484] = {
 	 0,-1,-1,-1,-2,-1,-1,-1,-1,-1,-1,-1,-1,-1,-2, 0, 0,-2,-1,-1,-4,-1
 };
 const int8_t *blosum62() { return kBlosum62; }
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool timing_on() { static int on = -1; if (on < 0) { const char *e = getenv("MPA_TIMING"); on = e && *e && *e != '0'; } return on != 0; }
+void timing_note(const char *what, double ms) { if (timing_on()) fprintf(stderr, "[mpa-timing] %-28s %9.3f ms\n", what, ms); }
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }

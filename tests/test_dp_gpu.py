@@ -41,7 +41,7 @@ def test_shape_classes(ctx, oracle_built):
     rng = np.random.default_rng(12)
     P = refbind.DpParams(refbind.mapping_matrix(23))
     pairs = []
-    for al in (1, 2, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 57, 63, 64, 65, 72, 120, 128, 129, 200, 250, 300, 500):
+    for al in (1, 2, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 57, 63, 64, 65, 72, 120, 128, 129, 200, 250, 257, 300, 500, 513, 700, 1000):
         for _ in range(3):
             pairs.append(make_task(rng, al=al, p_indel=0.0))
     run_case(ctx, pairs, P, rng)
