@@ -26,7 +26,8 @@ struct DTask {
 };
 
 // Per-row record produced by the prep kernel, one uint32 per window row i:
-//   byte0 nas[i]        amino acid (aa20 code) of the codon ending at row i, 21 when undefined
+//   byte0 8*nas[i]      nas = amino acid (aa20 code) of the codon ending at row i, 21 when undefined; stored
+//                       times 8 because it is used directly as a byte offset into an LDS profile column
 //   byte1 donor[i+1]    (int8)  penalty of an intron whose first base is row i+2
 //   byte2 gei[i]        (uint8) gap-extension of D at this row: fs when nas[i] is a stop, else ge
 //   byte3 acceptor[i]   (int8)  penalty of an intron whose last base is row i

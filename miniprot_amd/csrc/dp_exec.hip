@@ -136,14 +136,10 @@ static int ext_class_of(int32_t ncol)
 	return -1;
 }
 
-template<int G, int NB> static hipError_t launch_ext(const ExtArgs &a, int n_waves, hipStream_t s)
+template<int G> static hipError_t launch_ext(const ExtArgs &a, int n_waves, hipStream_t s)
 {
-	const size_t lds = (size_t)2 * (64 / G) * 22 * G * NB * 2 + 2 * MPA_PEN_MAX * 4;
-	if (lds > 48 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void*)k_ext<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-	}
-	hipLaunchKernelGGL((k_ext<G, NB>), dim3(n_waves), dim3(64), lds, s, a);
+	const size_t lds = (size_t)2 * (64 / G) * G * PROF_COL_STRIDE + (size_t)(64 / G) * 32 * 8 + 2 * MPA_PEN_MAX * 4;
+	hipLaunchKernelGGL((k_ext<G>), dim3(n_waves), dim3(64), lds, s, a);
 	return hipGetLastError();
 }
 
@@ -161,9 +157,9 @@ template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_g
 static hipError_t launch_ext_class(int k, const ExtArgs &a, const ExtWideArgs &wa, int n_waves, hipStream_t s)
 {
 	switch (k) {
-	case 0: return launch_ext<16, 1>(a, n_waves, s);
-	case 1: return launch_ext<32, 1>(a, n_waves, s);
-	case 2: return launch_ext<64, 1>(a, n_waves, s);
+	case 0: return launch_ext<16>(a, n_waves, s);
+	case 1: return launch_ext<32>(a, n_waves, s);
+	case 2: return launch_ext<64>(a, n_waves, s);
 	case 3: return launch_ext_wide<2>(wa, n_waves, s);
 	case 4: return launch_ext_wide<4>(wa, n_waves, s);
 	case 5: return launch_ext_wide<8>(wa, n_waves, s);
@@ -316,7 +312,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		t.cig_off = cig_total, cig_total += t.cig_cap;
 		if (t.pad_ == 7) t.bnd_off = bnd_total, bnd_total += t.nl;
 	}
-	rec_total += max_nl + 16;                               // kernels read a few records past a call's end
+	rec_total += max_nl + 64;                               // kernels prefetch records up to 48 rows past a call's end
 
 	// ---- waves of the extension kernel
 	std::vector<ExtWave> ewaves;

@@ -128,6 +128,7 @@ __device__ __forceinline__ int32_t s_add(int32_t a, int32_t b) { return sat16(a 
 // K3: per-row records and query profiles
 // ------------------------------------------------------------------------------------------------
 struct PrepChunk { int32_t task; int32_t row0; };
+#define PROF_AA_STRIDE_REC 8   /* byte0 of a record = amino acid * 8 = byte offset into a profile column (k_ext) */
 
 // base of the strand-oriented contig at strand-local position x (ntseq.c:89-106 folded into addressing)
 __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off, int64_t len, int rev, int64_t x)
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 		}
 	}
 #undef B_
-	rec[t.rec_off + i] = make_rec(nas, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
+	rec[t.rec_off + i] = make_rec(nas * PROF_AA_STRIDE_REC, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
 }
 
 // query profile prof[a][col] = mat[a][aa(col)] (ns_gen_prof nasw-sse.c:212-224); columns >= al score -32768
@@ -236,6 +237,20 @@ __global__ __launch_bounds__(256) void k_prep_prof(const DTask *tasks, const cha
 
 // ------------------------------------------------------------------------------------------------
 // K1: extension (score only).  See file header.
+//
+// A lone wavefront pays >= 4 cycles for every instruction it issues, and at the batch sizes of a 1k-protein
+// step the GPU is latency bound (one 100k-row window per wave decides the wall time), so the row loop is
+// written for a minimal instruction count:
+//   * row records come from a small LDS ring refilled 16 rows at a time (one coalesced global load per
+//     16 rows instead of two dependent loads per row);
+//   * the query profile sits in LDS with an 8-byte stride per amino acid, {score, score<<16}, so that the
+//     two halves of a lane fetch their score with `base + byte0(record)` (one SDWA add each) and combine
+//     with one OR;
+//   * donor/acceptor windows and the H/D rings are register rings indexed at compile time (rows are
+//     processed in groups of three), so no state is ever moved;
+//   * the best-row / x-drop bookkeeping is two saturating subtractions and one compare per row: a lane votes
+//     if it beats the call's best score, and one "witness" lane per call proves the row is not x-dropped;
+//     everything exact happens in a rare slow path.
 // ------------------------------------------------------------------------------------------------
 struct ExtArgs {
 	const DTask *tasks;
@@ -247,101 +262,103 @@ struct ExtArgs {
 	PenTable pen;
 };
 
-template<int G, int NB>
+#define PROF_AA_STRIDE 8                       /* bytes per amino acid inside one column of the LDS profile */
+#define PROF_COL_STRIDE 184                    /* bytes per column: 23 * 8, an odd number of 8-byte words    */
+
+template<int G>
 __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 {
-	constexpr int NG = 64 / G;             // lane groups
-	constexpr int PW = G * NB;             // profile row width (columns)
+	constexpr int NG = 64 / G;               // lane groups per wave
+	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
 	extern __shared__ uint32_t lds_raw[];
-	int16_t *lds_prof = (int16_t*)lds_raw; // [2*NG slots][22][PW]
-	int32_t *lds_pen = (int32_t*)(lds_prof + 2 * NG * 22 * PW); // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
+	char *lds_prof = (char*)lds_raw;                                   // [NSLOT][G columns][23][2 x u32]
+	uint2 *lds_ring = (uint2*)(lds_prof + NSLOT * G * PROF_COL_STRIDE); // [NG][32 rows] {record of half 0, record of half 1}
+	int32_t *lds_pen = (int32_t*)(lds_ring + NG * 32);                 // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
 
 	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
-	const ExtWave wv = a.waves[blockIdx.x];
+	const ExtWave *wvp = &a.waves[blockIdx.x];
 	const DpConst c = a.c;
-	const uint32_t *recbase = a.rec + wv.rec_base;
+	const uint32_t *recbase = a.rec + wvp->rec_base;
+	const int32_t max_nl = wvp->max_nl;
 
 	int32_t tid[2], nl[2], al[2], ncol[2];
 	uint32_t roff[2];
 	bool done[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		tid[h] = wv.task[h * NG + grp];
+		tid[h] = wvp->task[h * NG + grp];
 		if (tid[h] >= 0) {
 			const DTask *t = &a.tasks[tid[h]];
 			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol;
-			roff[h] = (uint32_t)(t->rec_off - wv.rec_base);
+			roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
 			done[h] = false;
 		} else nl[h] = 0, al[h] = 1, ncol[h] = G, roff[h] = 0, done[h] = true;
 	}
-	// stage profiles and the penalty table in LDS
-	for (int s = 0; s < 2 * NG; ++s) {
-		int t = wv.task[s];
-		if (t < 0) continue;
-		const int16_t *src = a.prof + a.tasks[t].prof_off;
-		for (int k = lane; k < 22 * PW; k += 64) lds_prof[s * 22 * PW + k] = src[k];
+	// ---- stage the profiles: global [22][pw] int16 -> LDS [col][aa]{lo, hi}
+	for (int s = 0; s < NSLOT; ++s) {
+		const int t = wvp->task[s];
+		if (t < 0) {   // the two halves of a lane are OR-ed together: an empty slot must read as zero
+			for (int k = lane; k < G * PROF_COL_STRIDE / 4; k += 64) ((uint32_t*)(lds_prof + s * G * PROF_COL_STRIDE))[k] = 0;
+			continue;
+		}
+		const DTask *tt = &a.tasks[t];
+		const int16_t *src = a.prof + tt->prof_off;
+		for (int k = lane; k < 22 * G; k += 64) {
+			const int aa = k / G, cc = k - aa * G;
+			const uint32_t v = (uint16_t)src[aa * tt->pw + cc];
+			*(uint2*)(lds_prof + (s * G + cc) * PROF_COL_STRIDE + aa * PROF_AA_STRIDE) = make_uint2(v, v << 16);
+		}
 	}
 	for (int k = lane; k < MPA_PEN_MAX; k += 64) lds_pen[k] = a.pen.x[k], lds_pen[MPA_PEN_MAX + k] = a.pen.val[k];
+	// ---- record ring of 32 rows per lane group.  Lane (grp, col<16) moves row (16k + col): rows [0,16) go in now,
+	// rows [16,32) wait in `pf`; from then on rows [i+16, i+32) are fetched when i%16==0 and published when i%16==12.
+	const bool loader = col < 16;
+	uint2 pf = make_uint2(0, 0);
+	if (loader) {
+		lds_ring[grp * 32 + col] = make_uint2(recbase[roff[0] + col], recbase[roff[1] + col]);
+		pf = make_uint2(recbase[roff[0] + 16 + col], recbase[roff[1] + 16 + col]);
+	}
 	__syncthreads();
 
 	// ---- per-lane constants
-	uint32_t jge[NB], gojge[NB], ebv[NB];
-	uint64_t vm[2][NB];
-#pragma unroll
-	for (int b = 0; b < NB; ++b) {
-		const int gc = b * G + col;
-		jge[b] = splat16(gc * c.ge);
-		gojge[b] = splat16(c.go + gc * c.ge);
-		const int32_t ebp = c.end_bonus > 0 ? c.end_bonus : 0;
-		ebv[b] = pack16(gc == al[0] - 1 ? ebp : 0, gc == al[1] - 1 ? ebp : 0);
-		vm[0][b] = __ballot(gc < ncol[0]);
-		vm[1][b] = __ballot(gc < ncol[1]);
-	}
-	const uint32_t goP = splat16(c.go), ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0), fsP = splat16(c.fs);
-	const int pbase0 = ((0 * NG + grp) * 22 * PW + col) * 2, pbase1 = ((1 * NG + grp) * 22 * PW + col) * 2; // byte offsets
-	const char *ldsb = (const char*)lds_prof;
+	const uint32_t jge = splat16(col * c.ge), gojge = splat16(c.go + col * c.ge);
+	const uint32_t ebv = pack16(col == al[0] - 1 ? c.end_bonus : 0, col == al[1] - 1 ? c.end_bonus : 0);
+	const uint32_t vmskP = (col < ncol[0] ? 0x8000u : 0u) | (col < ncol[1] ? 0x80000000u : 0u);   // sign bits of the live halves
+	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
+	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
+	const uint32_t pbase0 = (uint32_t)(((0 * NG + grp) * G + col) * PROF_COL_STRIDE);
+	const uint32_t pbase1 = (uint32_t)(((1 * NG + grp) * G + col) * PROF_COL_STRIDE) + 4;           // the <<16 copy
+	const uint2 *ring = lds_ring + grp * 32;
 
-	// ---- DP state: rings of 3 rows for H (and its left-shifted copy) and D; A/B/C persist
-	uint32_t Hr[3][NB], Hs[3][NB], Dr[3][NB], A[NB], B[NB], C[NB], Hbest[NB];
+	// ---- DP state: rings of three rows (compile-time indexed), A/B/C persist
+	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP, Hbest = NEGP;
 #pragma unroll
-	for (int b = 0; b < NB; ++b) {
-#pragma unroll
-		for (int k = 0; k < 3; ++k) Hr[k][b] = Hs[k][b] = Dr[k][b] = NEGP;
-		A[b] = B[b] = C[b] = Hbest[b] = NEGP;
-	}
+	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
 	// virtual column -1 as row 2 sees it (nasw-sse.c:256-258): H(-1,-1)=0, H(0,-1)=H(1,-1)=-fs
-	if (col == 0) Hs[2][0] = 0u, Hs[1][0] = splat16(-c.fs), Hs[0][0] = splat16(-c.fs);
+	if (col == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
+	// donor[i-1], donor[i], donor[i+1] live in dn[R1], dn[R2]... : record r carries donor[r+1] and acceptor[r]
+	{
+		const uint2 q0 = ring[0], q1 = ring[1];
+		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
+		ac[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0b070903u), ac[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0b070903u);
+		dn[2] = ac[2] = 0;
+	}
 
 	// ---- bookkeeping of the reference's score-only loop (nasw-sse.c:423-433), per half
 	int32_t Gs[2] = { NEG16, NEG16 }, maxi[2] = { -1, -1 }, maxsc[2] = { INT32_MIN, INT32_MIN };
-	int32_t pk[2] = { 0, 0 }, pen[2] = { 0, 0 };
-	uint32_t Gv = NEGP, Tv = NEGP, penP = 0;
-	int32_t next_event = 2, n_active = 0;
-
-	// ---- row constants: sliding windows donor[i-1..i+1], acceptor[i-2..i]
-	uint32_t rA0 = recbase[roff[0] + 0], rB0 = recbase[roff[1] + 0];
-	uint32_t rA1 = recbase[roff[0] + 1], rB1 = recbase[roff[1] + 1];
-	uint32_t dim1, di = __builtin_amdgcn_perm(rB0, rA0, 0x0a050801u), dip1 = __builtin_amdgcn_perm(rB1, rA1, 0x0a050801u);
-	uint32_t aim2, aim1 = __builtin_amdgcn_perm(rB0, rA0, 0x0b070903u), ai = __builtin_amdgcn_perm(rB1, rA1, 0x0b070903u);
-	// software pipeline: records of rows i and i+1 in registers, profile scores of row i in registers
-	uint32_t r0A = recbase[roff[0] + 2], r0B = recbase[roff[1] + 2];
-	uint32_t r1A = recbase[roff[0] + 3], r1B = recbase[roff[1] + 3];
-	uint32_t S[NB];
-	{
-		const int o0 = pbase0 + (int)(r0A & 0xff) * (PW * 2), o1 = pbase1 + (int)(r0B & 0xff) * (PW * 2);
-#pragma unroll
-		for (int b = 0; b < NB; ++b)
-			S[b] = pack16(*(const int16_t*)(ldsb + o0 + b * G * 2), *(const int16_t*)(ldsb + o1 + b * G * 2));
-	}
+	int32_t pk[2] = { 0, 0 }, pen[2] = { 0, 0 }, wit[2] = { -1, -1 };
+	uint32_t Gv = NEGP, Tv = NEGP, penP = 0, witP = 0;
+	int32_t next_event = 2, limit = max_nl;
 
 	auto repack = [&]() {
 		Gv = pack16(done[0] ? 32767 : Gs[0], done[1] ? 32767 : Gs[1]);
 		Tv = pack16(done[0] ? NEG16 : sat16(Gs[0] - c.xdrop), done[1] ? NEG16 : sat16(Gs[1] - c.xdrop));
 		penP = pack16(pen[0], pen[1]);
-		n_active = __popcll(__ballot(!done[0] && col == 0)) + __popcll(__ballot(!done[1] && col == 0));
+		witP = (!done[0] && wit[0] == col ? 0x8000u : 0u) | (!done[1] && wit[1] == col ? 0x80000000u : 0u);
+		if (__ballot(!done[0] || !done[1]) == 0) limit = 0;                 // every call of the wave has finished
 	};
 
-	// task ends and changes of the length penalty: rare, handled before the row is computed
+	// task ends and steps of the length penalty: rare, handled before the row is computed
 	auto events = [&](int32_t i) {
 		int32_t nx = INT32_MAX;
 #pragma unroll
@@ -357,108 +374,96 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 			}
 		}
 #pragma unroll
-		for (int off = 1; off < 64; off <<= 1) { int32_t o = __shfl_xor(nx, off); nx = nx < o ? nx : o; }
-		next_event = nx;
+		for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_xor(nx, off); nx = nx < o ? nx : o; }
+		next_event = __builtin_amdgcn_readfirstlane(nx);
 		repack();
 	};
 
 	int32_t i = 2;
-	const int32_t max_nl = wv.max_nl;
+	uint2 rcur = ring[2];                                                  // record of row i
+	uint32_t S;                                                            // profile scores of row i
+	{
+		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rcur.x & 0xff));
+		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rcur.y & 0xff));
+		S = s0 | s1;
+	}
 
 	auto row = [&](auto kc) {
 		constexpr int K = decltype(kc)::value;
 		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;   // ring slots of rows i-1, i-2, i-3
-		// prefetch the record of row i+2
-		const uint32_t r2A = recbase[roff[0] + (uint32_t)i + 2], r2B = recbase[roff[1] + (uint32_t)i + 2];
-		// unpack the record of row i
-		const uint32_t dnew = __builtin_amdgcn_perm(r0B, r0A, 0x0a050801u);
-		const uint32_t anew = __builtin_amdgcn_perm(r0B, r0A, 0x0b070903u);
-		const uint32_t gei = __builtin_amdgcn_perm(r0B, r0A, 0x0c060c02u);
-		dim1 = di, di = dip1, dip1 = dnew;
-		aim2 = aim1, aim1 = ai, ai = anew;
-		// profile scores of row i+1 (LDS latency overlaps this row's arithmetic)
-		uint32_t Sn[NB];
-		{
-			const int o0 = pbase0 + (int)(r1A & 0xff) * (PW * 2), o1 = pbase1 + (int)(r1B & 0xff) * (PW * 2);
-#pragma unroll
-			for (int b = 0; b < NB; ++b)
-				Sn[b] = pack16(*(const int16_t*)(ldsb + o0 + b * G * 2), *(const int16_t*)(ldsb + o1 + b * G * 2));
+		// ring maintenance, 16 rows at a time: fetch rows [i+16, i+32) when i%16==0, publish them when i%16==12
+		if ((i & 15) == 0) {                                               // (the first publish, at i=12, is the preloaded rows [16,32))
+			if (loader) pf = make_uint2(recbase[roff[0] + (uint32_t)i + 16 + col], recbase[roff[1] + (uint32_t)i + 16 + col]);
+		} else if ((i & 15) == 12) {
+			if (loader) lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
 		}
-		uint32_t carry = NEGP, prev_last = NEGP;
-		uint32_t Hn[NB];
-		uint64_t impm = 0, alv0 = 0, alv1 = 0;
-#pragma unroll
-		for (int b = 0; b < NB; ++b) {
-			uint32_t h, t, u;
-			h = p_adds(Hs[R3][b], S[b]);                                    // H(i-3,j-1) + s(i,j)
-			u = p_subs(Hr[R3][b], goP); t = p_max(u, Dr[R3][b]);            // D
-			t = p_subs(t, gei); Dr[R3][b] = t; h = p_max(h, t);
-			u = p_subs(Hr[R1][b], ioP); t = p_subs(u, dim1);                // A: phase-0 intron
-			t = p_max(t, A[b]); A[b] = t; h = p_max(h, p_subs(t, ai));
-			u = p_subs(Hs[R1][b], ioP); t = p_subs(u, di);                  // B: phase-1 intron
-			t = p_max(t, B[b]); B[b] = t; h = p_max(h, p_subs(t, aim2));
-			t = p_subs(u, dip1);                                            // C: phase-2 intron
-			t = p_max(t, C[b]); C[b] = t; h = p_max(h, p_subs(t, aim1));
-			t = p_max(p_max(Hr[R1][b], Hr[R2][b]), p_max(Hs[R1][b], Hs[R2][b])); // four frameshift moves
-			h = p_max(h, p_subs(t, fsP));
-			// horizontal gap chain as a prefix max of h + j*ge
-			uint32_t y = scan_max_pk<G>(p_adds(h, jge[b]));
-			uint32_t ex = shift1<G>(y, NEGP, lane);
-			if (NB > 1) {
-				ex = p_max(ex, carry);
-				carry = p_max(carry, (uint32_t)__builtin_amdgcn_readlane((int)y, 63));
-			}
-			h = p_max(h, p_subs(ex, gojge[b]));
-			Hn[b] = h;
-			// left-shifted copy for the next rows
-			uint32_t hs = shift1<G>(h, (NB > 1 && b > 0) ? prev_last : NEGP, lane);
-			if (NB > 1) prev_last = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
-			Hr[R3][b] = h, Hs[R3][b] = hs;
-			// votes against the per-call thresholds
-			const uint32_t cand = p_subs(p_adds(h, ebv[b]), penP);
-			impm |= (__ballot(lo16(cand) > lo16(Gv)) & vm[0][b]) | (__ballot(hi16(cand) > hi16(Gv)) & vm[1][b]);
-			alv0 |= __ballot(!(lo16(cand) < lo16(Tv))) & vm[0][b];
-			alv1 |= __ballot(!(hi16(cand) < hi16(Tv))) & vm[1][b];
-		}
-		if (impm != 0 || has_empty_group<G>(alv0) || has_empty_group<G>(alv1)) {
+		// record of row i+1 and its profile scores (LDS latency overlaps this row's arithmetic)
+		const uint2 rnext = ring[(i + 1) & 31];
+		// unpack the record of row i: donor[i+1], acceptor[i], gap extension of this row
+		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);        // dn: R1 = donor[i-1], R2 = donor[i]... see below
+		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
+		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
+		// after the two assignments: dn[R3]=donor[i+1], dn[R1]=donor[i], dn[R2]=donor[i-1];
+		//                            ac[R3]=acceptor[i], ac[R1]=acceptor[i-1], ac[R2]=acceptor[i-2]
+		uint32_t h, t, u;
+		h = p_adds(Hs[R3], S);                                             // H(i-3,j-1) + s(i,j)
+		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);                     // D
+		t = p_subs(t, gei); Dr[R3] = t; h = p_max(h, t);
+		u = p_subs(Hr[R1], ioP); t = p_subs(u, dn[R2]);                    // A: phase-0 intron, donor[i-1], acceptor[i]
+		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ac[R3]));
+		u = p_subs(Hs[R1], ioP); t = p_subs(u, dn[R1]);                    // B: phase-1 intron, donor[i], acceptor[i-2]
+		t = p_max(t, B); B = t; h = p_max(h, p_subs(t, ac[R2]));
+		t = p_subs(u, dn[R3]);                                             // C: phase-2 intron, donor[i+1], acceptor[i-1]
+		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, ac[R1]));
+		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));          // four frameshift moves
+		h = p_max(h, p_subs(t, fsP));
+		// next row's profile lookups, issued here so that they are back before the next row starts
+		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rnext.x & 0xff));
+		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rnext.y & 0xff));
+		// horizontal gap chain as a prefix max of h + j*ge
+		const uint32_t y = scan_max_pk<G>(p_adds(h, jge));
+		const uint32_t ex = shift1<G>(y, NEGP, lane);
+		h = p_max(h, p_subs(ex, gojge));
+		Hr[R3] = h, Hs[R3] = shift1<G>(h, NEGP, lane);
+		// votes: sign bit of x set <=> this lane beats the call's best; of y <=> below the x-drop threshold
+		const uint32_t cand = p_subs(p_adds(h, ebv), penP);
+		const uint32_t x = p_subs(Gv, cand), yy = p_subs(cand, Tv);
+		const uint32_t vote = (x & vmskP) | (yy & witP);
+		if (__ballot(vote != 0) != 0) {
 			// slow path: exact restatement of nasw-sse.c:423-433 for the calls that need it
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				int32_t m = NEG16;
-#pragma unroll
-				for (int b = 0; b < NB; ++b) {
-					const int32_t cv = half16(p_subs(p_adds(Hn[b], ebv[b]), penP), h);
-					if (b * G + col < ncol[h]) m = imax(m, cv);
+			for (int hh = 0; hh < 2; ++hh) {
+				const int32_t cv = half16(cand, hh);
+				const bool live = col < ncol[hh];
+				const int32_t m = group_max<G>(live ? cv : NEG16);
+				if (!done[hh] && m > Gs[hh]) {                               // new best row
+					Gs[hh] = m, maxi[hh] = i, maxsc[hh] = m + pen[hh];
+					Hbest = hh ? ((Hbest & 0xffffu) | (h & 0xffff0000u)) : ((Hbest & 0xffff0000u) | (h & 0xffffu));
 				}
-				m = group_max<G>(m);
-				if (!done[h] && m > Gs[h]) {                                 // new best row
-					Gs[h] = m, maxi[h] = i, maxsc[h] = m + pen[h];
-#pragma unroll
-					for (int b = 0; b < NB; ++b)
-						Hbest[b] = h ? ((Hbest[b] & 0xffffu) | (Hn[b] & 0xffff0000u)) : ((Hbest[b] & 0xffff0000u) | (Hn[b] & 0xffffu));
+				if (!done[hh]) {
+					if (Gs[hh] - m > c.xdrop) done[hh] = true;               // x-drop
+					else {                                                   // witness: the first lane holding the row maximum
+						const uint64_t at = __ballot(live && cv == m) & group_mask<G>(lane);
+						wit[hh] = (__ffsll((unsigned long long)at) - 1) % G;
+					}
 				}
-				if (!done[h] && Gs[h] - m > c.xdrop) done[h] = true;        // x-drop
 			}
 			repack();
 		}
-		if (i == 2 && col == 0) Hs[R1][0] = NEGP, Hs[R2][0] = NEGP;        // column -1 is -inf from row 3 on
-#pragma unroll
-		for (int b = 0; b < NB; ++b) S[b] = Sn[b];
-		r0A = r1A, r0B = r1B, r1A = r2A, r1B = r2B;
+		if (i == 2 && col == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;               // column -1 is -inf from row 3 on
+		S = s0 | s1;
+		rcur = rnext;
 		++i;
 	};
 
-	while (i < max_nl) {
-		if (i >= next_event) events(i);
-		if (n_active == 0) break;
+	while (i < limit) {
+		if (i >= next_event) { events(i); if (i >= limit) break; }
 		row(std::integral_constant<int, 0>());
-		if (i >= max_nl) break;
-		if (i >= next_event) events(i);
-		if (n_active == 0) break;
+		if (i >= limit) break;
+		if (i >= next_event) { events(i); if (i >= limit) break; }
 		row(std::integral_constant<int, 1>());
-		if (i >= max_nl) break;
-		if (i >= next_event) events(i);
-		if (n_active == 0) break;
+		if (i >= limit) break;
+		if (i >= next_event) { events(i); if (i >= limit) break; }
 		row(std::integral_constant<int, 2>());
 	}
 
@@ -468,14 +473,10 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 		if (tid[h] < 0) continue;
 		int32_t first = INT32_MAX;
 		if (maxi[h] >= 0) {
-#pragma unroll
-			for (int b = 0; b < NB; ++b) {
-				const int gc = b * G + col;
-				int32_t v = half16(Hbest[b], h);
-				if (gc == al[h] - 1) v += c.end_bonus;
-				uint64_t m = __ballot(gc < al[h] && v == maxsc[h]) & group_mask<G>(lane);
-				if (m != 0 && first == INT32_MAX) first = b * G + (__ffsll((unsigned long long)m) - 1) % G;
-			}
+			int32_t v = half16(Hbest, h);
+			if (col == al[h] - 1) v += c.end_bonus;
+			const uint64_t m = __ballot(col < al[h] && v == maxsc[h]) & group_mask<G>(lane);
+			if (m != 0) first = (__ffsll((unsigned long long)m) - 1) % G;
 		}
 		if (col == 0) {
 			ExtOut o;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		const uint32_t gei = __builtin_amdgcn_perm(r0B, r0A, 0x0c060c02u);
 		dim1 = di, di = dip1, dip1 = dnew;
 		aim2 = aim1, aim1 = ai, ai = anew;
-		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(r0A & 0xff) * 128), *(const int16_t*)(ldsb + 22 * 128 + (int)(r0B & 0xff) * 128));
+		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(r0A & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(r0B & 0xff) * 16));
 		// what the wave to the left produced for this same row in the previous step
 		const uint32_t carry_in = w > 0 ? xY[(par ^ 1) * NW + w - 1] : NEGP;
 		const uint32_t left_h = w > 0 ? xH[(par ^ 1) * NW + w - 1] : NEGP;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 		for (int32_t i = 2; i < wv.max_nl; ++i) {
 			const bool rowlive = i < nl;
 			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
-			const int32_t nas = rcur & 0xff, gei = (rcur >> 16) & 0xff;
+			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
 			const int32_t S = myprof[nas * G];
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 		const int32_t i = step - w, par = step & 1;
 		if (i >= 2 && i < nl) {
 			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
-			const int32_t nas = rcur & 0xff, gei = (rcur >> 16) & 0xff;
+			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
 			const int32_t S = myprof[nas * G];
