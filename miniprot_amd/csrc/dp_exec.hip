@@ -145,7 +145,7 @@ template<int G> static hipError_t launch_ext(const ExtArgs &a, int n_waves, hipS
 
 template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_groups, hipStream_t s)
 {
-	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 4 * NW * 4;
+	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 4 * NW * 4 + 64 * 8;
 	if (lds > 48 * 1024) {
 		hipError_t e = hipFuncSetAttribute((const void*)k_ext_wide<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
@@ -312,7 +312,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		t.cig_off = cig_total, cig_total += t.cig_cap;
 		if (t.pad_ == 7) t.bnd_off = bnd_total, bnd_total += t.nl;
 	}
-	rec_total += max_nl + 64;                               // kernels prefetch records up to 48 rows past a call's end
+	rec_total += max_nl + 96;                               // kernels prefetch records up to 48 rows past a call's end
 
 	// ---- waves of the extension kernel
 	std::vector<ExtWave> ewaves;

@@ -84,6 +84,9 @@ template<int G> __device__ __forceinline__ uint32_t scan_max_pk(uint32_t x)
 	return x;
 }
 
+// barrier that orders LDS traffic only: outstanding global stores/atomics (vmcnt) keep draining across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define NEG32 (-(1 << 29))
 __device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 template<int G> __device__ __forceinline__ int32_t scan_max_i32(int32_t x)
@@ -380,7 +383,9 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 	};
 
 	int32_t i = 2;
-	uint2 rcur = ring[2];                                                  // record of row i
+	// software pipeline over LDS latency: the record of row i+2 is in flight while the profile scores of row
+	// i+1 are fetched with the (already landed) record of row i+1 at the very start of row i
+	uint2 rcur = ring[2], rnext = ring[3];                                 // records of rows i and i+1
 	uint32_t S;                                                            // profile scores of row i
 	{
 		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rcur.x & 0xff));
@@ -397,8 +402,10 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 		} else if ((i & 15) == 12) {
 			if (loader) lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
 		}
-		// record of row i+1 and its profile scores (LDS latency overlaps this row's arithmetic)
-		const uint2 rnext = ring[(i + 1) & 31];
+		// next row's profile scores and the record of row i+2: issued first, consumed one row later
+		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rnext.x & 0xff));
+		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rnext.y & 0xff));
+		const uint2 rnn = ring[(i + 2) & 31];
 		// unpack the record of row i: donor[i+1], acceptor[i], gap extension of this row
 		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);        // dn: R1 = donor[i-1], R2 = donor[i]... see below
 		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
@@ -417,9 +424,6 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, ac[R1]));
 		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));          // four frameshift moves
 		h = p_max(h, p_subs(t, fsP));
-		// next row's profile lookups, issued here so that they are back before the next row starts
-		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rnext.x & 0xff));
-		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rnext.y & 0xff));
 		// horizontal gap chain as a prefix max of h + j*ge
 		const uint32_t y = scan_max_pk<G>(p_adds(h, jge));
 		const uint32_t ex = shift1<G>(y, NEGP, lane);
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 		}
 		if (i == 2 && col == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;               // column -1 is -inf from row 3 on
 		S = s0 | s1;
-		rcur = rnext;
+		rcur = rnext, rnext = rnn;
 		++i;
 	};
 
@@ -517,24 +521,25 @@ template<int NW>
 __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 {
 	extern __shared__ uint32_t lds_raw[];
-	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots
+	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots and the record ring
 	int16_t *lds_prof = (int16_t*)lds_raw;
 	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 parities][NW] carry of the I scan
 	uint32_t *xH = xY + 2 * NW;                                  // [2 parities][NW] H of the block's last column
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const ExtWave wv = a.waves[blockIdx.x];
+	uint2 *ring = (uint2*)(xH + 2 * NW);                         // [64 rows] {record of half 0, record of half 1}
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
+	const ExtWave *wvp = &a.waves[blockIdx.x];
 	const DpConst c = a.c;
-	const uint32_t *recbase = a.rec + wv.rec_base;
+	const uint32_t *recbase = a.rec + wvp->rec_base;
 	uint32_t *rowkey = a.rowkey + (int64_t)blockIdx.x * 2 * a.key_stride;
 
 	int32_t tid[2], nl[2], al[2], ncol[2];
 	uint32_t roff[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		tid[h] = wv.task[h];
+		tid[h] = wvp->task[h];
 		if (tid[h] >= 0) {
 			const DTask *t = &a.tasks[tid[h]];
-			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol, roff[h] = (uint32_t)(t->rec_off - wv.rec_base);
+			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol, roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
 		} else nl[h] = 0, al[h] = 1, ncol[h] = 0, roff[h] = 0;
 	}
 	// profile columns of this wave
@@ -548,41 +553,52 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		}
 	}
 	if (threadIdx.x < 4 * NW) xY[threadIdx.x] = NEGP;             // xY and xH are contiguous
+	// record ring, filled by the leading wave: rows [0,32) now, then 16 rows at a time (see k_ext)
+	const bool loader = w == 0 && lane < 16;
+	uint2 pf = make_uint2(0, 0);
+	if (w == 0 && lane < 32) ring[lane] = make_uint2(recbase[roff[0] + lane], recbase[roff[1] + lane]);
+	if (loader) pf = make_uint2(recbase[roff[0] + 32 + lane], recbase[roff[1] + 32 + lane]);
 	__syncthreads();
 
 	const int gc = w * 64 + lane;
 	const uint32_t jge = splat16(gc * c.ge), gojge = splat16(c.go + gc * c.ge);
-	const int32_t ebp = c.end_bonus > 0 ? c.end_bonus : 0;
-	const uint32_t ebv = pack16(gc == al[0] - 1 ? ebp : 0, gc == al[1] - 1 ? ebp : 0);
-	const bool valid0 = gc < ncol[0], valid1 = gc < ncol[1];
+	const uint32_t ebv = pack16(gc == al[0] - 1 ? c.end_bonus : 0, gc == al[1] - 1 ? c.end_bonus : 0);
+	// live halves keep their value, dead halves read as -32768 in the row maximum
+	const uint32_t keepP = (gc < ncol[0] ? 0xffffu : 0u) | (gc < ncol[1] ? 0xffff0000u : 0u);
+	const uint32_t deadP = (gc < ncol[0] ? 0u : 0x8000u) | (gc < ncol[1] ? 0u : 0x80000000u);
 	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
 	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
 	const char *ldsb = (const char*)(lds_prof + (w * 2) * 22 * 64) + lane * 2;
-	const uint32_t keycol = 0xffffu - (uint32_t)gc;
 
-	uint32_t Hr[3], Hs[3], Dr[3], A = NEGP, B = NEGP, C = NEGP;
+	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP;
 #pragma unroll
 	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
 	if (w == 0 && lane == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
-
-	uint32_t rA0 = recbase[roff[0] + 0], rB0 = recbase[roff[1] + 0];
-	uint32_t rA1 = recbase[roff[0] + 1], rB1 = recbase[roff[1] + 1];
-	uint32_t dim1, di = __builtin_amdgcn_perm(rB0, rA0, 0x0a050801u), dip1 = __builtin_amdgcn_perm(rB1, rA1, 0x0a050801u);
-	uint32_t aim2, aim1 = __builtin_amdgcn_perm(rB0, rA0, 0x0b070903u), ai = __builtin_amdgcn_perm(rB1, rA1, 0x0b070903u);
-	uint32_t r0A = recbase[roff[0] + 2], r0B = recbase[roff[1] + 2];
-	uint32_t r1A = recbase[roff[0] + 3], r1B = recbase[roff[1] + 3];
-	const int32_t max_nl = wv.max_nl;
+	{
+		const uint2 q0 = ring[0], q1 = ring[1];
+		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
+		ac[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0b070903u), ac[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0b070903u);
+		dn[2] = ac[2] = 0;
+	}
+	const int32_t max_nl = wvp->max_nl;
+	uint2 rpre = ring[2];
 
 	auto row = [&](auto kc, int32_t i, int par) {
 		constexpr int K = decltype(kc)::value;
 		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
-		const uint32_t r2A = recbase[roff[0] + (uint32_t)i + 2], r2B = recbase[roff[1] + (uint32_t)i + 2];
-		const uint32_t dnew = __builtin_amdgcn_perm(r0B, r0A, 0x0a050801u);
-		const uint32_t anew = __builtin_amdgcn_perm(r0B, r0A, 0x0b070903u);
-		const uint32_t gei = __builtin_amdgcn_perm(r0B, r0A, 0x0c060c02u);
-		dim1 = di, di = dip1, dip1 = dnew;
-		aim2 = aim1, aim1 = ai, ai = anew;
-		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(r0A & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(r0B & 0xff) * 16));
+		if (w == 0) {                                                      // ring maintenance by the leading wave
+			if ((i & 15) == 0) {
+				if (i > 2 && loader) pf = make_uint2(recbase[roff[0] + (uint32_t)i + 32 + lane], recbase[roff[1] + (uint32_t)i + 32 + lane]);
+			} else if ((i & 15) == 12) {
+				if (loader) ring[((i + 20) & 63) + lane] = pf;               // rows [i+20, i+36): written >= NW steps before any wave reads them
+			}
+		}
+		const uint2 rcur = rpre;                                           // fetched during the previous row
+		rpre = ring[(i + 1) & 63];
+		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);
+		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
+		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
+		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(rcur.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rcur.y & 0xff) * 16));
 		// what the wave to the left produced for this same row in the previous step
 		const uint32_t carry_in = w > 0 ? xY[(par ^ 1) * NW + w - 1] : NEGP;
 		const uint32_t left_h = w > 0 ? xH[(par ^ 1) * NW + w - 1] : NEGP;
@@ -590,12 +606,12 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		h = p_adds(Hs[R3], S);
 		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
 		t = p_subs(t, gei); Dr[R3] = t; h = p_max(h, t);
-		u = p_subs(Hr[R1], ioP); t = p_subs(u, dim1);
-		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ai));
-		u = p_subs(Hs[R1], ioP); t = p_subs(u, di);
-		t = p_max(t, B); B = t; h = p_max(h, p_subs(t, aim2));
-		t = p_subs(u, dip1);
-		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, aim1));
+		u = p_subs(Hr[R1], ioP); t = p_subs(u, dn[R2]);
+		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ac[R3]));
+		u = p_subs(Hs[R1], ioP); t = p_subs(u, dn[R1]);
+		t = p_max(t, B); B = t; h = p_max(h, p_subs(t, ac[R2]));
+		t = p_subs(u, dn[R3]);
+		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, ac[R1]));
 		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));
 		h = p_max(h, p_subs(t, fsP));
 		const uint32_t y = scan_max_pk<64>(p_adds(h, jge));
@@ -605,33 +621,31 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		const uint32_t hs = shift1<64>(h, left_h, lane);
 		Hr[R3] = h, Hs[R3] = hs;
 		if (lane == 63) xY[par * NW + w] = p_max(carry_in, y), xH[par * NW + w] = h;
-		// per-row key: (H + end bonus) of the best column of this block, ties to the smallest column
-		const uint32_t hx = p_adds(h, ebv);
-		uint32_t k0 = valid0 && i < nl[0] ? ((uint32_t)(lo16(hx) + 32768) << 16 | keycol) : 0u;
-		uint32_t k1 = valid1 && i < nl[1] ? ((uint32_t)(hi16(hx) + 32768) << 16 | keycol) : 0u;
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, off), o1 = (uint32_t)__shfl_xor((int)k1, off);
-			k0 = k0 > o0 ? k0 : o0, k1 = k1 > o1 ? k1 : o1;
-		}
+		// per-row key: (H + end bonus) of the best column of this block, ties to the smallest column.  One packed
+		// DPP reduction for both halves, then the winning column from a ballot.
+		const uint32_t hx = (p_adds(h, ebv) & keepP) | deadP;
+		const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)scan_max_pk<64>(hx), 63);
+		const uint32_t df = hx ^ bm;
+		const uint64_t e0 = __ballot((df & 0xffffu) == 0), e1 = __ballot((df >> 16) == 0);
 		if (lane == 0) {
-			if (k0) atomicMax(&rowkey[i], k0);
-			if (k1) atomicMax(&rowkey[a.key_stride + i], k1);
+			if (i < nl[0] && e0) atomicMax(&rowkey[i], (uint32_t)(lo16(bm) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e0) - 1)));
+			if (i < nl[1] && e1) atomicMax(&rowkey[a.key_stride + i], (uint32_t)(hi16(bm) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e1) - 1)));
 		}
 		if (i == 2 && w == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
-		r0A = r1A, r0B = r1B, r1A = r2A, r1B = r2B;
 	};
 
-	for (int32_t t = 2; t < max_nl + NW - 1; ++t) {
-		const int32_t i = t - w;
-		if (i >= 2 && i < max_nl) {
-			const int k = (i - 2) % 3;
-			if (k == 0) row(std::integral_constant<int, 0>(), i, t & 1);
-			else if (k == 1) row(std::integral_constant<int, 1>(), i, t & 1);
-			else row(std::integral_constant<int, 2>(), i, t & 1);
+	// wave w runs w rows behind wave 0: w barriers of delay, then one barrier per row, then the remaining
+	// NW-1-w so that every wave passes the same number of barriers.  Step parity = (row + w) & 1.
+	for (int k = 0; k < w; ++k) lds_barrier();
+	{
+		int32_t i = 2;
+		while (i < max_nl) {
+			row(std::integral_constant<int, 0>(), i, (i + w) & 1); lds_barrier(); if (++i >= max_nl) break;
+			row(std::integral_constant<int, 1>(), i, (i + w) & 1); lds_barrier(); if (++i >= max_nl) break;
+			row(std::integral_constant<int, 2>(), i, (i + w) & 1); lds_barrier(); ++i;
 		}
-		__syncthreads();
 	}
+	for (int k = w; k < NW - 1; ++k) lds_barrier();
 	__threadfence();
 	__syncthreads();
 
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 	extern __shared__ uint32_t lds_raw[];
 	int16_t *lds_prof = (int16_t*)lds_raw;                      // [NW][22][64]
 	int4 *xB = (int4*)(lds_prof + NW * 22 * 64);               // [2 parities][NW] boundary records
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
 	const GlobWave wv = a.waves[blockIdx.x];
 	const DpConst c = a.c;
 	const int32_t tid = wv.task[0];
@@ -878,9 +892,10 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 	int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
 	uint32_t rcur = nl > 2 ? rec[2] : 0;
 
-	for (int32_t step = 2; step < nl + NW - 1; ++step) {
-		const int32_t i = step - w, par = step & 1;
-		if (i >= 2 && i < nl) {
+	for (int k = 0; k < w; ++k) lds_barrier();                   // skew: wave w runs w rows behind wave 0
+	for (int32_t i = 2; i < nl; ++i) {
+		const int32_t par = (i + w) & 1;
+		{
 			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
 			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
@@ -939,8 +954,9 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 			if (i == 2 && first_blk && lane == 0) H2s = NEG16, H3s = NEG16;
 			rcur = rnext;
 		}
-		__syncthreads();
+		lds_barrier();
 	}
+	for (int k = w; k < NW - 1; ++k) lds_barrier();
 	if (nl < 3 && threadIdx.x == 0) a.score[tid] = NEG16;
 }
 
