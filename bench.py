@@ -163,8 +163,15 @@ def main():
         ns = min(a.cpu_sample, len(prots0))
         gen_synth.write_fasta_aa(os.path.join(tmp, "p.fa"), prots0[:ns], names0[:ns])
         open(os.path.join(tmp, "empty.fa"), "w").close()
-        tl = time.time(); subprocess.run([ref_bin, "-t%d" % ncpu, "-u", mpi, os.path.join(tmp, "empty.fa")], capture_output=True); t_load = time.time() - tl
-        tl = time.time(); out = subprocess.run([ref_bin, "-t%d" % ncpu, "-u", mpi, os.path.join(tmp, "p.fa")], capture_output=True).stdout; t_run = time.time() - tl
+        def timed(args):
+            best, out = 1e30, b""
+            for _ in range(3):                              # best of three: the runs are short on a many-core host
+                tl = time.time()
+                out = subprocess.run([ref_bin, "-t%d" % ncpu, "-u", mpi] + args, capture_output=True).stdout
+                best = min(best, time.time() - tl)
+            return best, out
+        t_load, _ = timed([os.path.join(tmp, "empty.fa")])
+        t_run, out = timed([os.path.join(tmp, "p.fa")])
         ours = b"".join(l + b"\n" for l in all_paf[0].split(b"\n")[:-1] if l.split(b"\t", 1)[0].decode() in set(names0[:ns]))
         cpu_res = aligned_residues(out)
         cpu = {"value": cpu_res / max(t_run - t_load, 1e-6), "unit": "aligned residues/s", "cores": ncpu, "kind": "reference",

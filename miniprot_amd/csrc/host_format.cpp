@@ -5,6 +5,9 @@
 #include <cctype>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <vector>
 #include "host_core.h"
 
 namespace mpa {
@@ -116,12 +119,15 @@ using namespace mpa;
 extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                                   const mpa_result_t *r, char **out)
 {
-	std::string s;
 	double t0 = now_ms();
 	const mpa_hit_t *hits = mpa_result_hits(r);
 	const int64_t *off = mpa_result_hit_off(r);
 	const uint32_t *cig = mpa_result_cigars(r);
-	for (int32_t i = 0; i < q->n_seq; ++i) {
+	// every query's lines are independent: format in parallel, concatenate in input order (map.c:293-313)
+	const int32_t n_seq = q->n_seq;
+	std::vector<std::string> part((size_t)n_seq);
+	auto one = [&](int32_t i) {
+		std::string &s = part[i];
 		const char *seq = q->seqs + q->q_off[i];
 		const int32_t qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 		const int64_t n_reg = off[i + 1] - off[i];
@@ -136,7 +142,22 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 			++n_out;
 		}
 		if (n_out == 0 && (opt->flag & MPA_MF_SHOW_UNMAP)) put_paf(s, mi, *opt, names[i], seq, qlen, nullptr, cig);
+	};
+	{
+		unsigned hw = std::thread::hardware_concurrency();
+		const int nt = (int)std::max(1u, std::min(16u, hw / 4 ? hw / 4 : 1u));
+		std::atomic<int32_t> next(0);
+		auto work = [&]() { for (;;) { int32_t i = next.fetch_add(1); if (i >= n_seq) break; one(i); } };
+		std::vector<std::thread> pool;
+		for (int t = 1; t < nt && t < n_seq; ++t) pool.emplace_back(work);
+		work();
+		for (auto &th : pool) th.join();
 	}
+	size_t total = 0;
+	for (const std::string &x : part) total += x.size();
+	std::string s;
+	s.reserve(total);
+	for (const std::string &x : part) s += x;
 	timing_note("format_paf", now_ms() - t0);
 	char *buf = (char*)malloc(s.size() + 1);
 	memcpy(buf, s.data(), s.size());

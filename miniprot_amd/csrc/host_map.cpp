@@ -22,6 +22,9 @@
 #include <cassert>
 #include <cstring>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include "host_core.h"
 
 namespace mpa {
@@ -52,6 +55,8 @@ struct QueryState {
 	const char *seq = nullptr;
 	std::vector<Region> regs;
 	std::vector<AlignPlan> plans;
+	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
+	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
 };
 
 } // namespace mpa
@@ -75,20 +80,64 @@ struct mpa_batch_s {
 	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
 	std::vector<QueryState> qs;
 	std::vector<mpa_dp_task_t> tasks;
-	std::vector<std::pair<int32_t, int32_t>> task_owner;   // (query, plan) of every task
 };
 
 namespace mpa {
 
+// A small persistent worker pool: the stage machine calls parallel_for several times per batch and thread
+// creation would otherwise cost more than some of the stages.
+class WorkerPool {
+public:
+	static WorkerPool &get() { static WorkerPool *p = new WorkerPool(); return *p; }   // never destroyed: workers outlive main()
+	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
+		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+		std::unique_lock<std::mutex> run_lock(run_mu_);              // one parallel region at a time
+		ensure(n_threads - 1);
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			fn_ = &fn, n_ = n, next_.store(0), active_ = std::min<int>(n_threads - 1, (int)workers_.size()), pending_ = active_, ++epoch_;
+		}
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> g(mu_);
+		done_cv_.wait(g, [&] { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+private:
+	void ensure(int k) {
+		while ((int)workers_.size() < k) {
+			const int id = (int)workers_.size();
+			workers_.emplace_back([this, id] { loop(id); });
+			workers_.back().detach();
+		}
+	}
+	void work() { for (;;) { int64_t i = next_.fetch_add(1); if (i >= n_) break; (*fn_)(i); } }
+	void loop(int id) {
+		uint64_t seen = 0;
+		for (;;) {
+			std::unique_lock<std::mutex> g(mu_);
+			cv_.wait(g, [&] { return epoch_ != seen && id < active_; });
+			seen = epoch_;
+			g.unlock();
+			work();
+			g.lock();
+			if (--pending_ == 0) done_cv_.notify_all();
+		}
+	}
+	std::mutex mu_, run_mu_;
+	std::condition_variable cv_, done_cv_;
+	std::vector<std::thread> workers_;
+	const std::function<void(int64_t)> *fn_ = nullptr;
+	int64_t n_ = 0;
+	std::atomic<int64_t> next_{0};
+	int active_ = 0, pending_ = 0;
+	uint64_t epoch_ = 0;
+};
+
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 {
-	if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
-	std::atomic<int64_t> next(0);
-	std::vector<std::thread> pool;
-	const int nt = (int)std::min<int64_t>(n_threads, n);
-	for (int t = 0; t < nt; ++t)
-		pool.emplace_back([&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } });
-	for (auto &th : pool) th.join();
+	std::function<void(int64_t)> f = fn;
+	WorkerPool::get().run(n_threads, n, f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -421,7 +470,7 @@ static int32_t ungapped_score(const mpa_idx_s *mi, const mpa_mapopt_t &opt, cons
 
 // one mp_align_seq() call: either the ungapped shortcut (align.c:65-67) or a DP task with traceback
 static void make_segment(mpa_batch_s *b, const QueryState &qs, const Region &r, const AlignPlan &pl, int32_t ne0, int32_t ne1, int32_t ae0, int32_t ae1,
-                         int32_t qi, int32_t pi, std::vector<mpa_dp_task_t> &tasks, std::vector<std::pair<int32_t, int32_t>> &owner, Segment &s)
+                         int32_t qi, int32_t pi, std::vector<mpa_dp_task_t> &tasks, Segment &s)
 {
 	const mpa_mapopt_t &opt = b->opt;
 	s.ne0 = ne0, s.ne1 = ne1, s.ae0 = ae0, s.ae1 = ae1;
@@ -433,7 +482,6 @@ static void make_segment(mpa_batch_s *b, const QueryState &qs, const Region &r, 
 	} else {
 		s.task = (int32_t)tasks.size();
 		tasks.push_back(make_task(qs, r, pl.vs0 + ne0, nlen, ae0, alen, MPA_F_CIGAR, opt.io));
-		owner.emplace_back(qi, pi);
 	}
 }
 
@@ -445,73 +493,76 @@ static void store_result(Segment &s, const mpa_dp_rst_t *rst, const uint32_t *po
 	s.cigar.assign(pool + o.cigar_off, pool + o.cigar_off + o.n_cigar);
 }
 
-static void emit_round1(mpa_batch_s *b)
+// round-1 tasks of one query: both extensions of every region plus the gaps between kept anchors
+// (align.c:305-313, all iterations but the first).  Runs inside the threaded stage A.
+static void plan_round1(mpa_batch_s *b, QueryState &qs)
 {
 	const mpa_mapopt_t &opt = b->opt;
-	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
-		QueryState &qs = b->qs[qi];
-		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
-			AlignPlan &pl = qs.plans[pi];
-			const Region &r = qs.regs[pl.reg];
-			pl.t_left = (int32_t)b->tasks.size();
-			b->tasks.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT, opt.io));
-			b->task_owner.emplace_back((int32_t)qi, (int32_t)pi);
-			if (pl.has_right) {
-				pl.t_right = (int32_t)b->tasks.size();
-				b->tasks.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
-				b->task_owner.emplace_back((int32_t)qi, (int32_t)pi);
-			}
-			// gaps between consecutive kept anchors (align.c:305-313, all iterations but the first)
-			int32_t ne0 = (int32_t)(pl.vs1 - pl.vs0), ae0 = pl.as1;
-			for (int32_t i = pl.i0 + 1; i < r.cnt; ++i) {
-				if (!(r.a[i] >> 31 & 1)) continue;
-				const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
-				pl.gaps.emplace_back();
-				make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, (int32_t)qi, (int32_t)pi, b->tasks, b->task_owner, pl.gaps.back());
-				ne0 = ne1, ae0 = ae1;
-			}
+	for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
+		AlignPlan &pl = qs.plans[pi];
+		const Region &r = qs.regs[pl.reg];
+		pl.t_left = (int32_t)qs.local1.size();
+		qs.local1.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT, opt.io));
+		if (pl.has_right) {
+			pl.t_right = (int32_t)qs.local1.size();
+			qs.local1.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
+		}
+		int32_t ne0 = (int32_t)(pl.vs1 - pl.vs0), ae0 = pl.as1;
+		for (int32_t i = pl.i0 + 1; i < r.cnt; ++i) {
+			if (!(r.a[i] >> 31 & 1)) continue;
+			const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
+			pl.gaps.emplace_back();
+			make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, qs.qid, (int32_t)pi, qs.local1, pl.gaps.back());
+			ne0 = ne1, ae0 = ae1;
 		}
 	}
+}
+
+static void emit_round1(mpa_batch_s *b)
+{
+	int64_t n = 0;
+	for (QueryState &qs : b->qs) qs.base1 = n, n += (int64_t)qs.local1.size();
+	b->tasks.resize((size_t)n);
+	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t qi) {
+		QueryState &qs = b->qs[qi];
+		if (!qs.local1.empty()) memcpy(&b->tasks[qs.base1], qs.local1.data(), qs.local1.size() * sizeof(mpa_dp_task_t));
+	});
 }
 
 static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
 {
 	const mpa_mapopt_t &opt = b->opt;
 	std::vector<mpa_dp_task_t> next;
-	std::vector<std::pair<int32_t, int32_t>> owner;
 	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
 		QueryState &qs = b->qs[qi];
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
 			const Region &r = qs.regs[pl.reg];
-			for (Segment &g : pl.gaps) store_result(g, rst, pool);
-			pl.l_nt = rst[pl.t_left].nt_len, pl.l_aa = rst[pl.t_left].aa_len;
+			const mpa_dp_rst_t *mine = rst + qs.base1;                 // this query's slice of the round-1 results
+			for (Segment &g : pl.gaps) store_result(g, mine, pool);
+			pl.l_nt = mine[pl.t_left].nt_len, pl.l_aa = mine[pl.t_left].aa_len;
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
 				pl.t_left2 = (int32_t)next.size();
 				next.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT, opt.io_end));
-				owner.emplace_back((int32_t)qi, (int32_t)pi);
 			}
 			if (pl.has_right) {
-				pl.r_nt = rst[pl.t_right].nt_len, pl.r_aa = rst[pl.t_right].aa_len;
+				pl.r_nt = mine[pl.t_right].nt_len, pl.r_aa = mine[pl.t_right].aa_len;
 				if (pl.r_aa < qs.qlen - pl.mid_qe && pl.r_nt < opt.max_ext && opt.io > opt.io_end) {
 					const int64_t l_ext = std::min<int64_t>(pl.ae - pl.mid_ve, opt.max_ext);
 					pl.t_right2 = (int32_t)next.size();
 					next.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
-					owner.emplace_back((int32_t)qi, (int32_t)pi);
-				}
+					}
 			}
 		}
 	}
 	b->tasks.swap(next);
-	b->task_owner.swap(owner);
 }
 
 static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 {
 	const mpa_mapopt_t &opt = b->opt;
 	std::vector<mpa_dp_task_t> next;
-	std::vector<std::pair<int32_t, int32_t>> owner;
 	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
 		QueryState &qs = b->qs[qi];
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
@@ -523,16 +574,15 @@ static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 			r.vs = pl.vs1 - pl.l_nt;
 			r.qs = pl.as1 - pl.l_aa;
 			pl.has_left_span = true;
-			make_segment(b, qs, r, pl, (int32_t)(r.vs - pl.vs0), (int32_t)(pl.vs1 - pl.vs0), r.qs, pl.as1, (int32_t)qi, (int32_t)pi, next, owner, pl.left_span);
+			make_segment(b, qs, r, pl, (int32_t)(r.vs - pl.vs0), (int32_t)(pl.vs1 - pl.vs0), r.qs, pl.as1, (int32_t)qi, (int32_t)pi, next, pl.left_span);
 			if (pl.has_right && pl.r_nt > 0 && pl.r_aa > 0) {             // the accepted right-extension span (align.c:331)
 				const int32_t ne0 = (int32_t)(pl.mid_ve - pl.vs0);
 				pl.has_right_span = true;
-				make_segment(b, qs, r, pl, ne0, ne0 + pl.r_nt, pl.mid_qe, pl.mid_qe + pl.r_aa, (int32_t)qi, (int32_t)pi, next, owner, pl.right_span);
+				make_segment(b, qs, r, pl, ne0, ne0 + pl.r_nt, pl.mid_qe, pl.mid_qe + pl.r_aa, (int32_t)qi, (int32_t)pi, next, pl.right_span);
 			}
 		}
 	}
 	b->tasks.swap(next);
-	b->task_owner.swap(owner);
 }
 
 static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
@@ -582,7 +632,7 @@ mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 	}
 	double t0 = now_ms();
-	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); });
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); plan_round1(b, b->qs[i]); });
 	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
 	return b;
@@ -651,6 +701,7 @@ mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
 		}
 	}
 	res->hit_off[b->qs.size()] = (int64_t)res->hits.size();
+	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t i) { b->qs[i] = QueryState(); });   // free per-query state in parallel
 	delete b;
 	timing_note("batch_finish (flatten)", now_ms() - t_fin);
 	return res;
