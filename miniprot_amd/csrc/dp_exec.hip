@@ -58,7 +58,7 @@ struct mpa_ctx_s {
 	hipEvent_t ev[6] = {};
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
-	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey;
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff;
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -216,7 +216,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey }) b->release();
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff }) b->release();
 	for (auto &e : ctx->ev) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) (void)hipEventDestroy(e);
 	(void)hipEventDestroy(ctx->fork_ev);
@@ -526,26 +526,44 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	std::vector<ExtOut> eo;
 	std::vector<int32_t> sc, nc;
 	if (!ext_ids.empty()) { eo.resize(n); HIP_TRY(hipMemcpy(eo.data(), ctx->extout.p, sizeof(ExtOut) * n, hipMemcpyDeviceToHost)); }
-	std::vector<uint32_t> cig;
+	int64_t pool_n = 0;
+	std::vector<int64_t> dense_off;
 	if (!glob_ids.empty()) {
-		sc.resize(n), nc.resize(n), cig.resize(cig_total);
+		sc.resize(n), nc.resize(n);
 		HIP_TRY(hipMemcpy(sc.data(), ctx->score.p, n * 4, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(nc.data(), ctx->ncig.p, n * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(cig.data(), ctx->cig.p, (size_t)cig_total * 4, hipMemcpyDeviceToHost));
+		dense_off.resize(glob_ids.size());
+		for (size_t g = 0; g < glob_ids.size(); ++g) dense_off[g] = pool_n, pool_n += nc[glob_ids[g]];
 	}
-	int64_t pool_n = 0;
-	for (int32_t id : glob_ids) pool_n += nc[id];
 	uint32_t *pool = (uint32_t*)malloc((size_t)(pool_n > 0 ? pool_n : 1) * 4);
-	int64_t pp = 0;
-	for (int64_t k = 0; k < n; ++k) {
-		const DTask &t = T[k];
-		mpa_dp_rst_t &o = rst[k];
-		if (t.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) {
-			o.nt_len = eo[k].nt_len, o.aa_len = eo[k].aa_len, o.score = eo[k].score, o.n_cigar = 0, o.cigar_off = 0;
-		} else {
-			o.nt_len = t.nl, o.aa_len = t.al, o.score = sc[k], o.n_cigar = nc[k], o.cigar_off = pp;
-			memcpy(pool + pp, cig.data() + t.cig_off, (size_t)nc[k] * 4);
-			pp += nc[k];
+	if (pool_n > 0) {
+		// the slots were sized for the worst case (nl+al+4 words each): gather the real CIGARs into a dense pool on the
+		// device and copy only that over PCIe
+		int rc2;
+		if ((rc2 = ctx->cigd.ensure((size_t)pool_n * 4)) || (rc2 = ctx->cigoff.ensure(glob_ids.size() * 12 + 64))) { free(pool); return rc2; }
+		int64_t *d_off = ctx->cigoff.as<int64_t>();
+		int32_t *d_ids = (int32_t*)(d_off + glob_ids.size());
+		HIP_TRY(hipMemcpyAsync(d_off, dense_off.data(), glob_ids.size() * 8, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_ids, glob_ids.data(), glob_ids.size() * 4, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_cigar_gather, dim3((unsigned)glob_ids.size()), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_ids, d_off, (int32_t)glob_ids.size(),
+		                   ctx->ncig.as<int32_t>(), ctx->cig.as<uint32_t>(), ctx->cigd.as<uint32_t>());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(pool, ctx->cigd.p, (size_t)pool_n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+	}
+	{
+		size_t g = 0;
+		std::vector<int64_t> off_of(n, 0);
+		for (size_t k = 0; k < glob_ids.size(); ++k) off_of[glob_ids[k]] = dense_off[k];
+		(void)g;
+		for (int64_t k = 0; k < n; ++k) {
+			const DTask &t = T[k];
+			mpa_dp_rst_t &o = rst[k];
+			if (t.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) {
+				o.nt_len = eo[k].nt_len, o.aa_len = eo[k].aa_len, o.score = eo[k].score, o.n_cigar = 0, o.cigar_off = 0;
+			} else {
+				o.nt_len = t.nl, o.aa_len = t.al, o.score = sc[k], o.n_cigar = nc[k], o.cigar_off = off_of[k];
+			}
 		}
 	}
 	timing_note("  dp: download+assemble", now_ms() - t_res);

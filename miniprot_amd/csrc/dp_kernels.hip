@@ -1046,4 +1046,15 @@ __global__ __launch_bounds__(64) void k_backtrack(const DTask *tasks, const int3
 	if (lane == 0) n_cigar[tid] = n;
 }
 
+// dense copy of the CIGARs: every call's slot was sized for the worst case, only n_cigar words are real
+__global__ __launch_bounds__(64) void k_cigar_gather(const DTask *tasks, const int32_t *list, const int64_t *dst_off, int32_t n_list,
+                                                     const int32_t *n_cigar, const uint32_t *src, uint32_t *dst)
+{
+	if ((int32_t)blockIdx.x >= n_list) return;
+	const int32_t tid = list[blockIdx.x], n = n_cigar[tid];
+	const uint32_t *from = src + tasks[tid].cig_off;
+	uint32_t *to = dst + dst_off[blockIdx.x];
+	for (int32_t k = threadIdx.x; k < n; k += 64) to[k] = from[k];
+}
+
 } // namespace mpa

@@ -147,7 +147,7 @@ static void orf_kmers(const uint8_t *seq, int64_t st, int64_t en, int32_t kmer, 
 	}
 }
 
-void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out)
+void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out, bool sorted)
 {
 	const uint8_t *codon_tab = tab_codon();
 	// one open reading frame per codon phase: its number of codons so far and the position of its last base
@@ -173,7 +173,7 @@ void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kme
 		}
 	}
 	close(0), close(1), close(2);
-	if (out.size() <= 1) return;
+	if (!sorted || out.size() <= 1) return;
 	sort_u64(out.data(), out.data() + out.size());
 	out.erase(std::unique(out.begin(), out.end()), out.end());
 }

@@ -19,8 +19,9 @@ void sort_pairs_by_x(Pair64 *beg, Pair64 *end);        // radix_sort_mp128x: tie
 // ---- sketching (sketch.c) ---------------------------------------------------------------------------
 uint32_t hash32_mask(uint32_t key, uint32_t mask);
 void sketch_protein(const char *seq, int32_t len, int32_t kmer, int32_t mod_bit, std::vector<uint64_t> &out);
+// sorted=false leaves the k-mers unsorted and with duplicates (for callers that sort a merged list anyway)
 void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit,
-                int64_t boff, std::vector<uint64_t> &out);
+                int64_t boff, std::vector<uint64_t> &out, bool sorted = true);
 
 // ---- chaining (chain.c) -----------------------------------------------------------------------------
 struct ChainParams {

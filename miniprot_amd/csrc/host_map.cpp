@@ -144,6 +144,12 @@ template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 // stage A
 // ------------------------------------------------------------------------------------------------
 
+// per-substage wall-clock accumulators of stage A (summed over threads; printed with MPA_TIMING=1)
+static std::atomic<int64_t> g_acc[14];
+static const char *const kAccName[14] = { "A.sketch+lookup", "A.sort anchors", "A.pre-chain", "A.chain", "A.regions", "A.refine", "A.plan", "A.round-1 plan",
+	"  refine: fetch window", "  refine: sketch nt4", "  refine: sketch prot+sort", "  refine: pairs+sort", "  refine: chain", "  refine: n regions" };
+struct AccTimer { int k; double t0; AccTimer(int k_) : k(k_), t0(now_ms()) {} ~AccTimer() { g_acc[k] += (int64_t)((now_ms() - t0) * 1e6); } };
+
 // mp_cal_max_occ (map.c:126-141): boxplot-style cutoff on the occurrence counts of the query's seeds
 static int32_t occurrence_cutoff(const mpa_idx_s *mi, const std::vector<uint64_t> &seeds)
 {
@@ -167,32 +173,42 @@ static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const ch
 	const int64_t as = r.vs > extl ? r.vs - extl : 0;
 	const int64_t ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
 	std::vector<uint8_t> nt((size_t)(ae - as));
-	fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data());
+	g_acc[13] += 1000000LL * 1;                                // (count of refined regions, printed /1e6/threads)
+	{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
 	std::vector<uint64_t> sd, sq;
-	sketch_nt4(nt.data(), ae - as, mi->opt.min_aa_len, kmer, 0, 0, 0, sd);
-	sketch_protein(aa, l_aa, kmer, 0, sq);
-	sd.reserve(sd.size() + sq.size());
-	for (uint64_t x : sq) sd.push_back(x | 1ULL << 31);       // tag query k-mers; they sort after reference ones of the same hash
-	sort_u64(sd.data(), sd.data() + sd.size());
-	// all (reference position, query position) pairs of k-mers sharing a hash, unless there are too many
+	// the reference sorts + dedups the window's k-mers, appends the query's (bit 31 set) and sorts again; one sort of the
+	// merged list followed by the dedup gives the same list (query entries never equal reference entries)
+	{ AccTimer tm(9); sketch_nt4(nt.data(), ae - as, mi->opt.min_aa_len, kmer, 0, 0, 0, sd, false); }
 	std::vector<uint64_t> a;
-	const size_t n = sd.size();
-	for (size_t k = 0, i = 1; i <= n; ++i) {
-		if (i < n && sd[k] >> 32 == sd[i] >> 32) continue;
-		size_t j = k;
-		while (j < i && !(sd[j] >> 31 & 1)) ++j;
-		const int64_t n1 = (int64_t)(j - k), n2 = (int64_t)(i - j);
-		if (n1 > 0 && n2 > 0 && (int32_t)n1 * (int32_t)n2 <= opt.max_ava)
-			for (size_t i1 = k; i1 < j; ++i1)
-				for (size_t i2 = j; i2 < i; ++i2)
-					a.push_back((uint64_t)(uint32_t)sd[i1] << 32 | ((uint32_t)sd[i2] << 1 >> 1));
-		k = i;
+	{
+		AccTimer tm(10);
+		sketch_protein(aa, l_aa, kmer, 0, sq);
+		sd.reserve(sd.size() + sq.size());
+		for (uint64_t x : sq) sd.push_back(x | 1ULL << 31);       // tag query k-mers; they sort after reference ones of the same hash
+		sort_u64(sd.data(), sd.data() + sd.size());
+		sd.erase(std::unique(sd.begin(), sd.end()), sd.end());
 	}
-	sort_u64(a.data(), a.data() + a.size());
+	{
+		AccTimer tm(11);
+		// all (reference position, query position) pairs of k-mers sharing a hash, unless there are too many
+		const size_t n = sd.size();
+		for (size_t k = 0, i = 1; i <= n; ++i) {
+			if (i < n && sd[k] >> 32 == sd[i] >> 32) continue;
+			size_t j = k;
+			while (j < i && !(sd[j] >> 31 & 1)) ++j;
+			const int64_t n1 = (int64_t)(j - k), n2 = (int64_t)(i - j);
+			if (n1 > 0 && n2 > 0 && (int32_t)n1 * (int32_t)n2 <= opt.max_ava)
+				for (size_t i1 = k; i1 < j; ++i1)
+					for (size_t i2 = j; i2 < i; ++i2)
+						a.push_back((uint64_t)(uint32_t)sd[i1] << 32 | ((uint32_t)sd[i2] << 1 >> 1));
+			k = i;
+		}
+		sort_u64(a.data(), a.data() + a.size());
+	}
 	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
 	                opt.chn_coef_log, is_splice, kmer, 0 };
 	std::vector<uint64_t> u;
-	chain_anchors(cp, a, u);
+	{ AccTimer tm(12); chain_anchors(cp, a, u); }
 	if (u.empty()) { r.cnt = 0, r.off = -1, r.a.clear(); return; }
 	// the first chain with the highest score
 	size_t best = 0, skip = 0;
@@ -391,18 +407,28 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
 	std::vector<uint64_t> sd, a, u;
-	sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
-	sort_u64(sd.data(), sd.data() + sd.size());
-	int32_t max_occ = opt.max_occ;
-	if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
-	// anchors: every occurrence of every seed that is not too frequent (map.c:163-177)
-	for (uint64_t s : sd) {
-		const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-		if (en - st > max_occ) continue;
-		for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | (uint32_t)s);
+	{
+		AccTimer tm(0);
+		sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
+		sort_u64(sd.data(), sd.data() + sd.size());
+		int32_t max_occ = opt.max_occ;
+		if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
+		// anchors: every occurrence of every seed that is not too frequent (map.c:163-177)
+		size_t n_a = 0;
+		for (uint64_t s : sd) {
+			const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+			if (en - st <= max_occ) n_a += (size_t)(en - st);
+		}
+		a.reserve(n_a);
+		for (uint64_t s : sd) {
+			const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+			if (en - st > max_occ) continue;
+			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | (uint32_t)s);
+		}
 	}
-	sort_u64(a.data(), a.data() + a.size());
+	{ AccTimer tm(1); sort_u64(a.data(), a.data() + a.size()); }
 	if (!(opt.flag & MPA_MF_NO_PRE_CHAIN) && is_splice) {         // keep anchors that have a neighbour within one block
+		AccTimer tm(2);
 		const int32_t w = 1 << mi->opt.bbit;
 		ChainParams pre{ w, w, w, opt.max_chn_max_skip, opt.max_chn_iter, 2, 0, opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
 		chain_anchors(pre, a, u);
@@ -410,16 +436,20 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 	}
 	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
 	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
-	chain_anchors(cp, a, u);
+	{ AccTimer tm(3); chain_anchors(cp, a, u); }
 	std::vector<Region> &regs = qs.regs;
-	regions_from_chains(mi, u, a, regs);
-	sort_regions(regs);
-	assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
-	select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
-	// refinement at base resolution (map.c:205-222)
 	std::vector<uint64_t> ext;
-	extension_limits(nullptr, regs, &a, 100, opt.max_ext, ext);
 	{
+		AccTimer tm(4);
+		regions_from_chains(mi, u, a, regs);
+		sort_regions(regs);
+		assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
+		select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
+		// refinement at base resolution (map.c:205-222)
+		extension_limits(nullptr, regs, &a, 100, opt.max_ext, ext);
+	}
+	{
+		AccTimer tm(5);
 		std::vector<Region> kept;
 		for (size_t i = 0; i < regs.size(); ++i) {
 			refine_region(mi, opt, qs.seq, qs.qlen, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
@@ -427,6 +457,7 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 		}
 		regs.swap(kept);
 	}
+	AccTimer tm6(6);
 	sort_regions(regs);
 	assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
 	select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
@@ -632,8 +663,9 @@ mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 	}
 	double t0 = now_ms();
-	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); plan_round1(b, b->qs[i]); });
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); AccTimer tm(7); plan_round1(b, b->qs[i]); });
 	timing_note("stage A (seed..plan)", now_ms() - t0);
+	if (timing_on()) for (int k = 0; k < 14; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
 	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
 	return b;
 }
