@@ -61,7 +61,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:                                # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -75,7 +75,8 @@ def main():
     from hostpipe import map_batch_gpu
 
     ncpu = os.cpu_count() or 1
-    n_threads = a.threads if a.threads > 0 else max(1, ncpu // max(world, 1))
+    # host threads for the non-DP stages: share the cores between the ranks; beyond ~128 threads SMT contention loses
+    n_threads = a.threads if a.threads > 0 else max(1, min(128, ncpu // max(world, 1)))
 
     # ---- inputs (untimed): genome, index, proteins.  Every rank builds the same genome; proteins of a
     # rank are that rank's shard (same planted genes, rank-specific divergence), so per-GPU work is fixed.

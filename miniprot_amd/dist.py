@@ -17,7 +17,7 @@ def gather_bytes(payload, rank, world, device):
     """Gather one bytes object per rank to rank 0 (returns the list on rank 0, None elsewhere)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return [payload]
     n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
