@@ -42,7 +42,12 @@ extern "C" {
 #define MPA_MF_NO_SPLICE    0x1
 #define MPA_MF_NO_ALIGN     0x2
 #define MPA_MF_SHOW_UNMAP   0x4
+#define MPA_MF_GFF          0x8
+#define MPA_MF_NO_PAF       0x10
+#define MPA_MF_GTF          0x20
 #define MPA_MF_NO_PRE_CHAIN 0x40
+#define MPA_MF_SHOW_RESIDUE 0x80
+#define MPA_MF_SHOW_TRANS   0x100
 #define MPA_MF_NO_CS        0x200
 
 /* ---- options: field-for-field mirrors of mp_idxopt_t / mp_mapopt_t (miniprot.h:36-77) ---------- */
@@ -205,6 +210,12 @@ mpa_result_t *mpa_batch_finish(mpa_batch_t *b);                 /* destroys the 
  * names[q] is the query name.  Returns the byte count. */
 int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                        const mpa_result_t *r, char **out);
+
+/* mp_write_output() in full (format.c:453-473): PAF and/or GFF3 (MPA_MF_GFF, format.c:360-412) or GTF (MPA_MF_GTF,
+ * format.c:414-451) according to opt->flag.  *id_io is the running hit counter of the output file (map.c:306): pass the
+ * same variable for every batch of a run, starting at 0.  The caller prints "##gff-version 3" once per file (map.c:338). */
+int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                          const mpa_result_t *r, int64_t *id_io, char **out);
 
 const char *mpa_version(void);
 

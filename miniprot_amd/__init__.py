@@ -121,6 +121,8 @@ def lib():
             ("mpa_result_hit_off", C.POINTER(C.c_int64), [C.c_void_p]),
             ("mpa_result_cigars", C.POINTER(C.c_uint32), [C.c_void_p]),
             ("mpa_result_destroy", None, [C.c_void_p]),
+            ("mpa_format_output", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
+                                              C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
             ("mpa_format_paf", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
                                            C.c_void_p, C.POINTER(C.c_void_p)]),
         ]:

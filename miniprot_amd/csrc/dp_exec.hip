@@ -62,6 +62,7 @@ struct mpa_ctx_s {
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
+	std::vector<mpa_ctx_s*> siblings;         // extra contexts on the same device for concurrent sub-batches (owned)
 };
 
 namespace mpa {
@@ -214,6 +215,8 @@ mpa_ctx_t *mpa_ctx_create(int device)
 void mpa_ctx_destroy(mpa_ctx_t *ctx)
 {
 	if (!ctx) return;
+	for (mpa_ctx_s *sb : ctx->siblings) mpa_ctx_destroy(sb);
+	ctx->siblings.clear();
 	(void)hipSetDevice(ctx->device);
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
 	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff }) b->release();
@@ -226,6 +229,36 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 }
 
 int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi) { return dev_upload_index(ctx, mi); }
+
+} // extern "C"
+
+namespace mpa {
+// k-th sibling of a context: same device, own streams and buffers, created on first use
+mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
+{
+	if (k <= 0) return ctx;
+	while ((int)ctx->siblings.size() < k) {
+		mpa_ctx_t *sb = mpa_ctx_create(ctx->device);
+		if (!sb) return nullptr;
+		sb->tb_budget = ctx->tb_budget;
+		ctx->siblings.push_back(sb);
+	}
+	return ctx->siblings[k - 1];
+}
+void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
+{
+	for (mpa_ctx_s *sb : ctx->siblings) {
+		mpa_dp_stats_t &t = ctx->total, &u = sb->total;
+		t.n_ext += u.n_ext, t.n_glob += u.n_glob, t.cells_ext += u.cells_ext, t.cells_glob += u.cells_glob, t.rows_prep += u.rows_prep;
+		t.alg_bytes_ext += u.alg_bytes_ext, t.alg_bytes_glob += u.alg_bytes_glob;
+		t.ms_prep += u.ms_prep, t.ms_ext += u.ms_ext, t.ms_glob += u.ms_glob, t.ms_backtrack += u.ms_backtrack, t.ms_total += u.ms_total;
+		t.launches_ext += u.launches_ext, t.launches_glob += u.launches_glob;
+		u = mpa_dp_stats_t();
+	}
+}
+} // namespace mpa
+
+extern "C" {
 
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st) { *st = ctx->stats; }
 void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset)
@@ -265,7 +298,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		memset(&t, 0, sizeof(t));
 		if (x.nl < 0 || x.al <= 0 || x.qid < 0 || x.qid >= q->n_seq || x.io < 0 || x.io > 32000) { set_error("malformed DP task"); return MPA_ERR_ARG; }
 		t.nt_off = x.nt_off, t.vid = x.vid, t.nl = x.nl, t.al = x.al, t.flag = x.flag, t.io = x.io;
-		t.q_off = q->q_off[x.qid] + x.aa_off;
+		t.q_off = q->q_off[x.qid] + x.aa_off - q->q_off[0];     // relative to the slice uploaded below
 		t.ncol = (x.al + 7) / 8 * 8;
 		t.out_idx = (int32_t)k;
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
@@ -366,7 +399,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 
 	timing_note("  dp: classify/sort/layout", now_ms() - t_begin);
 	// ---- device memory
-	const int64_t q_bytes = q->q_off[q->n_seq];
+	const int64_t q_bytes = q->q_off[q->n_seq] - q->q_off[0];
 	int rc;
 	if ((rc = ctx->tasks.ensure(sizeof(DTask) * n)) || (rc = ctx->chunks.ensure(sizeof(PrepChunk) * (chunks.size() + 1))) ||
 	    (rc = ctx->qseq.ensure(q_bytes + 16)) || (rc = ctx->rec.ensure((size_t)rec_total * 4)) || (rc = ctx->prof.ensure((size_t)prof_total * 2 + 16)) ||
@@ -376,7 +409,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		return rc;
 	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, T.data(), sizeof(DTask) * n, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, chunks.data(), sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, q->seqs, q_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, q->seqs + q->q_off[0], q_bytes, hipMemcpyHostToDevice, s));
 	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
 	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));

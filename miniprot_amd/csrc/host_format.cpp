@@ -3,6 +3,7 @@
 // Follows mp_write_paf (format.c:333-358), mp_write_cs (format.c:102-187) and the per-query output
 // filters of worker_pipeline step 2 (map.c:298-311).  GFF3/GTF/--aln/--trans are not part of this round.
 #include <cctype>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -89,6 +90,7 @@ static void put_paf(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt
                     const mpa_hit_t *h, const uint32_t *cig_pool)
 {
 	static const char ops[] = "MIDNSHP=XBFGUVE";
+	if (opt.flag & (MPA_MF_GFF | MPA_MF_GTF)) s += "##PAF\t";
 	s += name, s.push_back('\t'), put_int(s, qlen);
 	if (!h) { s += "\t0\t0\t*\t*\t0\t0\t0\t0\t0\t0\n"; return; }
 	const Contig &c = mi->ctg[h->vid >> 1];
@@ -112,19 +114,121 @@ static void put_paf(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt
 	s.push_back('\n');
 }
 
+static void put_id(std::string &s, const char *prefix, const char *mid, int64_t id)     // "%s<mid>%.6ld"
+{
+	char buf[32];
+	snprintf(buf, sizeof(buf), "%.6ld", (long)id);
+	s += prefix, s += mid, s += buf;
+}
+
+static void put_ratio(std::string &s, double x)                                          // "%.4f"
+{
+	char buf[32];
+	snprintf(buf, sizeof(buf), "%.4f", x);
+	s += buf;
+}
+
+// mp_write_gff (format.c:360-412)
+static void put_gff(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt, const char *name, int32_t qlen, const mpa_hit_t &h,
+                    const mpa_feat_t *feat, int64_t id, int32_t hit_idx)
+{
+	if (!h.has_aln) return;
+	const Contig &c = mi->ctg[h.vid >> 1];
+	const bool rev = h.vid & 1, has_stop = h.qe == qlen && h.dist_stop == 0;
+	const int64_t ve_mrna = has_stop ? h.ve + 3 : h.ve;
+	std::string ids;
+	if (opt.gff_delim >= 33 && opt.gff_delim <= 126 && hit_idx >= 0) ids = name, ids.push_back((char)opt.gff_delim), put_int(ids, hit_idx);
+	else put_id(ids, opt.gff_prefix ? opt.gff_prefix : "MP", "", id);
+	int64_t vs = rev ? c.len - ve_mrna : h.vs, ve = rev ? c.len - h.vs : ve_mrna;
+	s += c.name, s += "\tminiprot\tmRNA\t", put_int(s, vs + 1), s.push_back('\t'), put_int(s, ve), s.push_back('\t'), put_int(s, h.dp_max);
+	s.push_back('\t'), s.push_back("+-"[rev]), s += "\t.\tID=", s += ids, s += ";Rank=", put_int(s, hit_idx);
+	s += ";Identity=", put_ratio(s, (double)h.n_iden * 3 / h.blen);
+	s += ";Positive=", put_ratio(s, (double)h.n_plus * 3 / h.blen);
+	if (h.n_fs > 0) s += ";Frameshift=", put_int(s, h.n_fs);
+	if (h.n_stop > 0) s += ";StopCodon=", put_int(s, h.n_stop);
+	s += ";Target=", s += name, s.push_back(' '), put_int(s, h.qs + 1), s.push_back(' '), put_int(s, h.qe), s.push_back('\n');
+	for (int32_t j = 0; j < h.n_feat; ++j) {
+		const mpa_feat_t &f = feat[j];
+		int64_t fe = f.ve;
+		if (has_stop && f.type == 0 && j + 1 < h.n_feat && feat[j + 1].type == 1) fe += 3;   // in GFF3 the last CDS includes the stop codon
+		vs = rev ? c.len - fe : f.vs, ve = rev ? c.len - f.vs : fe;
+		s += c.name, s += "\tminiprot\t", s += f.type == 1 ? "stop_codon" : "CDS";
+		s.push_back('\t'), put_int(s, vs + 1), s.push_back('\t'), put_int(s, ve), s.push_back('\t'), put_int(s, f.score), s.push_back('\t'), s.push_back("+-"[rev]);
+		s.push_back('\t'), put_int(s, f.phase), s += "\tParent=", s += ids, s += ";Rank=", put_int(s, hit_idx);
+		if (f.type == 0) {
+			s += ";Identity=", put_ratio(s, (double)f.n_iden * 3 / f.blen);
+			if (f.acceptor[0] && strncmp(f.acceptor, "AG", 2) != 0) s += ";Acceptor=", s.push_back(f.acceptor[0]), s.push_back(f.acceptor[1]);
+			if (f.donor[0] && strncmp(f.donor, "GT", 2) != 0) s += ";Donor=", s.push_back(f.donor[0]), s.push_back(f.donor[1]);
+			if (f.n_fs > 0) s += ";Frameshift=", put_int(s, f.n_fs);
+			if (f.n_stop > 0) s += ";StopCodon=", put_int(s, f.n_stop);
+			s += ";Target=", s += name, s.push_back(' '), put_int(s, f.qs + 1), s.push_back(' '), put_int(s, f.qe);
+		}
+		s.push_back('\n');
+	}
+}
+
+// mp_write_gtf (format.c:414-451)
+static void put_gtf(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt, int32_t qlen, const mpa_hit_t &h, const mpa_feat_t *feat, int64_t id)
+{
+	if (!h.has_aln) return;
+	const Contig &c = mi->ctg[h.vid >> 1];
+	const bool rev = h.vid & 1, has_stop = h.qe == qlen && h.dist_stop == 0;
+	const int64_t ve_mrna = has_stop ? h.ve + 3 : h.ve;
+	const char *prefix = opt.gff_prefix ? opt.gff_prefix : "MP";
+	std::string gid, tid;
+	put_id(gid, prefix, "G", id), put_id(tid, prefix, "T", id);
+	const int64_t vs = rev ? c.len - ve_mrna : h.vs, ve = rev ? c.len - h.vs : ve_mrna;
+	auto head = [&](const char *type, int64_t a, int64_t b, int32_t score) {
+		s += c.name, s += "\tminiprot\t", s += type, s.push_back('\t'), put_int(s, a + 1), s.push_back('\t'), put_int(s, b), s.push_back('\t');
+		put_int(s, score), s.push_back('\t'), s.push_back("+-"[rev]), s.push_back('\t');
+	};
+	head("gene", vs, ve, h.dp_max), s += ".\tgene_id \"", s += gid, s += "\";\n";
+	head("transcript", vs, ve, h.dp_max), s += ".\ttranscript_id \"", s += tid, s += "\"; gene_id \"", s += gid, s += "\";\n";
+	for (int32_t j = 0; j < h.n_feat; ++j) {
+		const mpa_feat_t &f = feat[j];
+		if (f.type != 0) continue;
+		const int64_t a = rev ? c.len - f.ve : f.vs, b = rev ? c.len - f.vs : f.ve;
+		int64_t a2 = a, b2 = b;
+		if (f.ve == h.ve) { if (rev) a2 = c.len - ve_mrna; else b2 = ve_mrna; }           // the last exon also covers the stop codon
+		head("exon", a2, b2, f.score), s += ".\ttranscript_id \"", s += tid, s += "\"; gene_id \"", s += gid, s += "\";\n";
+		head("CDS", a, b, f.score), put_int(s, f.phase), s += "\ttranscript_id \"", s += tid, s += "\"; gene_id \"", s += gid, s += "\";\n";
+	}
+}
+
 } // namespace mpa
 
 using namespace mpa;
 
-extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
-                                  const mpa_result_t *r, char **out)
+// mp_write_output (format.c:453-473) applied to a whole batch, with the output filters and the running hit id of
+// worker_pipeline step 2 (map.c:298-311).
+static int64_t format_batch(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                            const mpa_result_t *r, int64_t *id_io, char **out)
 {
 	double t0 = now_ms();
 	const mpa_hit_t *hits = mpa_result_hits(r);
 	const int64_t *off = mpa_result_hit_off(r);
 	const uint32_t *cig = mpa_result_cigars(r);
-	// every query's lines are independent: format in parallel, concatenate in input order (map.c:293-313)
+	const mpa_feat_t *feats = mpa_result_feats(r);
 	const int32_t n_seq = q->n_seq;
+	// which hits pass the filters: needed first, because the GFF/GTF ids count printed hits across queries
+	auto passes = [&](int32_t i, int64_t j, int32_t best_sc) {
+		const mpa_hit_t &h = hits[off[i] + j];
+		const int32_t sc = h.has_aln ? h.dp_max : h.chn_sc;
+		const int32_t qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
+		if (sc <= 0 || sc < (double)best_sc * opt->out_sim) return false;
+		if (h.qe - h.qs < (double)qlen * opt->out_cov) return false;
+		return true;
+	};
+	std::vector<int64_t> id_base((size_t)n_seq + 1, 0);
+	for (int32_t i = 0; i < n_seq; ++i) {
+		const int64_t n_reg = off[i + 1] - off[i];
+		int32_t best_sc = -1;
+		int64_t n_out = 0;
+		if (n_reg > 0) best_sc = hits[off[i]].has_aln ? hits[off[i]].dp_max : hits[off[i]].chn_sc;
+		for (int64_t j = 0; j < n_reg && j < opt->out_n; ++j) n_out += passes(i, j, best_sc);
+		id_base[i + 1] = id_base[i] + n_out;
+	}
+	const int64_t id0 = id_io ? *id_io : 0;
 	std::vector<std::string> part((size_t)n_seq);
 	auto one = [&](int32_t i) {
 		std::string &s = part[i];
@@ -132,16 +236,19 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 		const int32_t qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 		const int64_t n_reg = off[i + 1] - off[i];
 		const mpa_hit_t *h = hits + off[i];
-		int32_t best_sc = -1, n_out = 0;
+		int32_t best_sc = -1;
+		int64_t id = id0 + id_base[i];
 		if (n_reg > 0) best_sc = h[0].has_aln ? h[0].dp_max : h[0].chn_sc;
 		for (int64_t j = 0; j < n_reg && j < opt->out_n; ++j) {
-			const int32_t sc = h[j].has_aln ? h[j].dp_max : h[j].chn_sc;
-			if (sc <= 0 || sc < (double)best_sc * opt->out_sim) continue;
-			if (h[j].qe - h[j].qs < (double)qlen * opt->out_cov) continue;
-			put_paf(s, mi, *opt, names[i], seq, qlen, &h[j], cig);
-			++n_out;
+			if (!passes(i, j, best_sc)) continue;
+			++id;
+			if (opt->flag & MPA_MF_GTF) put_gtf(s, mi, *opt, qlen, h[j], feats + h[j].feat_off, id);
+			else {
+				if (!(opt->flag & MPA_MF_NO_PAF)) put_paf(s, mi, *opt, names[i], seq, qlen, &h[j], cig);
+				if (opt->flag & MPA_MF_GFF) put_gff(s, mi, *opt, names[i], qlen, h[j], feats + h[j].feat_off, id, (int32_t)j + 1);
+			}
 		}
-		if (n_out == 0 && (opt->flag & MPA_MF_SHOW_UNMAP)) put_paf(s, mi, *opt, names[i], seq, qlen, nullptr, cig);
+		if (id_base[i + 1] == id_base[i] && (opt->flag & MPA_MF_SHOW_UNMAP)) put_paf(s, mi, *opt, names[i], seq, qlen, nullptr, cig);
 	};
 	{
 		unsigned hw = std::thread::hardware_concurrency();
@@ -153,15 +260,31 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 		work();
 		for (auto &th : pool) th.join();
 	}
+	if (id_io) *id_io = id0 + id_base[n_seq];
 	size_t total = 0;
 	for (const std::string &x : part) total += x.size();
 	std::string s;
 	s.reserve(total);
 	for (const std::string &x : part) s += x;
-	timing_note("format_paf", now_ms() - t0);
+	timing_note("format output", now_ms() - t0);
 	char *buf = (char*)malloc(s.size() + 1);
 	memcpy(buf, s.data(), s.size());
 	buf[s.size()] = 0;
 	*out = buf;
 	return (int64_t)s.size();
+}
+
+extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                                  const mpa_result_t *r, char **out)
+{
+	mpa_mapopt_t o = *opt;
+	o.flag &= ~(uint32_t)(MPA_MF_GFF | MPA_MF_GTF | MPA_MF_NO_PAF);
+	return format_batch(mi, &o, q, names, r, nullptr, out);
+}
+
+extern "C" int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                                     const mpa_result_t *r, int64_t *id_io, char **out)
+{
+	if (opt->flag & (MPA_MF_SHOW_RESIDUE | MPA_MF_SHOW_TRANS)) { set_error("--aln/--trans output is not implemented"); *out = nullptr; return MPA_ERR_UNSUPPORTED; }
+	return format_batch(mi, opt, q, names, r, id_io, out);
 }

@@ -59,5 +59,7 @@ int32_t block2vid(const mpa_idx_s *mi, uint32_t blk);        // mp_idx_block2pos
 // ---- device executor (mpa_dp.hip) ----------------------------------------------------------------
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi);
 void dev_free_index(mpa_idx_s *mi);
+mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
+void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);
 
 } // namespace mpa

@@ -74,7 +74,10 @@ def format_paf(idx, mo, queries, res):
     L = mpa.lib()
     names = (C.c_char_p * len(queries.names))(*[n.encode() for n in queries.names])
     out = C.c_void_p()
-    n = L.mpa_format_paf(idx.h, C.byref(mo), C.byref(queries.c), names, res, C.byref(out))
+    idc = C.c_int64(0)
+    n = L.mpa_format_output(idx.h, C.byref(mo), C.byref(queries.c), names, res, C.byref(idc), C.byref(out))
+    if n < 0:
+        raise mpa.MpaError(mpa.last_error())
     txt = C.string_at(out.value, n)
     L.mpa_free(out)
     L.mpa_result_destroy(res)

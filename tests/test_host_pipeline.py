@@ -77,12 +77,23 @@ def test_dpp3_paf_identical(oracle_built):
     assert hashlib.md5(paf).hexdigest() == "74fd00200bda6c03380bb3062fb5178b"
 
 
+def test_dpp3_gff_identical(oracle_built):
+    """config 1 with --gff: md5 d08d9caa... recorded in SURVEY.md 8(c)"""
+    idx = mpa.Index.from_fasta(golden.path("DPP3-hs.gen.fa.gz"))
+    names, seqs = read_fasta(golden.path("DPP3-mm.pep.fa.gz"))
+    mo = mpa.default_mapopt()
+    mo.flag |= 0x8
+    out = b"##gff-version 3\n" + map_batch(idx, mo, mpa.Queries(seqs, names), oracle_executor)
+    assert hashlib.md5(out).hexdigest() == "d08d9caa27b8bd896ee4f14824597c54"
+
+
 @pytest.mark.parametrize("case", golden.SYNTH_CASES, ids=[c["name"] for c in golden.SYNTH_CASES])
 def test_synthetic_paf_identical(oracle_built, case):
     contigs, prots, names = golden.synth_inputs(case)
     idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
     paf = map_batch(idx, golden.mapopt_for(case), mpa.Queries(prots, names), oracle_executor, n_threads=4)
+    paf = golden.file_header(case) + paf
     ref = open(golden.path(case["name"] + ".ref.paf"), "rb").read()
     if paf != ref:
         for x, y in zip(paf.split(b"\n"), ref.split(b"\n")):
