@@ -170,14 +170,14 @@ static hipError_t launch_ext_class(int k, const ExtArgs &a, const ExtWideArgs &w
 
 template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s)
 {
-	const size_t lds = (size_t)NW * 22 * 64 * 2 + 2 * NW * 16;
+	const size_t lds = (size_t)NW * 22 * 64 * 2 + 2 * NW * 16 + 64 * 4;
 	hipLaunchKernelGGL((k_glob_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
 	return hipGetLastError();
 }
 
 template<int G> static hipError_t launch_glob(const GlobArgs &a, int n_waves, hipStream_t s)
 {
-	const size_t lds = (size_t)(64 / G) * 22 * G * 2;
+	const size_t lds = (size_t)(64 / G) * 22 * G * 2 + (size_t)(64 / G) * 32 * 4;
 	hipLaunchKernelGGL((k_glob<G>), dim3(n_waves), dim3(64), lds, s, a);
 	return hipGetLastError();
 }

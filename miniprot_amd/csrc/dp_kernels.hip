@@ -581,7 +581,8 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		dn[2] = ac[2] = 0;
 	}
 	const int32_t max_nl = wvp->max_nl;
-	uint2 rpre = ring[2];
+	uint2 rpre = ring[2], rnxt = ring[3];
+	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
 
 	auto row = [&](auto kc, int32_t i, int par) {
 		constexpr int K = decltype(kc)::value;
@@ -593,12 +594,14 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 				if (loader) ring[((i + 20) & 63) + lane] = pf;               // rows [i+20, i+36): written >= NW steps before any wave reads them
 			}
 		}
-		const uint2 rcur = rpre;                                           // fetched during the previous row
-		rpre = ring[(i + 1) & 63];
+		const uint2 rcur = rpre;                                           // records of rows i+1 (rnxt) and i+2 are in flight / landed
+		rpre = rnxt;
+		rnxt = ring[(i + 2) & 63];
 		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);
 		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
 		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
-		const uint32_t S = pack16(*(const int16_t*)(ldsb + (int)(rcur.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rcur.y & 0xff) * 16));
+		const uint32_t S = Spre;                                           // looked up during the previous row
+		Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
 		// what the wave to the left produced for this same row in the previous step
 		const uint32_t carry_in = w > 0 ? xY[(par ^ 1) * NW + w - 1] : NEGP;
 		const uint32_t left_h = w > 0 ? xH[(par ^ 1) * NW + w - 1] : NEGP;
@@ -757,6 +760,12 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 			}
 		}
 		__syncthreads();
+		// record ring (see k_ext): rows [0,16) now, rows [16,32) wait in pf, then 16 rows per refill
+		uint32_t *ring = (uint32_t*)(lds_prof + NG * 22 * G) + grp * 32;
+		const bool loader = col < 16;
+		uint32_t pf = 0;
+		if (loader) ring[col] = rec[col], pf = rec[16 + col];
+		__syncthreads();
 		const int16_t *myprof = lds_prof + grp * 22 * G + col;
 		const int32_t seg = slen > 0 ? gc / slen : 0;
 		const bool seg_start = slen > 0 && gc % slen == 0;
@@ -767,14 +776,16 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 		int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
 		if (first_blk && col == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
 		// donor/acceptor sliding windows
-		uint32_t q0 = nl > 0 ? rec[0] : 0, q1 = nl > 1 ? rec[1] : 0;
+		const uint32_t q0 = ring[0], q1 = ring[1];
 		int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
 		int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
-		uint32_t rcur = nl > 2 ? rec[2] : 0;
+		uint32_t rcur = ring[2], rnext = ring[3];
 
 		for (int32_t i = 2; i < wv.max_nl; ++i) {
 			const bool rowlive = i < nl;
-			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
+			if ((i & 15) == 0) { if (loader) pf = rec[i + 16 + col]; }
+			else if ((i & 15) == 12) { if (loader) ring[((i + 4) & 31) + col] = pf; }
+			const uint32_t rnn = ring[(i + 2) & 31];                      // two rows ahead: LDS latency is off the critical path
 			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 			D3 = D2, D2 = D1, D1 = Dn;
 			A = An, B = Bn, C = Cn;
 			if (i == 2 && first_blk && col == 0) H2s = NEG16, H3s = NEG16;
-			rcur = rnext;
+			rcur = rnext, rnext = rnn;
 		}
 	}
 	if (tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
@@ -877,6 +888,12 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 		}
 		if (threadIdx.x < 2 * NW) xB[threadIdx.x] = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
 	}
+	// record ring of 64 rows shared by the waves, maintained by wave 0 (see k_ext_wide)
+	uint32_t *ring = (uint32_t*)(xB + 2 * NW);
+	const bool loader = w == 0 && lane < 16;
+	uint32_t pf = 0;
+	if (w == 0 && lane < 32) ring[lane] = rec[lane];
+	if (loader) pf = rec[32 + lane];
 	__syncthreads();
 	const int16_t *myprof = lds_prof + w * 22 * 64 + lane;
 	const int32_t seg = slen > 0 ? gc / slen : 0;
@@ -887,16 +904,20 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 	int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
 	int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
 	if (first_blk && lane == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
-	uint32_t q0 = nl > 0 ? rec[0] : 0, q1 = nl > 1 ? rec[1] : 0;
+	const uint32_t q0 = ring[0], q1 = ring[1];
 	int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
 	int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
-	uint32_t rcur = nl > 2 ? rec[2] : 0;
+	uint32_t rcur = ring[2];
 
 	for (int k = 0; k < w; ++k) lds_barrier();                   // skew: wave w runs w rows behind wave 0
 	for (int32_t i = 2; i < nl; ++i) {
 		const int32_t par = (i + w) & 1;
 		{
-			const uint32_t rnext = (i + 1 < nl) ? rec[i + 1] : 0;
+			if (w == 0) {
+				if ((i & 15) == 0) { if (i > 2 && loader) pf = rec[i + 32 + lane]; }
+				else if ((i & 15) == 12) { if (loader) ring[((i + 20) & 63) + lane] = pf; }
+			}
+			const uint32_t rnext = ring[(i + 1) & 63];
 			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);

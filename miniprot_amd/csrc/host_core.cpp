@@ -63,7 +63,9 @@ static void pairs_digit_pass(Pair64 *beg, Pair64 *end, int shift)
 		Pair64 *p = beg;
 		for (int d = 0; d < 256; ++d) cursor[d] = p, p += cnt[d], limit[d] = p;
 	}
-	for (int k = 0; k < 256;) {
+	bool single = false;
+	for (int d = 0; d < 256; ++d) if (cnt[d] == (size_t)(end - beg)) { single = true; break; }
+	for (int k = 0; !single && k < 256;) {
 		if (cursor[k] == limit[k]) { ++k; continue; }
 		int d = (int)(cursor[k]->x >> shift & 0xff);
 		if (d == k) { ++cursor[k]; continue; }
@@ -89,8 +91,16 @@ static void pairs_digit_pass(Pair64 *beg, Pair64 *end, int shift)
 
 void sort_pairs_by_x(Pair64 *beg, Pair64 *end)
 {
-	if (end - beg <= 64) pairs_insertion(beg, end);
-	else pairs_digit_pass(beg, end, 56);
+	if (end - beg <= 64) { pairs_insertion(beg, end); return; }
+	// A digit level at which every key has the same byte leaves the array untouched (each element is already in
+	// "its" bucket) and just recurses into that single bucket, so the leading constant bytes can be skipped without
+	// changing the result -- keys here are chain scores or block ids, i.e. mostly zero in the top bytes.
+	uint64_t all_or = 0, all_and = ~0ULL;
+	for (const Pair64 *p = beg; p != end; ++p) all_or |= p->x, all_and &= p->x;
+	const uint64_t varying = all_or ^ all_and;
+	int shift = 56;
+	while (shift > 0 && ((varying >> shift) & 0xff) == 0) shift -= 8;
+	pairs_digit_pass(beg, end, shift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +248,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
 	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
 
-	std::vector<int32_t> f(n), mark(n, 0), peak(n);
+	std::vector<int32_t> f(n), mark(n, 0);
 	std::vector<int64_t> pred(n);
 
 	// ---- forward pass: best predecessor of every anchor (chain.c:181-209)
@@ -266,7 +276,6 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 			if (pred[j] >= 0) mark[pred[j]] = (int32_t)i;
 		}
 		f[i] = best, pred[i] = best_j;
-		peak[i] = best_j >= 0 && peak[best_j] > best ? peak[best_j] : best;
 		if (hot_f < best) hot_f = best, hot = i;
 	}
 
