@@ -106,7 +106,7 @@ void sort_pairs_by_x(Pair64 *beg, Pair64 *end)
 // ------------------------------------------------------------------------------------------------
 // sketching
 // ------------------------------------------------------------------------------------------------
-uint32_t hash32_mask(uint32_t key, uint32_t mask)
+uint32_t hash32_mask(uint32_t key, uint32_t mask)   // sketch.c:7-16; a bijection of the masked key space
 {
 	key = (key + ~(key << 15)) & mask;
 	key ^= key >> 10;
@@ -146,27 +146,25 @@ void sketch_protein(const char *seq, int32_t len, int32_t kmer, int32_t mod_bit,
 	}
 }
 
-static void orf_kmers(const uint8_t *seq, int64_t st, int64_t en, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out)
+// Walks the three forward reading frames of a nucleotide string (sketch.c:64-118): a frame's open reading frame
+// ends at a stop codon or an ambiguous base, and only ORFs of at least min_aa_len codons contribute k-mers.
+// sink(bucket, last_base_index) is called for every selected k-mer.
+template<class Sink>
+static inline void scan_nt4_kmers(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, Sink &&sink)
 {
-	const uint8_t *c13 = tab_codon13();
-	KmerRoller roll(kmer, mod_bit);
-	for (int64_t i = st; i < en; i += 3) {
-		uint32_t bucket;
-		if (roll.feed(c13[seq[i] << 4 | seq[i + 1] << 2 | seq[i + 2]], &bucket))
-			out.push_back((uint64_t)bucket << 32 | (uint64_t)(((i + 2) >> bbit) + boff));
-	}
-}
-
-void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out, bool sorted)
-{
-	const uint8_t *codon_tab = tab_codon();
+	const uint8_t *codon_tab = tab_codon(), *c13 = tab_codon13();
 	// one open reading frame per codon phase: its number of codons so far and the position of its last base
 	int64_t orf_len[3] = { 0, 0, 0 }, orf_end[3] = { -1, -1, -1 };
 	auto close = [&](int f) {
-		if (orf_len[f] >= min_aa_len) orf_kmers(seq, orf_end[f] + 1 - orf_len[f] * 3, orf_end[f] + 1, kmer, mod_bit, bbit, boff, out);
+		if (orf_len[f] >= min_aa_len) {
+			KmerRoller roll(kmer, mod_bit);
+			for (int64_t i = orf_end[f] + 1 - orf_len[f] * 3, en = orf_end[f] + 1; i < en; i += 3) {
+				uint32_t bucket;
+				if (roll.feed(c13[seq[i] << 4 | seq[i + 1] << 2 | seq[i + 2]], &bucket)) sink(bucket, i + 2);
+			}
+		}
 		orf_len[f] = 0, orf_end[f] = -1;
 	};
-	out.clear();
 	int32_t valid = 0;
 	uint32_t codon = 0;
 	for (int64_t i = 0; i < len; ++i) {
@@ -183,9 +181,78 @@ void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kme
 		}
 	}
 	close(0), close(1), close(2);
+}
+
+void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit, int64_t boff, std::vector<uint64_t> &out, bool sorted)
+{
+	out.clear();
+	scan_nt4_kmers(seq, len, min_aa_len, kmer, mod_bit, [&](uint32_t bucket, int64_t last) {
+		out.push_back((uint64_t)bucket << 32 | (uint64_t)((last >> bbit) + boff));
+	});
 	if (!sorted || out.size() <= 1) return;
 	sort_u64(out.data(), out.data() + out.size());
 	out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+// mp_refine_reg's seeding (map.c:97-131) without materialising the window's k-mer list: the reference sorts the
+// window's and the query's k-mers together and pairs up equal hashes; the same pairs come out of streaming the window
+// past a bitmap of the query's hashes, keeping the (rare) hits, and grouping those.  `qk` is the query's k-mer list
+// (hash<<32 | position) sorted; `filter` has bit h set for every hash h in it.
+void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32_t kmer, const std::vector<uint64_t> &qk,
+                       const uint64_t *filter, int32_t max_ava, std::vector<uint64_t> &hits, std::vector<uint64_t> &a)
+{
+	hits.clear(), a.clear();
+	// One pass over the window, three interleaved reading frames.  `filter` is indexed by the packed k-mer word (the hash
+	// is a bijection of it, so it is only evaluated for the rare hits).  A frame's hits are provisional until its open
+	// reading frame turns out to be at least min_aa_len codons long.
+	const uint8_t *codon_tab = tab_codon(), *c13 = tab_codon13();
+	const uint32_t mask = (1U << kmer * 4) - 1;
+	uint32_t word[3] = { 0, 0, 0 }, codon = 0;
+	int32_t orf_len[3] = { 0, 0, 0 }, valid = 0;
+	size_t mark[3] = { 0, 0, 0 };                      // hits[] holds committed hits; provisional ones live in pend[f]
+	static thread_local std::vector<uint64_t> pend[3];
+	for (int f = 0; f < 3; ++f) pend[f].clear();
+	(void)mark;
+	auto close = [&](int f) {
+		if (orf_len[f] >= min_aa_len) hits.insert(hits.end(), pend[f].begin(), pend[f].end());
+		pend[f].clear(), orf_len[f] = 0, word[f] = 0;
+	};
+	int f = 1;                                         // phase label of the codon ending at i: (i + 1) % 3
+	for (int64_t i = 0; i < len; ++i, f = f == 2 ? 0 : f + 1) {
+		const uint32_t b = nt[i];
+		if (b < 4) {
+			codon = (codon << 2 | b) & 0x3f;
+			if (++valid >= 3) {
+				if (codon_tab[codon] >= 20) close(f);
+				else {
+					const uint32_t w = word[f] = (word[f] << 4 | c13[codon]) & mask;
+					if (++orf_len[f] >= kmer && (filter[w >> 6] >> (w & 63) & 1))
+						pend[f].push_back((uint64_t)hash32_mask(w, mask) << 32 | (uint64_t)i);
+				}
+			}
+		} else {
+			close(0), close(1), close(2);
+			valid = 0, codon = 0;
+		}
+	}
+	close(0), close(1), close(2);
+	if (hits.empty()) return;
+	sort_u64(hits.data(), hits.data() + hits.size());
+	size_t q0 = 0;
+	for (size_t k = 0, i = 1; i <= hits.size(); ++i) {
+		if (i < hits.size() && hits[k] >> 32 == hits[i] >> 32) continue;
+		const uint64_t h = hits[k] >> 32;
+		while (q0 < qk.size() && qk[q0] >> 32 < h) ++q0;
+		size_t q1 = q0;
+		while (q1 < qk.size() && qk[q1] >> 32 == h) ++q1;
+		const int64_t n1 = (int64_t)(i - k), n2 = (int64_t)(q1 - q0);
+		if (n2 > 0 && (int32_t)n1 * (int32_t)n2 <= max_ava)
+			for (size_t i1 = k; i1 < i; ++i1)
+				for (size_t i2 = q0; i2 < q1; ++i2)
+					a.push_back((uint64_t)(uint32_t)hits[i1] << 32 | (uint32_t)qk[i2]);
+		k = i;
+	}
+	sort_u64(a.data(), a.data() + a.size());
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,6 +23,10 @@ void sketch_protein(const char *seq, int32_t len, int32_t kmer, int32_t mod_bit,
 void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kmer, int32_t mod_bit, int32_t bbit,
                 int64_t boff, std::vector<uint64_t> &out, bool sorted = true);
 
+// refinement seeding (map.c:97-131): all (window position<<32 | query position) pairs of equal k-mers, sorted
+void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32_t kmer, const std::vector<uint64_t> &qk_sorted,
+                       const uint64_t *filter, int32_t max_ava, std::vector<uint64_t> &hits_scratch, std::vector<uint64_t> &a);
+
 // ---- chaining (chain.c) -----------------------------------------------------------------------------
 struct ChainParams {
 	int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;

@@ -166,31 +166,61 @@ static int32_t occurrence_cutoff(const mpa_idx_s *mi, const std::vector<uint64_t
 }
 
 // mp_refine_reg (map.c:32-111): re-seed the region's window with all 5-mers at base resolution, re-chain
-static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const char *aa, int32_t l_aa, Region &r, int32_t extl, int32_t extr)
+// The query side of the refinement seeding, built once per query: its k-mers sorted by hash and a bitmap over the
+// hash space (2^(4k) bits; one per worker thread, reused) with the query's hashes set.
+struct RefineQuery {
+	std::vector<uint64_t> qk;
+	std::vector<uint64_t> *filter = nullptr;
+	int32_t kmer = 0;
+	static std::vector<uint64_t> &thread_filter(int32_t kmer) {
+		static thread_local std::vector<uint64_t> f;
+		const size_t words = ((size_t)1 << (4 * kmer)) / 64 + 1;
+		if (f.size() < words) f.assign(words, 0);
+		return f;
+	}
+	std::vector<uint32_t> words;                      // packed k-mer words of the query (bitmap keys)
+	RefineQuery(const char *aa, int32_t l_aa, int32_t k) : kmer(k) {
+		sketch_protein(aa, l_aa, k, 0, qk);
+		sort_u64(qk.data(), qk.data() + qk.size());
+		if (k <= 6) {
+			filter = &thread_filter(k);
+			const uint8_t *aa13 = tab_aa13();
+			const uint32_t mask = (1U << 4 * k) - 1;
+			uint32_t w = 0;
+			for (int32_t i = 0, run = 0; i < l_aa; ++i) {
+				const uint32_t c = aa13[(uint8_t)aa[i]];
+				if (c >= 14) { run = 0, w = 0; continue; }
+				w = (w << 4 | c) & mask;
+				if (++run >= k) words.push_back(w), (*filter)[w >> 6] |= 1ULL << (w & 63);
+			}
+		}
+	}
+	~RefineQuery() { if (filter) for (uint32_t w : words) (*filter)[w >> 6] = 0; }
+};
+
+static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, Region &r, int32_t extl, int32_t extr)
 {
 	const int32_t kmer = opt.kmer2, is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	const int64_t ctg_len = mi->ctg[r.vid >> 1].len;
 	const int64_t as = r.vs > extl ? r.vs - extl : 0;
 	const int64_t ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
-	std::vector<uint8_t> nt((size_t)(ae - as));
+	static thread_local std::vector<uint8_t> nt;
+	static thread_local std::vector<uint64_t> sd, a;
+	nt.resize((size_t)(ae - as));
 	g_acc[13] += 1000000LL * 1;                                // (count of refined regions, printed /1e6/threads)
 	{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
-	std::vector<uint64_t> sd, sq;
-	// the reference sorts + dedups the window's k-mers, appends the query's (bit 31 set) and sorts again; one sort of the
-	// merged list followed by the dedup gives the same list (query entries never equal reference entries)
-	{ AccTimer tm(9); sketch_nt4(nt.data(), ae - as, mi->opt.min_aa_len, kmer, 0, 0, 0, sd, false); }
-	std::vector<uint64_t> a;
-	{
+	if (rq.filter) {
+		AccTimer tm(9);
+		refine_seed_pairs(nt.data(), ae - as, mi->opt.min_aa_len, kmer, rq.qk, rq.filter->data(), opt.max_ava, sd, a);
+	} else {
+		// large k: the reference's own formulation -- sort the window's and the query's (bit 31 set) k-mers together;
+		// one sort of the merged list gives the same groups (query entries never equal reference entries)
 		AccTimer tm(10);
-		sketch_protein(aa, l_aa, kmer, 0, sq);
-		sd.reserve(sd.size() + sq.size());
-		for (uint64_t x : sq) sd.push_back(x | 1ULL << 31);       // tag query k-mers; they sort after reference ones of the same hash
+		sketch_nt4(nt.data(), ae - as, mi->opt.min_aa_len, kmer, 0, 0, 0, sd, false);
+		for (uint64_t x : rq.qk) sd.push_back(x | 1ULL << 31);
 		sort_u64(sd.data(), sd.data() + sd.size());
 		sd.erase(std::unique(sd.begin(), sd.end()), sd.end());
-	}
-	{
-		AccTimer tm(11);
-		// all (reference position, query position) pairs of k-mers sharing a hash, unless there are too many
+		a.clear();
 		const size_t n = sd.size();
 		for (size_t k = 0, i = 1; i <= n; ++i) {
 			if (i < n && sd[k] >> 32 == sd[i] >> 32) continue;
@@ -451,8 +481,9 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 	{
 		AccTimer tm(5);
 		std::vector<Region> kept;
+		RefineQuery rq(qs.seq, qs.qlen, opt.kmer2);
 		for (size_t i = 0; i < regs.size(); ++i) {
-			refine_region(mi, opt, qs.seq, qs.qlen, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
+			refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
 			if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
 		}
 		regs.swap(kept);
