@@ -24,7 +24,8 @@ void sort_u64(uint64_t *beg, uint64_t *end)
 	uint64_t all_or = 0, all_and = ~0ULL;
 	for (size_t i = 0; i < n; ++i) all_or |= beg[i], all_and &= beg[i];
 	const uint64_t varying = all_or ^ all_and;
-	std::vector<uint64_t> tmp(n);
+	static thread_local std::vector<uint64_t> tmp;
+	if (tmp.size() < n) tmp.resize(n);
 	uint64_t *src = beg, *dst = tmp.data();
 	for (int shift = 0; shift < 64; shift += 11) {
 		if (((varying >> shift) & 0x7ff) == 0) continue;
@@ -315,8 +316,13 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
 	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
 
-	std::vector<int32_t> f(n), mark(n, 0);
-	std::vector<int64_t> pred(n);
+	// per-thread scratch, reused across calls: with hundreds of workers, fresh multi-hundred-KB vectors per call turn
+	// into mmap/munmap traffic on the shared address space
+	static thread_local std::vector<int32_t> f, mark, order;
+	static thread_local std::vector<int64_t> pred;
+	static thread_local std::vector<Pair64> ends, first;
+	static thread_local std::vector<uint64_t> packed, u_sorted;
+	f.resize(n), pred.resize(n), mark.assign(n, 0);
 
 	// ---- forward pass: best predecessor of every anchor (chain.c:181-209)
 	int64_t win = 0, hot = -1;         // start of the target-distance window; anchor with the best score so far
@@ -347,18 +353,21 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 	}
 
 	// ---- extraction, best chain end first (chain.c:8-75)
-	std::vector<Pair64> ends;
+	ends.clear();
 	for (int64_t i = 0; i < n; ++i)
 		if (f[i] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[i], (uint64_t)i });
 	if (ends.empty()) { a.clear(); return; }
 	sort_pairs_by_x(ends.data(), ends.data() + ends.size());
 	std::fill(mark.begin(), mark.end(), 0);
-	std::vector<int32_t> order;                        // anchor indices of the kept chains, each chain from its END backwards
-	order.reserve(n);
+	order.clear();                                     // anchor indices of the kept chains, each chain from its END backwards
 	for (int64_t k = (int64_t)ends.size() - 1; k >= 0; --k) {
 		const int64_t tail = (int64_t)ends[k].y;
 		const int32_t tail_f = (int32_t)ends[k].x;
 		if (mark[tail] != 0) continue;
+		// An unclaimed anchor without predecessor is a one-anchor chain.  When min_cnt rejects those, the only trace it
+		// would leave is its own claim mark, which nothing reads any more: every anchor chained onto it scores above
+		// kmer == f[tail] and has therefore been visited already.
+		if (pred[tail] < 0 && p.min_cnt > 1) continue;
 		// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
 		int64_t cut = tail, walk = tail, stop = -1;
 		int32_t best_suffix = 0;
@@ -382,8 +391,8 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 	if (u.empty()) { a.clear(); return; }
 
 	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
-	std::vector<uint64_t> packed(order.size());
-	std::vector<Pair64> first(u.size());
+	packed.resize(order.size());
+	first.resize(u.size());
 	{
 		size_t k = 0;
 		for (size_t c = 0; c < u.size(); ++c) {
@@ -394,7 +403,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 		}
 	}
 	sort_pairs_by_x(first.data(), first.data() + first.size());
-	std::vector<uint64_t> u_sorted(u.size());
+	u_sorted.resize(u.size());
 	a.resize(packed.size());
 	size_t k = 0;
 	for (size_t c = 0; c < u.size(); ++c) {
@@ -404,7 +413,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 		memcpy(&a[k], &packed[from], cnt * sizeof(uint64_t));
 		k += cnt;
 	}
-	u.swap(u_sorted);
+	u.assign(u_sorted.begin(), u_sorted.end());
 }
 
 } // namespace mpa

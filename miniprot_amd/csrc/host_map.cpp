@@ -436,7 +436,8 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 	const mpa_mapopt_t &opt = b->opt;
 	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
-	std::vector<uint64_t> sd, a, u;
+	static thread_local std::vector<uint64_t> sd, a, u;     // per-worker scratch (see chain_anchors)
+	a.clear(), u.clear();
 	{
 		AccTimer tm(0);
 		sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
