@@ -217,6 +217,14 @@ int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_q
 int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                           const mpa_result_t *r, int64_t *id_io, char **out);
 
+/* A stream of mini-batches (the loop of mp_map_file()'s kt_pipeline, map.c:273-345, which overlaps only file I/O with
+ * mapping): a three-stage software pipeline in which the host seeding/chaining of batch k+1 and the flattening +
+ * formatting of batch k-1 overlap the GPU DP rounds of batch k.  results[k] is what mpa_map_batch() returns for
+ * batches[k].  With names != NULL (names[k][q] = name of query q of batch k) the output text of every batch is produced
+ * as well, as by mpa_format_output() with *id_io threaded through the batches in order: text[k] (mpa_free) / text_len[k]. */
+int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                    const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len);
+
 const char *mpa_version(void);
 
 #ifdef __cplusplus

@@ -121,6 +121,9 @@ def lib():
             ("mpa_result_hit_off", C.POINTER(C.c_int64), [C.c_void_p]),
             ("mpa_result_cigars", C.POINTER(C.c_uint32), [C.c_void_p]),
             ("mpa_result_destroy", None, [C.c_void_p]),
+            ("mpa_map_batches", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MapOpt), C.c_int32, C.POINTER(QBatch),
+                                          C.POINTER(C.POINTER(C.c_char_p)), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
             ("mpa_format_output", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
                                               C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
             ("mpa_format_paf", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
@@ -269,6 +272,26 @@ def dpopt_from(mo):
     dp = DpOpt()
     lib().mpa_dpopt_from_mapopt(C.byref(mo), C.byref(dp))
     return dp
+
+
+def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False):
+    """mpa_map_batches(): a stream of Queries batches through the pipelined mapper.  Returns the list of output texts
+    (bytes, one per batch; the hit-id counter runs across the batches as in one output file)."""
+    n = len(batches)
+    qb = (QBatch * n)(*[b.c for b in batches])
+    name_arrays = [(C.c_char_p * len(b.names))(*[x.encode() for x in b.names]) for b in batches]
+    names = (C.POINTER(C.c_char_p) * n)(*[C.cast(a, C.POINTER(C.c_char_p)) for a in name_arrays])
+    res = (C.c_void_p * n)()
+    text = (C.c_void_p * n)()
+    tlen = (C.c_int64 * n)()
+    idc = C.c_int64(0)
+    _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc), text, tlen))
+    out = []
+    for k in range(n):
+        out.append(C.string_at(text[k], tlen[k]))
+        lib().mpa_free(C.c_void_p(text[k]))
+        lib().mpa_result_destroy(C.c_void_p(res[k]))
+    return out
 
 
 def dp_run(ctx, idx, dpopt, queries, tasks):

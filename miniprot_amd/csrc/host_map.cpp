@@ -88,7 +88,10 @@ namespace mpa {
 // creation would otherwise cost more than some of the stages.
 class WorkerPool {
 public:
-	static WorkerPool &get() { static WorkerPool *p = new WorkerPool(); return *p; }   // never destroyed: workers outlive main()
+	// never destroyed: workers outlive main().  One pool per lane, so that the pipeline stages of mpa_map_batches()
+	// (seeding of the next batch / DP-round bookkeeping / flattening + formatting of the previous one) can each run
+	// their own parallel region at the same time.
+	static WorkerPool &get(int lane) { static WorkerPool *p[3] = { new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
 	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
 		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
 		std::unique_lock<std::mutex> run_lock(run_mu_);              // one parallel region at a time
@@ -134,10 +137,11 @@ private:
 	uint64_t epoch_ = 0;
 };
 
+static thread_local int tl_pool_lane = 0;
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 {
 	std::function<void(int64_t)> f = fn;
-	WorkerPool::get().run(n_threads, n, f);
+	WorkerPool::get(tl_pool_lane).run(n_threads, n, f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -779,11 +783,8 @@ const mpa_feat_t *mpa_result_feats(const mpa_result_t *r) { return r->feats.data
 void mpa_result_destroy(mpa_result_t *r) { delete r; }
 
 // one (sub-)batch through the stage machine with the HIP executor
-static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
+static int run_dp_rounds(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_qbatch_t *q, mpa_batch_t *b)
 {
-	*out = nullptr;
-	mpa_batch_t *b = mpa_batch_begin(mi, opt, q, n_threads);
-	if (!b) return MPA_ERR_ARG;
 	const mpa_dp_task_t *tasks;
 	mpa_dpopt_t dpopt;
 	int64_t n;
@@ -795,13 +796,91 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 		double t0 = now_ms();
 		int rc = mpa_dp_run(ctx, mi, &dpopt, q, n, tasks, rst.data(), &pool, &n_pool);
 		timing_note("mpa_dp_run (total)", now_ms() - t0);
-		if (rc != MPA_OK) { free(pool); delete b; return rc; }
+		if (rc != MPA_OK) { free(pool); return rc; }
 		rc = mpa_batch_dp_results(b, rst.data(), pool);
 		free(pool);
-		if (rc != MPA_OK) { delete b; return rc; }
+		if (rc != MPA_OK) return rc;
 	}
+	return MPA_OK;
+}
+
+static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
+{
+	*out = nullptr;
+	mpa_batch_t *b = mpa_batch_begin(mi, opt, q, n_threads);
+	if (!b) return MPA_ERR_ARG;
+	const int rc = run_dp_rounds(ctx, mi, q, b);
+	if (rc != MPA_OK) { delete b; return rc; }
 	*out = mpa_batch_finish(b);
 	return MPA_OK;
+}
+
+// Several mini-batches as a three-stage software pipeline: [seed..plan of batch k+1] | [DP rounds of batch k on the GPU]
+// | [flatten + format batch k-1].  Each stage is one host thread driving its own worker-pool lane.
+int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                    const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
+{
+	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
+	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
+	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
+	struct Slot { mpa_batch_t *b = nullptr; bool begun = false, dp_done = false; };
+	std::vector<Slot> slot((size_t)n_batches);
+	std::mutex mu;
+	std::condition_variable cv;
+	int32_t n_dp_done = 0, rc_all = MPA_OK;
+	std::string err;
+	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
+
+	std::thread seeder([&] {
+		tl_pool_lane = 1;
+		for (int32_t k = 0; k < n_batches; ++k) {
+			{	// stay at most one batch ahead of the one in its DP rounds
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_dp_done + 1; });
+				if (rc_all != MPA_OK) return;
+			}
+			mpa_batch_t *b = mpa_batch_begin(mi, opt, &batches[k], n_threads);
+			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
+			std::lock_guard<std::mutex> g(mu);
+			slot[k].b = b, slot[k].begun = true;
+			cv.notify_all();
+		}
+	});
+	std::thread finisher([&] {
+		tl_pool_lane = 2;
+		for (int32_t k = 0; k < n_batches; ++k) {
+			{
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].dp_done; });
+				if (!slot[k].dp_done) return;
+			}
+			results[k] = mpa_batch_finish(slot[k].b);
+			slot[k].b = nullptr;
+			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], id_io, &text[k]);
+		}
+	});
+	for (int32_t k = 0; k < n_batches; ++k) {
+		{
+			std::unique_lock<std::mutex> g(mu);
+			cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
+			if (rc_all != MPA_OK) break;
+		}
+		const int rc = run_dp_rounds(ctx, mi, &batches[k], slot[k].b);
+		if (rc != MPA_OK) { fail(rc, mpa_last_error()); break; }
+		std::lock_guard<std::mutex> g(mu);
+		slot[k].dp_done = true, ++n_dp_done;
+		cv.notify_all();
+	}
+	seeder.join(), finisher.join();
+	if (rc_all != MPA_OK) {
+		for (Slot &sl : slot) delete sl.b;
+		for (int32_t k = 0; k < n_batches; ++k) {
+			delete results[k], results[k] = nullptr;
+			if (text && text[k]) free(text[k]), text[k] = nullptr;
+		}
+		set_error(err);
+	}
+	return rc_all;
 }
 
 int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
