@@ -6,8 +6,11 @@ CIGAR/statistics -> PAF text) over one batch of synthetic proteins against a syn
 is already resident in HBM.  Workload = BASELINE.json configs[1]: synthetic 50 Mbp genome x 1k ~400 aa
 proteins, prebuilt index, flags `-u` (generator: tools/gen_synth.py).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The K steps are K mini-batches handed to mpa_map_batches() as one stream (the library pipelines host seeding, GPU DP
+rounds and formatting across consecutive batches; --no-stream times one blocking mpa_map_batch() call per step).
 
 N>1: proteins are sharded over ranks (one process per GPU, no data-path collective); every rank maps
 its own shard of the same size (weak scaling) and the PAF text is gathered to rank 0 over RCCL.
@@ -47,15 +50,15 @@ def aligned_residues(paf):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-mb", type=float, default=50.0)
     ap.add_argument("--n-prot", type=int, default=1000)
     ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = all cores / ranks)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="proteins in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stream", action="store_true", help="hand the K steps to mpa_map_batches() as one pipelined stream of mini-batches "
-                    "instead of one blocking mpa_map_batch() call per step (pays off when host seeding is a large share: big genomes)")
+    ap.add_argument("--no-stream", action="store_true", help="one blocking mpa_map_batch() call per step instead of handing the K steps "
+                    "to mpa_map_batches() as a pipelined stream of mini-batches")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,12 +110,14 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(k):
-        """k steps = k mini-batches, one blocking mpa_map_batch() + format per step.  --stream hands them to the library as a
-        stream (mpa_map_batches), which overlaps the host seeding of batch i+1 and the formatting of batch i-1 with the GPU
-        DP rounds of batch i -- every step's work, pipeline fill and drain included, still happens inside the timed region."""
+        """k steps = k mini-batches of the same 1000 proteins, handed to the library as a stream (mpa_map_batches -- what
+        miniprot's own batch loop, map.c:273-345, would call): the host seeding of batch i+1 and the formatting of batch i-1
+        overlap the GPU DP rounds of batch i, and two batches are in their DP rounds at a time (the rounds of one batch are
+        dominated by the tails of a few very long DP calls).  Every step's work, pipeline fill and drain included, happens
+        inside the timed region.  --no-stream: one blocking mpa_map_batch() + format per step."""
         if k <= 0:
             return b""
-        if not a.stream:
+        if a.no_stream:
             out = b""
             for _ in range(k):
                 out = step()
@@ -196,7 +201,7 @@ def main():
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
            "config": {"workload": "synthetic %.0f Mbp genome x %d proteins per GPU (~400 aa, 15%% diverged), index resident in HBM, flags -u" % (a.genome_mb, a.n_prot),
-                      "proteins_per_gpu": a.n_prot, "aligned_residues_per_step": residues, "host_threads_per_rank": n_threads, "parallelism": "proteins sharded x%d" % world, "batching": "blocking call per step" if not a.stream else "stream of mini-batches (mpa_map_batches)"},
+                      "proteins_per_gpu": a.n_prot, "aligned_residues_per_step": residues, "host_threads_per_rank": n_threads, "parallelism": "proteins sharded x%d" % world, "batching": "blocking call per step" if a.no_stream else "stream of mini-batches (mpa_map_batches)"},
            "roofline": roofline, "cpu_baseline": cpu,
            "stage_ms_per_step": {k: v / a.steps for k, v in dp_ms.items()},
            "dp_cells_per_step": {"ext": ext_cells // max(a.steps, 1), "glob": glob_cells // max(a.steps, 1)},

@@ -436,14 +436,16 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	int n_side = 0;
 	struct Launch { int side; bool is_ext; };
 	std::vector<Launch> launches;
+	static const int n_streams = [] { const char *e = getenv("MPA_SIDE_STREAMS"); int v = e ? atoi(e) : mpa_ctx_s::kSide; return v < 1 ? 1 : v > mpa_ctx_s::kSide ? mpa_ctx_s::kSide : v; }();
 	auto begin_side = [&](bool is_ext) -> hipStream_t {
 		const int k = n_side++;
-		(void)hipStreamWaitEvent(ctx->side[k], ctx->fork_ev, 0);
-		(void)hipEventRecord(ctx->lev[2 * k], ctx->side[k]);
+		hipStream_t st = ctx->side[k % n_streams];
+		(void)hipStreamWaitEvent(st, ctx->fork_ev, 0);
+		(void)hipEventRecord(ctx->lev[2 * k], st);
 		launches.push_back(Launch{ k, is_ext });
-		return ctx->side[k];
+		return st;
 	};
-	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[k]); };
+	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[k % n_streams]); };
 
 	// ---- K1: extension calls
 	ExtArgs ea;

@@ -829,14 +829,19 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, rc_all = MPA_OK;
 	std::string err;
+	int n_lanes = 2;
+	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
+	n_lanes = std::max(1, std::min(n_lanes, 4));
+	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
+	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	std::thread seeder([&] {
 		tl_pool_lane = 1;
 		for (int32_t k = 0; k < n_batches; ++k) {
-			{	// stay at most one batch ahead of the one in its DP rounds
+			{	// stay at most one batch ahead of the ones in their DP rounds
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_dp_done + 1; });
+				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_dp_done + n_lanes; });
 				if (rc_all != MPA_OK) return;
 			}
 			mpa_batch_t *b = mpa_batch_begin(mi, opt, &batches[k], n_threads);
@@ -859,19 +864,29 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], id_io, &text[k]);
 		}
 	});
-	for (int32_t k = 0; k < n_batches; ++k) {
-		{
-			std::unique_lock<std::mutex> g(mu);
-			cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
-			if (rc_all != MPA_OK) break;
+	// DP lanes: lane d drives the DP rounds of batches d, d + n_lanes, ... on its own device context (streams + buffers).
+	// The rounds of one batch are dominated by the tails of a few very long DP calls, during which the GPU is nearly
+	// idle; the next batch's rounds fill that space.
+	auto dp_lane = [&](int d, mpa_ctx_t *cd) {
+		for (int32_t k = d; k < n_batches; k += n_lanes) {
+			{
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
+				if (rc_all != MPA_OK) return;
+			}
+			const int rc = run_dp_rounds(cd, mi, &batches[k], slot[k].b);
+			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
+			std::lock_guard<std::mutex> g(mu);
+			slot[k].dp_done = true, ++n_dp_done;
+			cv.notify_all();
 		}
-		const int rc = run_dp_rounds(ctx, mi, &batches[k], slot[k].b);
-		if (rc != MPA_OK) { fail(rc, mpa_last_error()); break; }
-		std::lock_guard<std::mutex> g(mu);
-		slot[k].dp_done = true, ++n_dp_done;
-		cv.notify_all();
-	}
+	};
+	std::vector<std::thread> lanes;
+	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
+	dp_lane(0, ctx);
+	for (auto &t : lanes) t.join();
 	seeder.join(), finisher.join();
+	ctx_absorb_sibling_stats(ctx);
 	if (rc_all != MPA_OK) {
 		for (Slot &sl : slot) delete sl.b;
 		for (int32_t k = 0; k < n_batches; ++k) {
