@@ -137,10 +137,14 @@ static int ext_class_of(int32_t ncol)
 	return -1;
 }
 
-template<int G> static hipError_t launch_ext(const ExtArgs &a, int n_waves, hipStream_t s)
+// the three narrow classes (16/32/64 lanes per call) in one launch; a.waves = the whole descriptor array
+static hipError_t launch_ext_narrow(const ExtArgs &a, const int *first, const int *cnt, hipStream_t s)
 {
-	const size_t lds = (size_t)2 * (64 / G) * G * PROF_COL_STRIDE + (size_t)(64 / G) * 32 * 8 + 2 * MPA_PEN_MAX * 4;
-	hipLaunchKernelGGL((k_ext<G>), dim3(n_waves), dim3(64), lds, s, a);
+	// LDS of the largest instantiation (G = 16: 4 rings)
+	const size_t lds = (size_t)2 * 64 * PROF_COL_STRIDE + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4;
+	NarrowMap m{};
+	for (int k = 0; k < 3; ++k) m.first[k] = first[k], m.cnt[k] = cnt[k];
+	hipLaunchKernelGGL(k_ext_narrow, dim3((unsigned)(cnt[0] + cnt[1] + cnt[2])), dim3(64), lds, s, a, m);
 	return hipGetLastError();
 }
 
@@ -155,16 +159,13 @@ template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_g
 	return hipGetLastError();
 }
 
-static hipError_t launch_ext_class(int k, const ExtArgs &a, const ExtWideArgs &wa, int n_waves, hipStream_t s)
+static hipError_t launch_ext_wide_class(int k, const ExtWideArgs &wa, int n_groups, hipStream_t s)
 {
 	switch (k) {
-	case 0: return launch_ext<16>(a, n_waves, s);
-	case 1: return launch_ext<32>(a, n_waves, s);
-	case 2: return launch_ext<64>(a, n_waves, s);
-	case 3: return launch_ext_wide<2>(wa, n_waves, s);
-	case 4: return launch_ext_wide<4>(wa, n_waves, s);
-	case 5: return launch_ext_wide<8>(wa, n_waves, s);
-	default: return launch_ext_wide<16>(wa, n_waves, s);
+	case 3: return launch_ext_wide<2>(wa, n_groups, s);
+	case 4: return launch_ext_wide<4>(wa, n_groups, s);
+	case 5: return launch_ext_wide<8>(wa, n_groups, s);
+	default: return launch_ext_wide<16>(wa, n_groups, s);
 	}
 }
 
@@ -175,10 +176,15 @@ template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_gro
 	return hipGetLastError();
 }
 
-template<int G> static hipError_t launch_glob(const GlobArgs &a, int n_waves, hipStream_t s)
+// traceback classes 0,1,2 (16/32/64 lanes) and 7 (block-major, > 1024 columns) in one launch; a.waves = whole array
+static hipError_t launch_glob_narrow(const GlobArgs &a, const int *first, const int *cnt, hipStream_t s)
 {
-	const size_t lds = (size_t)(64 / G) * 22 * G * 2 + (size_t)(64 / G) * 32 * 4;
-	hipLaunchKernelGGL((k_glob<G>), dim3(n_waves), dim3(64), lds, s, a);
+	const size_t lds = (size_t)22 * 64 * 2 + (size_t)4 * 32 * 4;
+	NarrowMap m{};
+	const int cls[4] = { 0, 1, 2, 7 };
+	int total = 0;
+	for (int k = 0; k < 4; ++k) m.first[k] = first[cls[k]], m.cnt[k] = cnt[cls[k]], total += cnt[cls[k]];
+	hipLaunchKernelGGL(k_glob_narrow, dim3((unsigned)total), dim3(64), lds, s, a, m);
 	return hipGetLastError();
 }
 
@@ -454,13 +460,20 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	ExtWideArgs wa;
 	wa.tasks = ea.tasks, wa.rec = ea.rec, wa.prof = ea.prof, wa.out = ea.out, wa.c = dc, wa.pen = pen, wa.key_stride = key_stride;
 	int64_t wide_groups_done = 0;
-	for (int cls = kNumExtClasses - 1; cls >= 0; --cls) {               // widest classes first
+	for (int cls = kNumExtClasses - 1; cls >= 3; --cls) {               // widest classes first
 		if (ewave_cnt[cls] == 0) continue;
-		ea.waves = wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
+		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
 		wa.rowkey = ctx->rowkey.as<uint32_t>() + wide_groups_done * 2 * key_stride;
-		if (cls >= 3) wide_groups_done += ewave_cnt[cls];
+		wide_groups_done += ewave_cnt[cls];
 		hipStream_t st = begin_side(true);
-		HIP_TRY(launch_ext_class(cls, ea, wa, ewave_cnt[cls], st));
+		HIP_TRY(launch_ext_wide_class(cls, wa, ewave_cnt[cls], st));
+		end_side();
+		ctx->stats.launches_ext++;
+	}
+	if (ewave_cnt[0] + ewave_cnt[1] + ewave_cnt[2] > 0) {               // the narrow classes share one launch
+		ea.waves = ctx->waves.as<ExtWave>();
+		hipStream_t st = begin_side(true);
+		HIP_TRY(launch_ext_narrow(ea, ewave_first.data(), ewave_cnt.data(), st));
 		end_side();
 		ctx->stats.launches_ext++;
 	}
@@ -505,12 +518,11 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		GlobArgs ga;
 		ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
 		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc;
+		// classes 0,1,2,7 share one launch ("narrow"); every wide class has its own
 		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
+			if (cls < 0) { ga.waves = d_gw; return launch_glob_narrow(ga, first, cnt, st); }
 			ga.waves = d_gw + first[cls];
 			switch (cls) {
-			case 0: return launch_glob<16>(ga, cnt[cls], st);
-			case 1: return launch_glob<32>(ga, cnt[cls], st);
-			case 2: case 7: return launch_glob<64>(ga, cnt[cls], st);
 			case 3: return launch_glob_wide<2>(ga, cnt[cls], st);
 			case 4: return launch_glob_wide<4>(ga, cnt[cls], st);
 			case 5: return launch_glob_wide<8>(ga, cnt[cls], st);
@@ -518,11 +530,13 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 			}
 		};
 		HIP_TRY(hipEventRecord(ctx->ev[3], s));
-		// every class on its own stream (next to the extension classes in the first round); the walk needs them all
+		// every launch on its own stream (next to the extension classes in the first round); the walk needs them all
 		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
 		const size_t first_glob_launch = launches.size();
-		for (int cls = kNumGlobClasses - 1; cls >= 0; --cls) {
-			if (!cnt[cls]) continue;
+		const int order[5] = { 6, 5, 4, 3, -1 };
+		for (int oi = 0; oi < 5; ++oi) {
+			const int cls = order[oi];
+			if (cls >= 0 ? !cnt[cls] : !(cnt[0] + cnt[1] + cnt[2] + cnt[7])) continue;
 			if (n_side >= mpa_ctx_s::kSide) {                                // out of side streams: run on the main stream
 				HIP_TRY(launch_glob_class(cls, s));
 			} else {

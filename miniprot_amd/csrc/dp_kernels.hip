@@ -269,7 +269,7 @@ struct ExtArgs {
 #define PROF_COL_STRIDE 184                    /* bytes per column: 23 * 8, an odd number of 8-byte words    */
 
 template<int G>
-__global__ __launch_bounds__(64) void k_ext(ExtArgs a)
+__device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 {
 	constexpr int NG = 64 / G;               // lane groups per wave
 	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
@@ -279,7 +279,6 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 	int32_t *lds_pen = (int32_t*)(lds_ring + NG * 32);                 // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
 
 	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
-	const ExtWave *wvp = &a.waves[blockIdx.x];
 	const DpConst c = a.c;
 	const uint32_t *recbase = a.rec + wvp->rec_base;
 	const int32_t max_nl = wvp->max_nl;
@@ -491,6 +490,21 @@ __global__ __launch_bounds__(64) void k_ext(ExtArgs a)
 			a.out[tid[h]] = o;
 		}
 	}
+}
+
+// One launch for the three narrow shapes (16 / 32 / 64 lanes per call): wave b of the launch belongs to the class whose
+// range of wave descriptors contains it.  Fewer, larger launches matter because every concurrently running kernel
+// occupies a hardware queue and a stream of batches keeps several rounds in flight (dp_exec.hip).
+struct NarrowMap { int32_t first[4], cnt[4]; };
+
+__global__ __launch_bounds__(64) void k_ext_narrow(ExtArgs a, NarrowMap m)
+{
+	int b = blockIdx.x;
+	if (b < m.cnt[0]) { ext_narrow<16>(a, a.waves + m.first[0] + b); return; }
+	b -= m.cnt[0];
+	if (b < m.cnt[1]) { ext_narrow<32>(a, a.waves + m.first[1] + b); return; }
+	b -= m.cnt[1];
+	ext_narrow<64>(a, a.waves + m.first[2] + b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -723,13 +737,12 @@ struct GlobArgs {
 #define SEG_BIG (1 << 20)
 
 template<int G>
-__global__ __launch_bounds__(64) void k_glob(GlobArgs a)
+__device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv)
 {
 	constexpr int NG = 64 / G;
 	extern __shared__ uint32_t lds_raw[];
 	int16_t *lds_prof = (int16_t*)lds_raw;           // [NG][22][G] for the current column block
 	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
-	const GlobWave wv = a.waves[blockIdx.x];
 	const DpConst c = a.c;
 	const int32_t tid = wv.task[grp];
 	DTask t;
@@ -855,6 +868,19 @@ __global__ __launch_bounds__(64) void k_glob(GlobArgs a)
 		}
 	}
 	if (tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
+}
+
+// one launch for the narrow traceback shapes (classes 16 / 32 / 64 lanes and the block-major one), see k_ext_narrow
+__global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
+{
+	int b = blockIdx.x;
+	if (b < m.cnt[0]) { glob_narrow<16>(a, a.waves[m.first[0] + b]); return; }
+	b -= m.cnt[0];
+	if (b < m.cnt[1]) { glob_narrow<32>(a, a.waves[m.first[1] + b]); return; }
+	b -= m.cnt[1];
+	if (b < m.cnt[2]) { glob_narrow<64>(a, a.waves[m.first[2] + b]); return; }
+	b -= m.cnt[2];
+	glob_narrow<64>(a, a.waves[m.first[3] + b]);
 }
 
 // ------------------------------------------------------------------------------------------------
