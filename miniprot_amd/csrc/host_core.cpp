@@ -40,6 +40,38 @@ void sort_u64(uint64_t *beg, uint64_t *end)
 	if (src != beg) memcpy(beg, src, n * sizeof(uint64_t));
 }
 
+// Anchors (block<<32 | query position) gathered seed by seed in ascending query position: a STABLE sort on the block
+// bits alone yields the full-key order (map.c:178 sorts the whole 64-bit word).  Two or three counting passes over the
+// significant block bits instead of one per 11 bits of the whole word.
+void sort_anchors_by_block(std::vector<uint64_t> &a)
+{
+	const size_t n = a.size();
+	if (n < 2) return;
+	if (n <= 256) { std::sort(a.begin(), a.end()); return; }
+	uint64_t all_or = 0;
+	for (size_t i = 0; i < n; ++i) all_or |= a[i] >> 32;
+	int bits = 0;
+	while (bits < 32 && (all_or >> bits) != 0) ++bits;
+	if (bits == 0) return;
+	const int n_pass = bits <= 13 ? 1 : bits <= 26 ? 2 : 3, width = (bits + n_pass - 1) / n_pass;
+	static thread_local std::vector<uint64_t> tmp;
+	static thread_local std::vector<uint32_t> cnt;
+	if (tmp.size() < n) tmp.resize(n);
+	cnt.resize((size_t)1 << width);
+	uint64_t *src = a.data(), *dst = tmp.data();
+	const uint32_t mask = (1u << width) - 1;
+	for (int pass = 0; pass < n_pass; ++pass) {
+		const int shift = 32 + pass * width;
+		std::fill(cnt.begin(), cnt.end(), 0u);
+		for (size_t i = 0; i < n; ++i) ++cnt[(src[i] >> shift) & mask];
+		uint32_t acc = 0;
+		for (size_t d = 0; d < cnt.size(); ++d) { const uint32_t c = cnt[d]; cnt[d] = acc, acc += c; }
+		for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & mask]++] = src[i];
+		std::swap(src, dst);
+	}
+	if (src != a.data()) memcpy(a.data(), src, n * sizeof(uint64_t));
+}
+
 // Sort of (x,y) pairs by x whose treatment of EQUAL x must match the reference's in-place MSD radix sort
 // (it is unstable, and chain extraction / region order / extension limits consume the resulting order).
 // Runs of <= 64 elements use a stable insertion sort; longer runs are permuted digit by digit with the

@@ -14,6 +14,7 @@ struct Pair64 { uint64_t x, y; };     // mp128_t (miniprot.h:32)
 
 // ---- sorting (ksort.h:109-162 semantics) ---------------------------------------------------------
 void sort_u64(uint64_t *beg, uint64_t *end);          // radix_sort_mp64: ties are identical values
+void sort_anchors_by_block(std::vector<uint64_t> &a);  // a[] ascending in its low word: stable sort on the high word
 void sort_pairs_by_x(Pair64 *beg, Pair64 *end);        // radix_sort_mp128x: tie order is algorithm-defined
 
 // ---- sketching (sketch.c) ---------------------------------------------------------------------------

@@ -448,20 +448,24 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 		sort_u64(sd.data(), sd.data() + sd.size());
 		int32_t max_occ = opt.max_occ;
 		if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
-		// anchors: every occurrence of every seed that is not too frequent (map.c:163-177)
+		// anchors: every occurrence of every seed that is not too frequent (map.c:163-177), gathered in ascending query
+		// position so that the sort only has to look at the block ids
+		static thread_local std::vector<uint64_t> kept;          // query position << 32 | index bucket
+		kept.clear();
 		size_t n_a = 0;
 		for (uint64_t s : sd) {
 			const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-			if (en - st <= max_occ) n_a += (size_t)(en - st);
+			if (en - st <= max_occ && en > st) n_a += (size_t)(en - st), kept.push_back((uint64_t)(uint32_t)s << 32 | (uint64_t)bkt);
 		}
+		std::sort(kept.begin(), kept.end());
 		a.reserve(n_a);
-		for (uint64_t s : sd) {
-			const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-			if (en - st > max_occ) continue;
-			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | (uint32_t)s);
+		for (uint64_t kq : kept) {
+			const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+			const uint64_t qpos = kq >> 32;
+			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | qpos);
 		}
 	}
-	{ AccTimer tm(1); sort_u64(a.data(), a.data() + a.size()); }
+	{ AccTimer tm(1); sort_anchors_by_block(a); }
 	if (!(opt.flag & MPA_MF_NO_PRE_CHAIN) && is_splice) {         // keep anchors that have a neighbour within one block
 		AccTimer tm(2);
 		const int32_t w = 1 << mi->opt.bbit;
