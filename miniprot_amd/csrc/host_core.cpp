@@ -339,6 +339,66 @@ static inline int32_t link_score(uint64_t cur, uint64_t prev, const ChainParams 
 	return sc;
 }
 
+// The chain ends in the order the reference's sort leaves them -- for the common case that almost every anchor is a
+// chain of one.  With min_cnt > 1 such "root" anchors (no predecessor, score == kmer, the smallest key) never yield a
+// chain, so only the order of the OTHER ends matters; but that order is a product of the in-place MSD radix sort
+// (pairs_digit_pass) run over the whole array, roots included.  With all scores below 256 that sort is a single digit
+// pass, and its effect on the non-roots can be replayed without the roots: bucket `kmer` is the first region
+// [0, n_root); walking it only ever moves the non-roots found there (in ascending position) into the heads of their
+// buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
+// Returns false if the preconditions do not hold (the caller then builds and sorts the full list).
+static bool sorted_chain_ends_sparse(const ChainParams &p, int64_t n, const std::vector<int32_t> &f, const std::vector<int64_t> &pred,
+                                     std::vector<Pair64> &tail)
+{
+	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return false;
+	size_t cnt[256];
+	memset(cnt, 0, sizeof(cnt));
+	int64_t m = 0;
+	for (int64_t i = 0; i < n; ++i)
+		if (pred[i] >= 0) {
+			if (f[i] > 255 || f[i] <= p.kmer) return false;   // (f > kmer always holds for a chained anchor; belt and braces)
+			++cnt[f[i]], ++m;
+		}
+	const int64_t n_root = n - m;
+	tail.resize((size_t)m);
+	if (m == 0) return true;
+	// the slots [n_root, n) as they are before the sort
+	for (int64_t q = n_root; q < n; ++q) tail[(size_t)(q - n_root)] = Pair64{ (uint64_t)(int64_t)f[q], (uint64_t)q };
+	size_t cursor[256], limit[256];
+	{
+		size_t at = 0;
+		for (int d = 0; d < 256; ++d) cursor[d] = at, at += cnt[d], limit[d] = at;
+	}
+	const int k0 = p.kmer;
+	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
+	for (int64_t i = 0; i < n_root; ++i) {
+		if (pred[i] < 0) continue;
+		Pair64 carried{ (uint64_t)(int64_t)f[i], (uint64_t)i };
+		int d = (int)(carried.x & 0xff);
+		do {
+			const Pair64 placed = carried;
+			carried = tail[cursor[d]];
+			tail[cursor[d]++] = placed;
+			d = (int)(carried.x & 0xff);
+		} while (d != k0);
+	}
+	// the remaining buckets, entirely inside the tail (same walk as pairs_digit_pass)
+	for (int k = k0 + 1; k < 256;) {
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(tail[cursor[k]].x & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = tail[cursor[k]];
+		do {
+			const Pair64 placed = carried;
+			carried = tail[cursor[d]];
+			tail[cursor[d]++] = placed;
+			d = (int)(carried.x & 0xff);
+		} while (d != k);
+		tail[cursor[k]++] = carried;
+	}
+	return true;
+}
+
 void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
 {
 	u.clear();
@@ -386,10 +446,12 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 
 	// ---- extraction, best chain end first (chain.c:8-75)
 	ends.clear();
-	for (int64_t i = 0; i < n; ++i)
-		if (f[i] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[i], (uint64_t)i });
+	if (!sorted_chain_ends_sparse(p, n, f, pred, ends)) {
+		for (int64_t i = 0; i < n; ++i)
+			if (f[i] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[i], (uint64_t)i });
+		sort_pairs_by_x(ends.data(), ends.data() + ends.size());
+	}
 	if (ends.empty()) { a.clear(); return; }
-	sort_pairs_by_x(ends.data(), ends.data() + ends.size());
 	std::fill(mark.begin(), mark.end(), 0);
 	order.clear();                                     // anchor indices of the kept chains, each chain from its END backwards
 	for (int64_t k = (int64_t)ends.size() - 1; k >= 0; --k) {
@@ -449,3 +511,31 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 }
 
 } // namespace mpa
+
+// Test hooks (not part of include/mpamd.h): the host stages with reference-defined tie behaviour, callable on raw arrays so
+// that tests/ can fuzz them against the oracle.  Same argument order as mp_chain (chain.c:160).
+extern "C" int32_t mpa_dbg_chain(int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t max_skip, int32_t max_iter, int32_t min_cnt,
+                                 int32_t min_sc, float coef_log, int32_t is_spliced, int32_t kmer, int32_t bbit,
+                                 int64_t n, uint64_t *a, uint64_t *u, int64_t *n_out)
+{
+	mpa::ChainParams p{ max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc, coef_log, is_spliced, kmer, bbit };
+	std::vector<uint64_t> av(a, a + n), uv;
+	mpa::chain_anchors(p, av, uv);
+	memcpy(a, av.data(), av.size() * 8);
+	memcpy(u, uv.data(), uv.size() * 8);
+	*n_out = (int64_t)av.size();
+	return (int32_t)uv.size();
+}
+
+extern "C" void mpa_dbg_sort_pairs(uint64_t *beg, uint64_t *end)
+{
+	mpa::sort_pairs_by_x((mpa::Pair64*)beg, (mpa::Pair64*)end);
+}
+
+extern "C" void mpa_dbg_sort_anchors(uint64_t *a, int64_t n)
+{
+	std::vector<uint64_t> v(a, a + n);
+	mpa::sort_anchors_by_block(v);
+	memcpy(a, v.data(), (size_t)n * 8);
+}
+
