@@ -237,28 +237,35 @@ void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32
 	hits.clear(), a.clear();
 	// One pass over the window, three interleaved reading frames.  `filter` is indexed by the packed k-mer word (the hash
 	// is a bijection of it, so it is only evaluated for the rare hits).  A frame's hits are provisional until its open
-	// reading frame turns out to be at least min_aa_len codons long.
-	const uint8_t *codon_tab = tab_codon(), *c13 = tab_codon13();
+	// reading frame turns out to be at least min_aa_len codons long.  The loop is unrolled by three so that the state of
+	// each frame (k-mer word, ORF length) lives in registers.
+	uint8_t tab[64];                                    // codon -> reduced residue, 0xff for a stop
+	{
+		const uint8_t *codon_tab = tab_codon(), *c13 = tab_codon13();
+		for (int c = 0; c < 64; ++c) tab[c] = codon_tab[c] >= 20 ? 0xff : c13[c];
+	}
 	const uint32_t mask = (1U << kmer * 4) - 1;
 	uint32_t word[3] = { 0, 0, 0 }, codon = 0;
 	int32_t orf_len[3] = { 0, 0, 0 }, valid = 0;
-	size_t mark[3] = { 0, 0, 0 };                      // hits[] holds committed hits; provisional ones live in pend[f]
 	static thread_local std::vector<uint64_t> pend[3];
 	for (int f = 0; f < 3; ++f) pend[f].clear();
-	(void)mark;
 	auto close = [&](int f) {
-		if (orf_len[f] >= min_aa_len) hits.insert(hits.end(), pend[f].begin(), pend[f].end());
-		pend[f].clear(), orf_len[f] = 0, word[f] = 0;
+		if (!pend[f].empty()) {
+			if (orf_len[f] >= min_aa_len) hits.insert(hits.end(), pend[f].begin(), pend[f].end());
+			pend[f].clear();
+		}
+		orf_len[f] = 0, word[f] = 0;
 	};
-	int f = 1;                                         // phase label of the codon ending at i: (i + 1) % 3
-	for (int64_t i = 0; i < len; ++i, f = f == 2 ? 0 : f + 1) {
+	// f = phase label of the codon ending at base i: (i + 1) % 3
+	auto step = [&](int64_t i, const int f) __attribute__((always_inline)) {
 		const uint32_t b = nt[i];
-		if (b < 4) {
+		if (__builtin_expect(b < 4, 1)) {
 			codon = (codon << 2 | b) & 0x3f;
 			if (++valid >= 3) {
-				if (codon_tab[codon] >= 20) close(f);
+				const uint32_t t = tab[codon];
+				if (t == 0xff) close(f);
 				else {
-					const uint32_t w = word[f] = (word[f] << 4 | c13[codon]) & mask;
+					const uint32_t w = word[f] = (word[f] << 4 | t) & mask;
 					if (++orf_len[f] >= kmer && (filter[w >> 6] >> (w & 63) & 1))
 						pend[f].push_back((uint64_t)hash32_mask(w, mask) << 32 | (uint64_t)i);
 				}
@@ -267,7 +274,11 @@ void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32
 			close(0), close(1), close(2);
 			valid = 0, codon = 0;
 		}
-	}
+	};
+	int64_t i = 0;
+	for (; i + 3 <= len; i += 3) step(i, 1), step(i + 1, 2), step(i + 2, 0);
+	if (i < len) step(i, 1), ++i;
+	if (i < len) step(i, 2), ++i;
 	close(0), close(1), close(2);
 	if (hits.empty()) return;
 	sort_u64(hits.data(), hits.data() + hits.size());

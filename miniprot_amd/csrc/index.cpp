@@ -53,14 +53,32 @@ int64_t fetch_nt(const mpa_idx_s *mi, int32_t vid, int64_t st, int64_t en, uint8
 	const Contig &c = mi->ctg[cid];
 	if (st < 0 || en < 0 || st >= c.len) return -1;
 	if (en > c.len) en = c.len;
+	// two bases per packed byte through a 256-entry table (forward: low nibble first; reverse strand: complemented,
+	// high nibble first); a nibble above 3 is an ambiguous base and stays what it is
+	static const struct Tab {
+		uint16_t fwd[256], rev[256];
+		Tab() {
+			for (int b = 0; b < 256; ++b) {
+				const uint8_t lo = b & 0xf, hi = b >> 4;
+				const uint8_t clo = lo >= 4 ? lo : 3 - lo, chi = hi >= 4 ? hi : 3 - hi;
+				fwd[b] = (uint16_t)(lo | hi << 8), rev[b] = (uint16_t)(chi | clo << 8);
+			}
+		}
+	} tab;
 	int64_t k = 0;
 	if (!(vid & 1)) {
-		for (int64_t p = c.off + st; p < c.off + en; ++p) out[k++] = nt_at(mi, p);
+		int64_t p = c.off + st;
+		const int64_t pe = c.off + en;
+		if (p < pe && (p & 1)) out[k++] = nt_at(mi, p++);
+		for (; p + 2 <= pe; p += 2, k += 2) memcpy(out + k, &tab.fwd[mi->seq[p >> 1]], 2);
+		if (p < pe) out[k++] = nt_at(mi, p);
 	} else {                                          // reverse strand: walk the forward strand backwards, complement
-		for (int64_t p = c.off + c.len - 1 - st; p >= c.off + c.len - en; --p) {
-			uint8_t b = nt_at(mi, p);
-			out[k++] = b >= 4 ? b : (uint8_t)(3 - b);
-		}
+		int64_t p = c.off + c.len - 1 - st;           // first base to emit, going down to pe (inclusive)
+		const int64_t pe = c.off + c.len - en;
+		auto one = [&](int64_t q) { const uint8_t b = nt_at(mi, q); out[k++] = b >= 4 ? b : (uint8_t)(3 - b); };
+		if (p >= pe && !(p & 1)) one(p--);            // p even: its byte's high nibble belongs to p+1, emit alone
+		for (; p - 1 >= pe; p -= 2, k += 2) memcpy(out + k, &tab.rev[mi->seq[p >> 1]], 2);   // p odd: byte holds (p-1, p)
+		if (p >= pe) one(p);
 	}
 	return k;
 }
