@@ -149,9 +149,9 @@ template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 // ------------------------------------------------------------------------------------------------
 
 // per-substage wall-clock accumulators of stage A (summed over threads; printed with MPA_TIMING=1)
-static std::atomic<int64_t> g_acc[14];
-static const char *const kAccName[14] = { "A.sketch+lookup", "A.sort anchors", "A.pre-chain", "A.chain", "A.regions", "A.refine", "A.plan", "A.round-1 plan",
-	"  refine: fetch window", "  refine: sketch nt4", "  refine: sketch prot+sort", "  refine: pairs+sort", "  refine: chain", "  refine: n regions" };
+static std::atomic<int64_t> g_acc[16];
+static const char *const kAccName[16] = { "A.sketch+lookup", "A.sort anchors", "A.pre-chain", "A.chain", "A.regions", "A.refine", "A.plan", "A.round-1 plan",
+	"  refine: fetch window", "  refine: sketch nt4", "  refine: sketch prot+sort", "  refine: pairs+sort", "  refine: chain", "  refine: n regions", "  anchors (x1000, all queries / threads)", "  pre-chain survivors (x1000)" };
 struct AccTimer { int k; double t0; AccTimer(int k_) : k(k_), t0(now_ms()) {} ~AccTimer() { g_acc[k] += (int64_t)((now_ms() - t0) * 1e6); } };
 
 // mp_cal_max_occ (map.c:126-141): boxplot-style cutoff on the occurrence counts of the query's seeds
@@ -465,6 +465,7 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | qpos);
 		}
 	}
+	g_acc[14] += (int64_t)a.size() * 1000;
 	{ AccTimer tm(1); sort_anchors_by_block(a); }
 	if (!(opt.flag & MPA_MF_NO_PRE_CHAIN) && is_splice) {         // keep anchors that have a neighbour within one block
 		AccTimer tm(2);
@@ -472,6 +473,7 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 		ChainParams pre{ w, w, w, opt.max_chn_max_skip, opt.max_chn_iter, 2, 0, opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
 		chain_anchors(pre, a, u);
 		sort_u64(a.data(), a.data() + a.size());
+		g_acc[15] += (int64_t)a.size() * 1000;
 	}
 	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
 	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
@@ -705,7 +707,7 @@ mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const
 	double t0 = now_ms();
 	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); AccTimer tm(7); plan_round1(b, b->qs[i]); });
 	timing_note("stage A (seed..plan)", now_ms() - t0);
-	if (timing_on()) for (int k = 0; k < 14; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
+	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
 	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
 	return b;
 }
