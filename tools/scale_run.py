@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4000, help="proteins per mini-batch")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("-I", dest="set_I", action="store_true")
+    ap.add_argument("-G", dest="set_G", type=int, default=0, help="max intron size (miniprot -G: max_intron = bw = G)")
+    ap.add_argument("--min-exons", type=int, default=1)
+    ap.add_argument("--imin", type=int, default=70)
     ap.add_argument("--n-frac", type=float, default=0.0)
     ap.add_argument("--mu", type=float, default=7.5)
     ap.add_argument("--sigma", type=float, default=1.5)
@@ -43,7 +46,7 @@ def main():
     ncpu = os.cpu_count() or 1
     thr = a.threads or max(1, min(128, ncpu))
     t0 = time.time()
-    contigs, prots, names = gen_synth.generate(int(a.genome_mb * 1e6), a.n_ctg, a.n_prot, a.seed, mu=a.mu, sigma=a.sigma, imax=a.imax, n_frac=a.n_frac)
+    contigs, prots, names = gen_synth.generate(int(a.genome_mb * 1e6), a.n_ctg, a.n_prot, a.seed, mu=a.mu, sigma=a.sigma, imin=a.imin, imax=a.imax, n_frac=a.n_frac, min_exons=a.min_exons)
     t1 = time.time()
     idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(a.n_ctg)])
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, max(8, thr)))
@@ -51,6 +54,8 @@ def main():
     mo = mpa.default_mapopt(); mo.flag |= 4
     if a.set_I:
         mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+    if a.set_G:
+        mo.max_intron = mo.bw = a.set_G
     print("generate %.1fs, index build %.1fs (%d threads), genome %d bp, max_intron %d" % (t1 - t0, t2 - t1, thr, idx.genome_len(), mo.max_intron), file=sys.stderr)
     batches = [mpa.Queries(prots[i:i + a.batch], names[i:i + a.batch]) for i in range(0, len(prots), a.batch)]
     ours = None
@@ -77,7 +82,7 @@ def main():
                 f.write(">%s\n%s\n" % (n, s if isinstance(s, str) else s.decode()))
         open(os.path.join(a.tmp, "empty.faa"), "w").close()
         exe = os.path.join(ROOT, "oracle", "_ref", "miniprot")
-        flags = ["-u"] + (["-I"] if a.set_I else [])
+        flags = ["-u"] + (["-I"] if a.set_I else []) + (["-G", str(a.set_G)] if a.set_G else [])
         def run(q):
             t = time.time()
             out = subprocess.run([exe, "-t%d" % ncpu] + flags + [mpi, q], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
