@@ -357,24 +357,32 @@ static inline int32_t link_score(uint64_t cur, uint64_t prev, const ChainParams 
 // pass, and its effect on the non-roots can be replayed without the roots: bucket `kmer` is the first region
 // [0, n_root); walking it only ever moves the non-roots found there (in ascending position) into the heads of their
 // buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
+// The view may therefore leave out anchors that are alone in their neighbourhood (v.pos != nullptr).
 // Returns false if the preconditions do not hold (the caller then builds and sorts the full list).
-static bool sorted_chain_ends_sparse(const ChainParams &p, int64_t n, const std::vector<int32_t> &f, const std::vector<int64_t> &pred,
-                                     std::vector<Pair64> &tail)
+static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, std::vector<Pair64> &tail)
 {
+	const int64_t n = v.n_total;
 	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return false;
 	size_t cnt[256];
 	memset(cnt, 0, sizeof(cnt));
 	int64_t m = 0;
-	for (int64_t i = 0; i < n; ++i)
-		if (pred[i] >= 0) {
-			if (f[i] > 255 || f[i] <= p.kmer) return false;   // (f > kmer always holds for a chained anchor; belt and braces)
-			++cnt[f[i]], ++m;
+	for (int64_t i = 0; i < v.m; ++i)
+		if (v.pred[i] >= 0) {
+			if (v.f[i] > 255 || v.f[i] <= p.kmer) return false;   // (f > kmer always holds for a chained anchor; belt and braces)
+			++cnt[v.f[i]], ++m;
 		}
 	const int64_t n_root = n - m;
-	tail.resize((size_t)m);
+	const Pair64 some_root{ (uint64_t)p.kmer, ~0ULL };
+	tail.assign((size_t)m, some_root);
 	if (m == 0) return true;
-	// the slots [n_root, n) as they are before the sort
-	for (int64_t q = n_root; q < n; ++q) tail[(size_t)(q - n_root)] = Pair64{ (uint64_t)(int64_t)f[q], (uint64_t)q };
+	// the slots [n_root, n) as they are before the sort; view entry i sits at position pos[i] (dense view: i)
+	int64_t first_tail = v.m;                          // first view entry at or behind n_root
+	if (!v.pos) first_tail = std::min<int64_t>(n_root, v.m);
+	else first_tail = std::lower_bound(v.pos, v.pos + v.m, (int32_t)std::min<int64_t>(n_root, INT32_MAX)) - v.pos;
+	for (int64_t i = first_tail; i < v.m; ++i) {
+		const int64_t q = v.pos ? v.pos[i] : i;
+		tail[(size_t)(q - n_root)] = Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i };
+	}
 	size_t cursor[256], limit[256];
 	{
 		size_t at = 0;
@@ -382,9 +390,9 @@ static bool sorted_chain_ends_sparse(const ChainParams &p, int64_t n, const std:
 	}
 	const int k0 = p.kmer;
 	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
-	for (int64_t i = 0; i < n_root; ++i) {
-		if (pred[i] < 0) continue;
-		Pair64 carried{ (uint64_t)(int64_t)f[i], (uint64_t)i };
+	for (int64_t i = 0; i < first_tail; ++i) {
+		if (v.pred[i] < 0) continue;
+		Pair64 carried{ (uint64_t)(int64_t)v.f[i], (uint64_t)i };
 		int d = (int)(carried.x & 0xff);
 		do {
 			const Pair64 placed = carried;
@@ -410,62 +418,34 @@ static bool sorted_chain_ends_sparse(const ChainParams &p, int64_t n, const std:
 	return true;
 }
 
-void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
+// chain.c:8-110 on the result of the forward pass: extraction (best chain end first), then the kept chains laid out in
+// ascending anchor order and sorted by their first target position.
+void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u)
 {
 	u.clear();
-	const int64_t n = (int64_t)a.size();
-	if (n == 0) return;
-	int32_t max_dist_x = std::max(p.max_dist_x, p.bw), max_dist_y = p.max_dist_y;
-	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
 	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
-
-	// per-thread scratch, reused across calls: with hundreds of workers, fresh multi-hundred-KB vectors per call turn
-	// into mmap/munmap traffic on the shared address space
-	static thread_local std::vector<int32_t> f, mark, order;
-	static thread_local std::vector<int64_t> pred;
+	const int32_t *f = v.f, *pred = v.pred;
+	static thread_local std::vector<int32_t> mark, order;
 	static thread_local std::vector<Pair64> ends, first;
 	static thread_local std::vector<uint64_t> packed, u_sorted;
-	f.resize(n), pred.resize(n), mark.assign(n, 0);
-
-	// ---- forward pass: best predecessor of every anchor (chain.c:181-209)
-	int64_t win = 0, hot = -1;         // start of the target-distance window; anchor with the best score so far
-	int32_t hot_f = 0;
-	for (int64_t i = 0; i < n; ++i) {
-		int64_t best_j = -1;
-		int32_t best = p.kmer, skipped = 0;
-		while (win < i && (int64_t)(((a[i] >> 32) - (a[win] >> 32)) << p.bbit) > max_dist_x) ++win;
-		if (hot >= 0 && hot >= win) {                   // always try the best anchor seen so far, whatever max_skip does below
-			int32_t sc = hot_f + link_score(a[i], a[hot], p, max_dist_x, max_dist_y);
-			if (sc > best) best = sc, best_j = hot;
-		} else hot_f = 0, hot = -1;
-		if (i - win > p.max_iter) win = i - p.max_iter;
-		for (int64_t j = i - 1; j >= win; --j) {
-			int32_t sc = link_score(a[i], a[j], p, max_dist_x, max_dist_y);
-			if (sc == kIncompatible) continue;
-			sc += f[j];
-			if (sc > best) {
-				best = sc, best_j = j;
-				if (skipped > 0) --skipped;
-			} else if (mark[j] == (int32_t)i) {         // j is already a predecessor of a better-placed anchor
-				if (++skipped > p.max_skip) break;
-			}
-			if (pred[j] >= 0) mark[pred[j]] = (int32_t)i;
-		}
-		f[i] = best, pred[i] = best_j;
-		if (hot_f < best) hot_f = best, hot = i;
-	}
-
-	// ---- extraction, best chain end first (chain.c:8-75)
+	const uint64_t kAbsent = ~0ULL;                     // an anchor the view leaves out (alone in its neighbourhood)
 	ends.clear();
-	if (!sorted_chain_ends_sparse(p, n, f, pred, ends)) {
-		for (int64_t i = 0; i < n; ++i)
-			if (f[i] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[i], (uint64_t)i });
+	if (!sorted_chain_ends_sparse(p, v, ends)) {
+		// the full list: absent anchors are roots (score kmer); they can only be left out when min_cnt rejects them anyway
+		int64_t vi = 0;
+		for (int64_t q = 0; q < v.n_total; ++q) {
+			if (vi < v.m && (v.pos ? v.pos[vi] : vi) == q) {
+				if (f[vi] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[vi], (uint64_t)vi });
+				++vi;
+			} else if (p.kmer >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)p.kmer, kAbsent });
+		}
 		sort_pairs_by_x(ends.data(), ends.data() + ends.size());
 	}
-	if (ends.empty()) { a.clear(); return; }
-	std::fill(mark.begin(), mark.end(), 0);
+	if (ends.empty()) { a_out.clear(); return; }
+	mark.assign((size_t)v.m, 0);
 	order.clear();                                     // anchor indices of the kept chains, each chain from its END backwards
 	for (int64_t k = (int64_t)ends.size() - 1; k >= 0; --k) {
+		if (ends[k].y == kAbsent) continue;
 		const int64_t tail = (int64_t)ends[k].y;
 		const int32_t tail_f = (int32_t)ends[k].x;
 		if (mark[tail] != 0) continue;
@@ -493,7 +473,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u.push_back((uint64_t)sc << 32 | (uint64_t)cnt);
 		else order.resize(before);                       // rejected chains keep their anchors claimed
 	}
-	if (u.empty()) { a.clear(); return; }
+	if (u.empty()) { a_out.clear(); return; }
 
 	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
 	packed.resize(order.size());
@@ -502,23 +482,69 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 		size_t k = 0;
 		for (size_t c = 0; c < u.size(); ++c) {
 			const size_t cnt = (uint32_t)u[c];
-			for (size_t j = 0; j < cnt; ++j) packed[k + j] = a[order[k + cnt - 1 - j]];
+			for (size_t j = 0; j < cnt; ++j) packed[k + j] = v.a[order[k + cnt - 1 - j]];
 			first[c] = Pair64{ packed[k] >> 32, (uint64_t)k << 32 | (uint64_t)c };
 			k += cnt;
 		}
 	}
 	sort_pairs_by_x(first.data(), first.data() + first.size());
 	u_sorted.resize(u.size());
-	a.resize(packed.size());
+	a_out.resize(packed.size());
 	size_t k = 0;
 	for (size_t c = 0; c < u.size(); ++c) {
 		const uint32_t which = (uint32_t)first[c].y;
 		const size_t cnt = (uint32_t)u[which], from = (size_t)(first[c].y >> 32);
 		u_sorted[c] = u[which];
-		memcpy(&a[k], &packed[from], cnt * sizeof(uint64_t));
+		memcpy(&a_out[k], &packed[from], cnt * sizeof(uint64_t));
 		k += cnt;
 	}
 	u.assign(u_sorted.begin(), u_sorted.end());
+}
+
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
+{
+	u.clear();
+	const int64_t n = (int64_t)a.size();
+	if (n == 0) return;
+	int32_t max_dist_x = std::max(p.max_dist_x, p.bw), max_dist_y = p.max_dist_y;
+	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
+
+	// per-thread scratch, reused across calls: with hundreds of workers, fresh multi-hundred-KB vectors per call turn
+	// into mmap/munmap traffic on the shared address space
+	static thread_local std::vector<int32_t> f, mark, pred;
+	static thread_local std::vector<uint64_t> a_in;
+	f.resize(n), pred.resize(n), mark.assign(n, 0);
+
+	// ---- forward pass: best predecessor of every anchor (chain.c:181-209)
+	int64_t win = 0, hot = -1;         // start of the target-distance window; anchor with the best score so far
+	int32_t hot_f = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (int64_t)(((a[i] >> 32) - (a[win] >> 32)) << p.bbit) > max_dist_x) ++win;
+		if (hot >= 0 && hot >= win) {                   // always try the best anchor seen so far, whatever max_skip does below
+			int32_t sc = hot_f + link_score(a[i], a[hot], p, max_dist_x, max_dist_y);
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		for (int64_t j = i - 1; j >= win; --j) {
+			int32_t sc = link_score(a[i], a[j], p, max_dist_x, max_dist_y);
+			if (sc == kIncompatible) continue;
+			sc += f[j];
+			if (sc > best) {
+				best = sc, best_j = j;
+				if (skipped > 0) --skipped;
+			} else if (mark[j] == (int32_t)i) {         // j is already a predecessor of a better-placed anchor
+				if (++skipped > p.max_skip) break;
+			}
+			if (pred[j] >= 0) mark[pred[j]] = (int32_t)i;
+		}
+		f[i] = best, pred[i] = (int32_t)best_j;
+		if (hot_f < best) hot_f = best, hot = i;
+	}
+	a_in.assign(a.begin(), a.end());
+	const ChainView v{ n, n, nullptr, f.data(), pred.data(), a_in.data() };
+	chain_extract(p, v, a, u);
 }
 
 } // namespace mpa

@@ -37,6 +37,17 @@ struct ChainParams {
 // a: sorted anchors, rewritten with the anchors of the kept chains (chain by chain, ascending);
 // u: one entry per chain, score<<32 | n_anchors
 void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u);
+// The state after the forward pass (chain.c:181-209) of a chaining problem with n_total anchors.  A dense view holds all of
+// them (pos == nullptr, m == n_total).  A sparse view (only valid when min_cnt > 1) may leave out anchors that have no
+// predecessor and are nobody's predecessor; pos[] are then the ascending positions of the m anchors it does hold.
+struct ChainView {
+	int64_t n_total, m;
+	const int32_t *pos;      // [m] or nullptr
+	const int32_t *f;        // [m] chain score ending at the anchor
+	const int32_t *pred;     // [m] view index of the predecessor, -1 for none
+	const uint64_t *a;       // [m] the anchors
+};
+void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u);
 
 // ---- regions (miniprot.h:119-145, hit.c) --------------------------------------------------------------
 struct Feat {
