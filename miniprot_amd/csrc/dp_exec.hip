@@ -10,13 +10,16 @@
 // roofline record).  There is no CPU fallback here by design.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
 #include <cstring>
 #include <cstdlib>
 #include <string>
 #include <vector>
 #include "mpa_internal.h"
+#include "host_core.h"
 #include "dp_device.h"
 #include "dp_kernels.hip"
+#include "seed_exec.hip"
 
 namespace mpa {
 
@@ -44,7 +47,29 @@ struct DeviceIndex {
 	int device = -1;
 	uint8_t *seq = nullptr;
 	int64_t *ctg_off = nullptr, *ctg_len = nullptr;
+	uint32_t *kb = nullptr;                   // k-mer occurrence lists (block ids), uploaded on first GPU seeding call
 };
+
+struct HostPinned {
+	void *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return MPA_OK;
+		if (p) (void)hipHostFree(p);
+		p = nullptr, cap = 0;
+		const size_t want = bytes + (bytes >> 2) + 4096;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return MPA_ERR_HIP; }
+		cap = want;
+		return MPA_OK;
+	}
+	template<typename T> T *as() { return (T*)p; }
+};
+
+struct SeedBufs {
+	DevBuf jobs, key[2], val[2], f, pred, mark, flag, idx, tmp, qfirst, cfirst, o_pos, o_f, o_pred, o_a;
+	HostPinned h_jobs, h_pos, h_f, h_pred, h_a;
+};
+
 
 } // namespace mpa
 
@@ -63,6 +88,7 @@ struct mpa_ctx_s {
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
 	std::vector<mpa_ctx_s*> siblings;         // extra contexts on the same device for concurrent sub-batches (owned)
+	SeedBufs seed;                            // buffers of the GPU seeding stage (seed_exec.hip)
 };
 
 namespace mpa {
@@ -92,6 +118,7 @@ void dev_free_index(mpa_idx_s *mi)
 	if (!mi->dev) return;
 	(void)hipSetDevice(mi->dev->device);
 	(void)hipFree(mi->dev->seq); (void)hipFree(mi->dev->ctg_off); (void)hipFree(mi->dev->ctg_len);
+	if (mi->dev->kb) (void)hipFree(mi->dev->kb);
 	delete mi->dev;
 	mi->dev = nullptr;
 }
@@ -261,6 +288,96 @@ void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 		t.launches_ext += u.launches_ext, t.launches_glob += u.launches_glob;
 		u = mpa_dp_stats_t();
 	}
+}
+} // namespace mpa
+
+namespace mpa {
+// GPU seeding for one mini-batch: anchors -> sort -> forward pass of the pre-chain -> the anchors that have a neighbour.
+// jobs: the kept seeds of all queries (qid ascending, within a query ascending query position, dst = running anchor
+// offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
+// (pred = position inside the query, -1 for none).
+int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out)
+{
+	const int64_t n = qfirst[n_query];
+	out.cfirst.assign((size_t)n_query + 1, 0);
+	out.pos = out.f = out.pred = nullptr, out.a = nullptr, out.m = 0;
+	if (n == 0 || n_jobs == 0) return MPA_OK;
+	if (pre.bbit <= 0) { set_error("GPU pre-chain needs block anchors (bbit > 0)"); return MPA_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
+	DeviceIndex *d = mi->dev;
+	if (!d->kb) {
+		static std::mutex mu;
+		std::lock_guard<std::mutex> g(mu);
+		if (!d->kb) {
+			uint32_t *p = nullptr;
+			HIP_TRY(hipMalloc((void**)&p, mi->kb.size() * 4 + 16));
+			HIP_TRY(hipMemcpy(p, mi->kb.data(), mi->kb.size() * 4, hipMemcpyHostToDevice));
+			d->kb = p;
+		}
+	}
+	PreParams pp;
+	pp.max_dist_x = std::max(pre.max_dist_x, pre.bw), pp.max_dist_y = pre.max_dist_y;
+	if (pp.max_dist_y < pre.bw && !pre.is_spliced) pp.max_dist_y = pre.bw;
+	pp.bw = pre.bw, pp.max_skip = pre.max_skip, pp.max_iter = pre.max_iter, pp.kmer = pre.kmer, pp.bbit = pre.bbit;
+	pp.is_spliced = pre.is_spliced, pp.coef_log = pre.coef_log, pp.max_dblock = pp.max_dist_x >> pre.bbit;
+	int nb = 1, qb = 1;
+	while ((1ULL << nb) < (uint64_t)mi->n_block + (uint64_t)pp.max_dblock + 2) ++nb;
+	while ((1LL << qb) < n_query) ++qb;
+	if (nb + qb > 64) { set_error("GPU pre-chain: too many queries x blocks for a 64-bit key"); return MPA_ERR_UNSUPPORTED; }
+	SeedBufs &B = ctx->seed;
+	hipStream_t s = ctx->stream;
+	// ---- upload the seed jobs
+	if (B.h_jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
+	SeedJobDev *hj = B.h_jobs.as<SeedJobDev>();
+	for (int64_t i = 0; i < n_jobs; ++i) hj[i] = SeedJobDev{ jobs[i].kb_off, jobs[i].dst, jobs[i].cnt, jobs[i].qpos, jobs[i].qid, 0 };
+	if (B.jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK || B.qfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK ||
+	    B.cfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK) return MPA_ERR_HIP;
+	for (int k = 0; k < 2; ++k) if (B.key[k].ensure((size_t)n * 8) != MPA_OK || B.val[k].ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
+	if (B.f.ensure((size_t)n * 4) != MPA_OK || B.pred.ensure((size_t)n * 4) != MPA_OK || B.mark.ensure((size_t)n * 4) != MPA_OK ||
+	    B.flag.ensure((size_t)n * 4) != MPA_OK || B.idx.ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(B.qfirst.p, qfirst, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
+	const unsigned nblk = (unsigned)((n + 255) / 256);
+	hipLaunchKernelGGL(k_seed_gather, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, B.key[0].as<uint64_t>(), B.val[0].as<uint32_t>());
+	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	HIP_TRY(hipGetLastError());
+	// ---- stable sort on (query, block): the anchors were gathered in ascending query position
+	size_t tmp_bytes = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val[0].as<uint32_t>(), B.val[1].as<uint32_t>(),
+	                                  (size_t)n, 0u, (unsigned)(nb + qb), s));
+	size_t scan_bytes = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+	if (B.tmp.ensure(std::max(tmp_bytes, scan_bytes) + 256) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(rocprim::radix_sort_pairs(B.tmp.p, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val[0].as<uint32_t>(), B.val[1].as<uint32_t>(),
+	                                  (size_t)n, 0u, (unsigned)(nb + qb), s));
+	const uint64_t *key = B.key[1].as<uint64_t>();
+	const uint32_t *val = B.val[1].as<uint32_t>();
+	hipLaunchKernelGGL(k_prechain_fwd, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
+	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.qfirst.as<int64_t>(), n_query, n, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
+	                   B.cfirst.as<int64_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const int64_t m = out.cfirst[n_query];
+	out.m = m;
+	if (m == 0) return MPA_OK;
+	if (B.o_pos.ensure((size_t)m * 4) != MPA_OK || B.o_f.ensure((size_t)m * 4) != MPA_OK || B.o_pred.ensure((size_t)m * 4) != MPA_OK || B.o_a.ensure((size_t)m * 8) != MPA_OK ||
+	    B.h_pos.ensure((size_t)m * 4) != MPA_OK || B.h_f.ensure((size_t)m * 4) != MPA_OK || B.h_pred.ensure((size_t)m * 4) != MPA_OK || B.h_a.ensure((size_t)m * 8) != MPA_OK) return MPA_ERR_HIP;
+	hipLaunchKernelGGL(k_seed_compact, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
+	                   B.pred.as<int32_t>(), B.o_pos.as<int32_t>(), B.o_f.as<int32_t>(), B.o_pred.as<int32_t>(), B.o_a.as<uint64_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(B.h_pos.p, B.o_pos.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
+	return MPA_OK;
 }
 } // namespace mpa
 

@@ -564,6 +564,65 @@ extern "C" int32_t mpa_dbg_chain(int32_t max_dist_x, int32_t max_dist_y, int32_t
 	return (int32_t)uv.size();
 }
 
+// The pre-chain through a SPARSE view built the way the GPU stage builds it (seed_exec.hip): forward pass, then only the
+// anchors of runs of >= 2 anchors whose consecutive blocks differ by at most one.  Lets the CPU tests cover
+// chain_extract()'s sparse branch.
+extern "C" int32_t mpa_dbg_prechain_sparse(int32_t bw, int32_t max_skip, int32_t max_iter, float coef_log, int32_t is_spliced, int32_t kmer, int32_t bbit,
+                                           int64_t n, uint64_t *a, uint64_t *u, int64_t *n_out)
+{
+	using namespace mpa;
+	ChainParams p{ bw, bw, bw, max_skip, max_iter, 2, 0, coef_log, is_spliced, kmer, bbit };
+	// dense forward pass (same loop as chain_anchors)
+	std::vector<int32_t> f(n), pred(n), mark(n, 0);
+	const int32_t max_dist_x = std::max(p.max_dist_x, p.bw);
+	int32_t max_dist_y = p.max_dist_y;
+	if (max_dist_y < p.bw && !p.is_spliced) max_dist_y = p.bw;
+	int64_t win = 0, hot = -1;
+	int32_t hot_f = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (int64_t)(((a[i] >> 32) - (a[win] >> 32)) << p.bbit) > max_dist_x) ++win;
+		if (hot >= 0 && hot >= win) {
+			int32_t sc = hot_f + link_score(a[i], a[hot], p, max_dist_x, max_dist_y);
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		for (int64_t j = i - 1; j >= win; --j) {
+			int32_t sc = link_score(a[i], a[j], p, max_dist_x, max_dist_y);
+			if (sc == kIncompatible) continue;
+			sc += f[j];
+			if (sc > best) { best = sc, best_j = j; if (skipped > 0) --skipped; }
+			else if (mark[j] == (int32_t)i) { if (++skipped > p.max_skip) break; }
+			if (pred[j] >= 0) mark[pred[j]] = (int32_t)i;
+		}
+		f[i] = best, pred[i] = (int32_t)best_j;
+		if (hot_f < best) hot_f = best, hot = i;
+	}
+	// sparse view: runs of >= 2
+	const uint64_t max_dblock = (uint64_t)(max_dist_x >> p.bbit);
+	std::vector<int32_t> vpos, vf, vpred;
+	std::vector<uint64_t> va;
+	for (int64_t s = 0; s < n;) {
+		int64_t e = s + 1;
+		while (e < n && (a[e] >> 32) - (a[e - 1] >> 32) <= max_dblock) ++e;
+		if (e - s >= 2)
+			for (int64_t i = s; i < e; ++i) {
+				const int32_t c = (int32_t)vpos.size();
+				vpos.push_back((int32_t)i), vf.push_back(f[i]), va.push_back(a[i]);
+				vpred.push_back(pred[i] < 0 ? -1 : c - (int32_t)(i - pred[i]));
+			}
+		s = e;
+	}
+	const ChainView v{ n, (int64_t)vpos.size(), vpos.data(), vf.data(), vpred.data(), va.data() };
+	std::vector<uint64_t> av, uv;
+	chain_extract(p, v, av, uv);
+	memcpy(a, av.data(), av.size() * 8);
+	memcpy(u, uv.data(), uv.size() * 8);
+	*n_out = (int64_t)av.size();
+	return (int32_t)uv.size();
+}
+
 extern "C" void mpa_dbg_sort_pairs(uint64_t *beg, uint64_t *end)
 {
 	mpa::sort_pairs_by_x((mpa::Pair64*)beg, (mpa::Pair64*)end);

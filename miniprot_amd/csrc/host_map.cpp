@@ -55,6 +55,8 @@ struct QueryState {
 	const char *seq = nullptr;
 	std::vector<Region> regs;
 	std::vector<AlignPlan> plans;
+	std::vector<uint64_t> seeds;         // kept seeds (query position << 32 | index bucket), ascending; only between the seeding sub-stages
+	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
 };
@@ -433,33 +435,46 @@ static void append_cigar(std::vector<uint32_t> &cig, uint32_t op, int32_t len)  
 	else cig.push_back((uint32_t)len << 4 | op);
 }
 
-// everything of mp_map() up to and including the alignment plans (map.c:143-226)
-static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
+// mp_map() in sub-stages.  (1) the query's seeds that are not too frequent (map.c:152-170)
+static void stage_seeds(mpa_batch_s *b, QueryState &qs)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
-	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
-	static thread_local std::vector<uint64_t> sd, a, u;     // per-worker scratch (see chain_anchors)
-	a.clear(), u.clear();
+	static thread_local std::vector<uint64_t> sd;
+	AccTimer tm(0);
+	sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
+	sort_u64(sd.data(), sd.data() + sd.size());
+	int32_t max_occ = opt.max_occ;
+	if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
+	// kept in ascending query position so that the anchor sort only has to look at the block ids
+	qs.seeds.clear(), qs.n_anchor = 0;
+	for (uint64_t s : sd) {
+		const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+		if (en - st <= max_occ && en > st) qs.n_anchor += en - st, qs.seeds.push_back((uint64_t)(uint32_t)s << 32 | (uint64_t)bkt);
+	}
+	std::sort(qs.seeds.begin(), qs.seeds.end());
+}
+
+static inline ChainParams prechain_params(const mpa_idx_s *mi, const mpa_mapopt_t &opt)
+{
+	const int32_t w = 1 << mi->opt.bbit;
+	return ChainParams{ w, w, w, opt.max_chn_max_skip, opt.max_chn_iter, 2, 0, opt.chn_coef_log, !(opt.flag & MPA_MF_NO_SPLICE), mi->opt.kmer, mi->opt.bbit };
+}
+static inline bool prechain_enabled(const mpa_mapopt_t &opt) { return !(opt.flag & MPA_MF_NO_PRE_CHAIN) && !(opt.flag & MPA_MF_NO_SPLICE); }
+
+// (2, host) anchors of the kept seeds (map.c:171-178), sorted; the pre-chain keeps those with a neighbour within one block
+static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
+{
+	const mpa_idx_s *mi = b->mi;
+	const mpa_mapopt_t &opt = b->opt;
+	const int64_t n_bucket = (int64_t)mi->ki.size();
+	static thread_local std::vector<uint64_t> u;
+	a.clear();
 	{
 		AccTimer tm(0);
-		sketch_protein(qs.seq, qs.qlen, mi->opt.kmer, mi->opt.mod_bit, sd);
-		sort_u64(sd.data(), sd.data() + sd.size());
-		int32_t max_occ = opt.max_occ;
-		if (sd.size() >= 8) max_occ = std::min(max_occ, occurrence_cutoff(mi, sd));
-		// anchors: every occurrence of every seed that is not too frequent (map.c:163-177), gathered in ascending query
-		// position so that the sort only has to look at the block ids
-		static thread_local std::vector<uint64_t> kept;          // query position << 32 | index bucket
-		kept.clear();
-		size_t n_a = 0;
-		for (uint64_t s : sd) {
-			const int64_t bkt = (int64_t)(s >> 32), st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-			if (en - st <= max_occ && en > st) n_a += (size_t)(en - st), kept.push_back((uint64_t)(uint32_t)s << 32 | (uint64_t)bkt);
-		}
-		std::sort(kept.begin(), kept.end());
-		a.reserve(n_a);
-		for (uint64_t kq : kept) {
+		a.reserve((size_t)qs.n_anchor);
+		for (uint64_t kq : qs.seeds) {
 			const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
 			const uint64_t qpos = kq >> 32;
 			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | qpos);
@@ -467,14 +482,41 @@ static void stage_seed_to_plan(mpa_batch_s *b, QueryState &qs)
 	}
 	g_acc[14] += (int64_t)a.size() * 1000;
 	{ AccTimer tm(1); sort_anchors_by_block(a); }
-	if (!(opt.flag & MPA_MF_NO_PRE_CHAIN) && is_splice) {         // keep anchors that have a neighbour within one block
+	if (prechain_enabled(opt)) {
 		AccTimer tm(2);
-		const int32_t w = 1 << mi->opt.bbit;
-		ChainParams pre{ w, w, w, opt.max_chn_max_skip, opt.max_chn_iter, 2, 0, opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
-		chain_anchors(pre, a, u);
+		chain_anchors(prechain_params(mi, opt), a, u);
 		sort_u64(a.data(), a.data() + a.size());
 		g_acc[15] += (int64_t)a.size() * 1000;
 	}
+}
+
+// (2, GPU) the same from the sparse result of dev_prechain_forward(): extraction only
+static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const PrechainSparse &ps, std::vector<uint64_t> &a)
+{
+	AccTimer tm(2);
+	static thread_local std::vector<int32_t> vpred;
+	static thread_local std::vector<uint64_t> u;
+	const int64_t c0 = ps.cfirst[qs.qid], m = ps.cfirst[qs.qid + 1] - c0;
+	a.clear();
+	g_acc[14] += qs.n_anchor * 1000;
+	if (m == 0) return;
+	vpred.resize((size_t)m);
+	const int32_t *pos = ps.pos + c0, *pp = ps.pred + c0;
+	for (int64_t c = 0; c < m; ++c) vpred[c] = pp[c] < 0 ? -1 : (int32_t)(c - (pos[c] - pp[c]));   // runs are contiguous in both numberings
+	const ChainView v{ qs.n_anchor, m, pos, ps.f + c0, vpred.data(), ps.a + c0 };
+	chain_extract(prechain_params(b->mi, b->opt), v, a, u);
+	sort_u64(a.data(), a.data() + a.size());
+	g_acc[15] += (int64_t)a.size() * 1000;
+}
+
+// (3) everything else up to and including the alignment plans (map.c:185-226)
+static void stage_chain_to_plan(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
+{
+	const mpa_idx_s *mi = b->mi;
+	const mpa_mapopt_t &opt = b->opt;
+	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
+	static thread_local std::vector<uint64_t> u;
+	u.clear();
 	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
 	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
 	{ AccTimer tm(3); chain_anchors(cp, a, u); }
@@ -694,7 +736,8 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+// seed_ctx != nullptr: anchors, their sort and the forward pass of the pre-chain run on that device context
+static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
 {
 	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
 	mpa_batch_s *b = new mpa_batch_s();
@@ -705,11 +748,62 @@ mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 	}
 	double t0 = now_ms();
-	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seed_to_plan(b, b->qs[i]); AccTimer tm(7); plan_round1(b, b->qs[i]); });
+	const bool on_device = seed_ctx && prechain_enabled(*opt) && mi->opt.bbit > 0 && q->n_seq > 0;
+	if (!on_device) {
+		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
+			static thread_local std::vector<uint64_t> a;
+			stage_seeds(b, b->qs[i]);
+			stage_anchors_host(b, b->qs[i], a);
+			stage_chain_to_plan(b, b->qs[i], a);
+			AccTimer tm(7);
+			plan_round1(b, b->qs[i]);
+		});
+	} else {
+		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seeds(b, b->qs[i]); });
+		const double t1 = now_ms();
+		std::vector<int64_t> qfirst((size_t)q->n_seq + 1, 0);
+		size_t n_jobs = 0;
+		for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, n_jobs += b->qs[i].seeds.size();
+		std::vector<SeedJob> jobs(n_jobs);
+		std::vector<size_t> jfirst((size_t)q->n_seq + 1, 0);
+		for (int32_t i = 0; i < q->n_seq; ++i) jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
+		const int64_t n_bucket = (int64_t)mi->ki.size();
+		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
+			int64_t dst = qfirst[i];
+			size_t j = jfirst[i];
+			for (uint64_t kq : b->qs[i].seeds) {
+				const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+				jobs[j++] = SeedJob{ st, dst, (int32_t)(en - st), (int32_t)(kq >> 32), (int32_t)i };
+				dst += en - st;
+			}
+		});
+		PrechainSparse ps;
+		const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)n_jobs, ps);
+		if (rc != MPA_OK) { delete b; return nullptr; }
+		timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
+		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
+			static thread_local std::vector<uint64_t> a;
+			stage_anchors_from_device(b, b->qs[i], ps, a);
+			stage_chain_to_plan(b, b->qs[i], a);
+			AccTimer tm(7);
+			plan_round1(b, b->qs[i]);
+		});
+	}
 	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
 	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
 	return b;
+}
+
+static bool gpu_seeding_wanted()
+{
+	const char *e = getenv("MPA_GPU_SEED");             // (read per call: the tests flip it)
+	return e ? atoi(e) != 0 : false;
+}
+
+mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+{
+	return batch_begin_impl(nullptr, mi, opt, q, n_threads);
 }
 
 int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpopt_t *opt)
@@ -813,7 +907,7 @@ static int run_dp_rounds(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_qbatch_t
 static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
 {
 	*out = nullptr;
-	mpa_batch_t *b = mpa_batch_begin(mi, opt, q, n_threads);
+	mpa_batch_t *b = batch_begin_impl(gpu_seeding_wanted() ? ctx : nullptr, mi, opt, q, n_threads);
 	if (!b) return MPA_ERR_ARG;
 	const int rc = run_dp_rounds(ctx, mi, q, b);
 	if (rc != MPA_OK) { delete b; return rc; }
@@ -840,6 +934,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	n_lanes = std::max(1, std::min(n_lanes, 4));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
+	mpa_ctx_t *seed_ctx = gpu_seeding_wanted() ? ctx_sibling(ctx, n_lanes) : nullptr;   // the seeder's own streams and buffers
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	std::thread seeder([&] {
@@ -850,7 +945,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_dp_done + n_lanes; });
 				if (rc_all != MPA_OK) return;
 			}
-			mpa_batch_t *b = mpa_batch_begin(mi, opt, &batches[k], n_threads);
+			mpa_batch_t *b = batch_begin_impl(seed_ctx, mi, opt, &batches[k], n_threads);
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].b = b, slot[k].begun = true;

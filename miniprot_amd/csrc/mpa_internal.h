@@ -62,4 +62,16 @@ void dev_free_index(mpa_idx_s *mi);
 mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);
 
+// ---- GPU seeding (seed_exec.hip + the driver in dp_exec.hip) --------------------------------------
+struct SeedJob { int64_t kb_off, dst; int32_t cnt, qpos, qid; };   // one kept seed: its occurrence list and where its anchors go
+struct PrechainSparse {              // result for a mini-batch: the anchors that have a neighbour, query by query
+	std::vector<int64_t> cfirst;     // [n_query + 1] offsets into the arrays below
+	int64_t m = 0;
+	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call
+	const uint64_t *a = nullptr;
+};
+struct ChainParams;
+int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out);
+
 } // namespace mpa

@@ -1,0 +1,144 @@
+// seed_exec.hip -- GPU side of the seeding stage, included by dp_exec.hip.
+//
+// For a whole mini-batch at once:
+//   k_seed_gather   anchors of every kept seed: (query, block) key + query position      map.c:163-177
+//   rocPRIM         one stable LSD radix sort over (query, block)                          map.c:178 (radix_sort_mp64)
+//   k_prechain_fwd  forward pass of the block-resolution pre-chain                         chain.c:112-151,181-209
+//   scan + k_seed_compact   only anchors that have a neighbour travel back to the host
+// The pre-chain only links anchors at most one 256-bp block apart, so the sorted anchors of a query fall into
+// independent "runs" (maximal stretches in which consecutive blocks differ by at most max_dblock); ~97 % of the anchors
+// at genome scale are runs of one, which the extraction (host, chain_extract on a sparse ChainView) never needs to see.
+// One thread walks one run with exactly the reference's loop; the arithmetic of comput_sc() includes two float
+// operations, compiled without FMA contraction like the host code.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace mpa {
+
+struct SeedJobDev { int64_t kb_off, dst; int32_t cnt, qpos, qid, pad; };
+
+__global__ __launch_bounds__(256) void k_seed_gather(const SeedJobDev *jobs, int32_t n_jobs, const uint32_t *kb, int nb, uint64_t *key, uint32_t *val)
+{
+	const int32_t j = blockIdx.x;
+	if (j >= n_jobs) return;
+	const SeedJobDev s = jobs[j];
+	const uint64_t hi = (uint64_t)s.qid << nb;
+	for (int32_t k = threadIdx.x; k < s.cnt; k += 256) {
+		key[s.dst + k] = hi | kb[s.kb_off + k];
+		val[s.dst + k] = (uint32_t)s.qpos;
+	}
+}
+
+struct PreParams { int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, kmer, bbit, is_spliced, max_dblock; float coef_log; };
+
+__device__ __forceinline__ float d_log2_poly(float x)          // mp_log2 (mppriv.h:91-99)
+{
+	union { float f; uint32_t i; } z = { x };
+	float r = (float)((int32_t)((z.i >> 23) & 255) - 128);
+	z.i &= ~(255u << 23);
+	z.i += 127u << 23;
+	r += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+	return r;
+}
+
+#define D_INCOMPAT INT32_MIN
+// comput_sc (chain.c:112-151) for block anchors (bbit > 0); blocks are query-local differences, so the query bits cancel
+__device__ __forceinline__ int32_t d_link_score(uint64_t kcur, uint32_t qcur, uint64_t kprev, uint32_t qprev, const PreParams &p)
+{
+	const int32_t dq = (int32_t)qcur - (int32_t)qprev, dq3 = dq * 3;
+	if (dq <= 0 || dq3 > p.max_dist_x || dq > p.max_dist_y) return D_INCOMPAT;
+	const int32_t bs = 1 << p.bbit;
+	const int32_t dr3 = (int32_t)((kcur - kprev) << p.bbit);
+	int32_t gap, gap_signed;
+	if (dq3 < dr3 - bs) gap = dr3 - bs - dq3, gap_signed = -gap;
+	else if (dq3 > dr3 + bs) gap = dq3 - dr3 - bs, gap_signed = gap;
+	else gap = gap_signed = 0;
+	if (gap > p.bw) return D_INCOMPAT;
+	int32_t sc = p.kmer < dq ? p.kmer : dq;
+	if (gap > 0) {
+		const float lin = (float)gap * .33334f;
+		const float lg = gap >= 2 ? p.coef_log * (d_log2_poly((float)(gap + 1)) - 1.0f) + 1.0f : (float)gap;
+		if (p.is_spliced && gap_signed < 0) sc -= (int)(lin < lg ? lin : lg);
+		else sc -= (int)(lin + lg);
+	}
+	if (kcur == kprev && gap == 0) sc += 2;                    // MP_BLOCK_BONUS
+	return sc;
+}
+
+// one thread per anchor; the thread of a run's first anchor walks the run (mp_chain's forward loop, chain.c:181-209)
+__global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, PreParams p,
+                                                      int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
+{
+	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (s >= n) return;
+	const uint64_t ks = key[s];
+	if (s > 0 && ks - key[s - 1] <= (uint64_t)p.max_dblock) return;      // not the head of its run
+	int64_t e = s + 1;
+	{
+		uint64_t prev = ks;
+		while (e < n) { const uint64_t k = key[e]; if (k - prev > (uint64_t)p.max_dblock) break; prev = k, ++e; }
+	}
+	if (e - s < 2) return;                                               // alone: f = kmer, no predecessor (the defaults)
+	const int64_t q0 = qfirst[ks >> nb];                                 // positions are stored relative to the query's first anchor
+	int64_t win = s, hot = -1;
+	int32_t hot_f = 0;
+	for (int64_t i = s; i < e; ++i) {
+		const uint64_t ki = key[i];
+		const uint32_t qi = val[i];
+		const int32_t me = (int32_t)(i - q0);
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (int64_t)((ki - key[win]) << p.bbit) > p.max_dist_x) ++win;
+		if (hot >= 0 && hot >= win) {
+			const int32_t l = d_link_score(ki, qi, key[hot], val[hot], p);
+			const int32_t sc = hot_f + l;                                  // (INT32_MIN + hot_f stays far below kmer, as on the host)
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		for (int64_t j = i - 1; j >= win; --j) {
+			int32_t sc = d_link_score(ki, qi, key[j], val[j], p);
+			if (sc == D_INCOMPAT) continue;
+			sc += f[j];
+			if (sc > best) {
+				best = sc, best_j = j;
+				if (skipped > 0) --skipped;
+			} else if (mark[j] == me) {
+				if (++skipped > p.max_skip) break;
+			}
+			const int32_t pj = pred[j];
+			if (pj >= 0) mark[q0 + pj] = me;
+		}
+		f[i] = best, pred[i] = best_j < 0 ? -1 : (int32_t)(best_j - q0);
+		flag[i] = 1;
+		if (hot_f < best) hot_f = best, hot = i;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) f[i] = kmer, pred[i] = -1, mark[i] = -1, flag[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
+                                                      const uint32_t *idx, const int32_t *f, const int32_t *pred, int32_t *o_pos, int32_t *o_f, int32_t *o_pred, uint64_t *o_a)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n || !flag[i]) return;
+	const uint64_t k = key[i];
+	const uint32_t d = idx[i];
+	o_pos[d] = (int32_t)(i - qfirst[k >> nb]);
+	o_f[d] = f[i], o_pred[d] = pred[i];
+	o_a[d] = (k & ((1ULL << nb) - 1)) << 32 | val[i];
+}
+
+// compact offset of every query's first anchor (+ the total)
+__global__ __launch_bounds__(256) void k_seed_bounds(const int64_t *qfirst, int32_t n_query, int64_t n, const uint32_t *idx, const uint32_t *flag, int64_t *cfirst)
+{
+	const int32_t q = blockIdx.x * 256 + threadIdx.x;
+	if (q > n_query) return;
+	const int64_t i = qfirst[q];
+	cfirst[q] = i < n ? (int64_t)idx[i] : (n > 0 ? (int64_t)idx[n - 1] + flag[n - 1] : 0);
+}
+
+} // namespace mpa

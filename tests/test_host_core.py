@@ -77,6 +77,43 @@ def test_chain_anchors_matches_oracle(oracle_built):
         assert np.array_equal(ua, ub) and np.array_equal(aa, ab), ("refine", it, n, args)
 
 
+def test_prechain_through_sparse_view_matches_oracle(oracle_built):
+    """the GPU seeding stage hands chain_extract() only the anchors that have a neighbour (a sparse ChainView): same chains"""
+    o, L = refbind.ora(), mpa.lib()
+    o.mpo_chain.restype = C.c_int32
+    o.mpo_chain.argtypes = CHAIN_ARGS
+    L.mpa_dbg_prechain_sparse.restype = C.c_int32
+    L.mpa_dbg_prechain_sparse.argtypes = [C.c_int32] * 3 + [C.c_float] + [C.c_int32] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(12)
+    big_f = 0
+    for it in range(300):
+        kind = it % 5
+        if kind == 0:
+            a = _anchors(rng, int(rng.choice([70, 500, 5000, 60000])), 3000000, 400, int(rng.choice([0, 3, 40])))
+        elif kind == 1:
+            a = _anchors(rng, int(rng.choice([65, 300, 3000])), int(rng.choice([50, 400, 3000])), 300, 20)
+        elif kind == 2:
+            a = _anchors(rng, 2000, 3000000, 400, 0)
+            hot = _anchors(rng, 300, 40, 300, 30) + (np.uint64(0 if rng.random() < 0.5 else 2999000) << np.uint64(32))
+            a = np.unique(np.concatenate([a, hot]))
+        elif kind == 3:   # a long collinear chain: chain scores above 255 (the dense fallback with absent roots)
+            m = int(rng.choice([60, 150]))
+            dq = np.cumsum(rng.integers(1, 4, m))
+            x = (5000 + (dq * 3) // 256).astype(np.uint64)
+            a = np.unique(np.concatenate([_anchors(rng, 3000, 3000000, 900, 5), (x << np.uint64(32)) | (10 + dq).astype(np.uint64)]))
+        else:
+            a = _anchors(rng, int(rng.choice([0, 1, 30, 64, 65, 66])), 2000, 200, 3)
+        max_iter = int(rng.choice([1000000, 1000000, 20]))
+        ua, aa = _chain(o.mpo_chain, a, [256, 256, 256, 25, max_iter, 2, 0, 0.75, 1, 6, 8])
+        b = a.copy()
+        u = np.zeros(len(a) + 1, np.uint64)
+        no = C.c_int64(0)
+        nu = L.mpa_dbg_prechain_sparse(256, 25, max_iter, 0.75, 1, 6, 8, len(b), b.ctypes.data, u.ctypes.data, C.byref(no))
+        assert np.array_equal(ua, u[:nu]) and np.array_equal(aa, b[:no.value]), (it, len(a))
+        big_f += len(ua) > 0 and int((ua >> np.uint64(32)).max()) > 255
+    assert big_f > 10
+
+
 def test_pair_sort_tie_order_matches_oracle(oracle_built):
     o, L = refbind.ora(), mpa.lib()
     L.mpa_dbg_sort_pairs.argtypes = [C.c_void_p, C.c_void_p]
