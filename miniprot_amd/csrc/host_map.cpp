@@ -82,6 +82,8 @@ struct mpa_batch_s {
 	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
 	std::vector<QueryState> qs;
 	std::vector<mpa_dp_task_t> tasks;
+	bool seeded_on_device = false;   // between the two seeding phases: `sparse` holds the device's pre-chain result
+	PrechainSparse sparse;
 };
 
 namespace mpa {
@@ -93,7 +95,7 @@ public:
 	// never destroyed: workers outlive main().  One pool per lane, so that the pipeline stages of mpa_map_batches()
 	// (seeding of the next batch / DP-round bookkeeping / flattening + formatting of the previous one) can each run
 	// their own parallel region at the same time.
-	static WorkerPool &get(int lane) { static WorkerPool *p[3] = { new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
+	static WorkerPool &get(int lane) { static WorkerPool *p[4] = { new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
 	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
 		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
 		std::unique_lock<std::mutex> run_lock(run_mu_);              // one parallel region at a time
@@ -736,8 +738,19 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-// seed_ctx != nullptr: anchors, their sort and the forward pass of the pre-chain run on that device context
-static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+// MPA_GPU_SEED: 0 = seeding always on the host, 1 = always on the device, unset = by the size of the batch
+static int gpu_seeding_mode()
+{
+	const char *e = getenv("MPA_GPU_SEED");             // (read per call: the tests flip it)
+	return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}
+// Below this many anchors per mini-batch the host's own sort + forward pass is faster than a round trip to a GPU that is
+// busy with DP rounds (measured: 2.7 M anchors at config 2 -> host, 25 M at 600 Mbp and 240 M at config 3 -> device).
+static const int64_t kDeviceSeedingMinAnchors = 8000000;
+
+// Phase 1 of a batch: seeds of every query; with a device context and a batch that is worth it, also the anchors, their
+// sort and the forward pass of the pre-chain (seed_exec.hip).
+static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
 {
 	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
 	mpa_batch_s *b = new mpa_batch_s();
@@ -747,58 +760,58 @@ static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	for (int32_t i = 0; i < q->n_seq; ++i) {
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
 	}
-	double t0 = now_ms();
-	const bool on_device = seed_ctx && prechain_enabled(*opt) && mi->opt.bbit > 0 && q->n_seq > 0;
-	if (!on_device) {
-		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
-			static thread_local std::vector<uint64_t> a;
-			stage_seeds(b, b->qs[i]);
-			stage_anchors_host(b, b->qs[i], a);
-			stage_chain_to_plan(b, b->qs[i], a);
-			AccTimer tm(7);
-			plan_round1(b, b->qs[i]);
-		});
-	} else {
-		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seeds(b, b->qs[i]); });
-		const double t1 = now_ms();
-		std::vector<int64_t> qfirst((size_t)q->n_seq + 1, 0);
-		size_t n_jobs = 0;
-		for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, n_jobs += b->qs[i].seeds.size();
-		std::vector<SeedJob> jobs(n_jobs);
-		std::vector<size_t> jfirst((size_t)q->n_seq + 1, 0);
-		for (int32_t i = 0; i < q->n_seq; ++i) jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
-		const int64_t n_bucket = (int64_t)mi->ki.size();
-		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
-			int64_t dst = qfirst[i];
-			size_t j = jfirst[i];
-			for (uint64_t kq : b->qs[i].seeds) {
-				const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-				jobs[j++] = SeedJob{ st, dst, (int32_t)(en - st), (int32_t)(kq >> 32), (int32_t)i };
-				dst += en - st;
-			}
-		});
-		PrechainSparse ps;
-		const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)n_jobs, ps);
-		if (rc != MPA_OK) { delete b; return nullptr; }
-		timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
-		parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
-			static thread_local std::vector<uint64_t> a;
-			stage_anchors_from_device(b, b->qs[i], ps, a);
-			stage_chain_to_plan(b, b->qs[i], a);
-			AccTimer tm(7);
-			plan_round1(b, b->qs[i]);
-		});
-	}
-	timing_note("stage A (seed..plan)", now_ms() - t0);
-	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
-	if (opt->flag & MPA_MF_NO_ALIGN) b->round = 4;
+	const double t0 = now_ms();
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seeds(b, b->qs[i]); });
+	const int mode = gpu_seeding_mode();
+	if (!seed_ctx || mode == 0 || !prechain_enabled(*opt) || mi->opt.bbit <= 0 || q->n_seq == 0) return b;
+	std::vector<int64_t> qfirst((size_t)q->n_seq + 1, 0);
+	std::vector<size_t> jfirst((size_t)q->n_seq + 1, 0);
+	for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
+	if (mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) return b;
+	std::vector<SeedJob> jobs(jfirst[q->n_seq]);
+	const int64_t n_bucket = (int64_t)mi->ki.size();
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
+		int64_t dst = qfirst[i];
+		size_t j = jfirst[i];
+		for (uint64_t kq : b->qs[i].seeds) {
+			const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
+			jobs[j++] = SeedJob{ st, dst, (int32_t)(en - st), (int32_t)(kq >> 32), (int32_t)i };
+			dst += en - st;
+		}
+	});
+	const double t1 = now_ms();
+	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jobs.size(), b->sparse);
+	if (rc != MPA_OK) { delete b; return nullptr; }
+	b->seeded_on_device = true;
+	timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
+	timing_note("stage A1 (seeds, device seeding)", now_ms() - t0);
 	return b;
 }
 
-static bool gpu_seeding_wanted()
+// Phase 2: pre-chain (host: anchors, sort, forward pass, extraction; after device seeding: extraction only), chaining,
+// regions, refinement, alignment plans.  b->sparse (pinned memory of the seeding context) is not needed afterwards.
+static void batch_plan_phase(mpa_batch_s *b)
 {
-	const char *e = getenv("MPA_GPU_SEED");             // (read per call: the tests flip it)
-	return e ? atoi(e) != 0 : false;
+	const double t0 = now_ms();
+	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t i) {
+		static thread_local std::vector<uint64_t> a;
+		if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, a);
+		else stage_anchors_host(b, b->qs[i], a);
+		stage_chain_to_plan(b, b->qs[i], a);
+		AccTimer tm(7);
+		plan_round1(b, b->qs[i]);
+	});
+	b->sparse = PrechainSparse();
+	timing_note("stage A (seed..plan)", now_ms() - t0);
+	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
+	if (b->opt.flag & MPA_MF_NO_ALIGN) b->round = 4;
+}
+
+static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+{
+	mpa_batch_t *b = batch_seed_phase(seed_ctx, mi, opt, q, n_threads);
+	if (b) batch_plan_phase(b);
+	return b;
 }
 
 mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
@@ -907,7 +920,7 @@ static int run_dp_rounds(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_qbatch_t
 static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
 {
 	*out = nullptr;
-	mpa_batch_t *b = batch_begin_impl(gpu_seeding_wanted() ? ctx : nullptr, mi, opt, q, n_threads);
+	mpa_batch_t *b = batch_begin_impl(ctx, mi, opt, q, n_threads);
 	if (!b) return MPA_ERR_ARG;
 	const int rc = run_dp_rounds(ctx, mi, q, b);
 	if (rc != MPA_OK) { delete b; return rc; }
@@ -923,32 +936,48 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
-	struct Slot { mpa_batch_t *b = nullptr; bool begun = false, dp_done = false; };
+	struct Slot { mpa_batch_t *b = nullptr; bool seeded = false, begun = false, dp_done = false; };
 	std::vector<Slot> slot((size_t)n_batches);
 	std::mutex mu;
 	std::condition_variable cv;
-	int32_t n_dp_done = 0, rc_all = MPA_OK;
+	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK;
 	std::string err;
 	int n_lanes = 2;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
 	n_lanes = std::max(1, std::min(n_lanes, 4));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
-	mpa_ctx_t *seed_ctx = gpu_seeding_wanted() ? ctx_sibling(ctx, n_lanes) : nullptr;   // the seeder's own streams and buffers
+	// the seeder's own streams and buffers, two sets: the result of batch k is consumed while batch k+1 is on the device
+	mpa_ctx_t *seed_ctx[2] = { ctx_sibling(ctx, n_lanes), ctx_sibling(ctx, n_lanes + 1) };
+	if (!seed_ctx[0] || !seed_ctx[1]) return MPA_ERR_HIP;
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	std::thread seeder([&] {
 		tl_pool_lane = 1;
 		for (int32_t k = 0; k < n_batches; ++k) {
-			{	// stay at most one batch ahead of the ones in their DP rounds
+			{	// stay at most one batch ahead of the planner (its result lives in one of two seeding contexts)
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_dp_done + n_lanes; });
+				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_planned + 1; });
 				if (rc_all != MPA_OK) return;
 			}
-			mpa_batch_t *b = batch_begin_impl(seed_ctx, mi, opt, &batches[k], n_threads);
+			mpa_batch_t *b = batch_seed_phase(seed_ctx[k & 1], mi, opt, &batches[k], n_threads);
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
-			slot[k].b = b, slot[k].begun = true;
+			slot[k].b = b, slot[k].seeded = true;
+			cv.notify_all();
+		}
+	});
+	std::thread planner([&] {
+		tl_pool_lane = 3;
+		for (int32_t k = 0; k < n_batches; ++k) {
+			{	// stay at most one batch ahead of the ones in their DP rounds
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes); });
+				if (rc_all != MPA_OK) return;
+			}
+			batch_plan_phase(slot[k].b);
+			std::lock_guard<std::mutex> g(mu);
+			slot[k].begun = true, ++n_planned;
 			cv.notify_all();
 		}
 	});
@@ -986,7 +1015,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
-	seeder.join(), finisher.join();
+	seeder.join(), planner.join(), finisher.join();
 	ctx_absorb_sibling_stats(ctx);
 	if (rc_all != MPA_OK) {
 		for (Slot &sl : slot) delete sl.b;
