@@ -89,6 +89,7 @@ struct mpa_ctx_s {
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
 	std::vector<mpa_ctx_s*> siblings;         // extra contexts on the same device for concurrent sub-batches (owned)
 	SeedBufs seed;                            // buffers of the GPU seeding stage (seed_exec.hip)
+	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
 };
 
 namespace mpa {
@@ -327,7 +328,13 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	while ((1LL << qb) < n_query) ++qb;
 	if (nb + qb > 64) { set_error("GPU pre-chain: too many queries x blocks for a 64-bit key"); return MPA_ERR_UNSUPPORTED; }
 	SeedBufs &B = ctx->seed;
-	hipStream_t s = ctx->stream;
+	if (!ctx->seed_stream) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
+	}
+	hipStream_t s = ctx->seed_stream;
+	const double t_begin = now_ms();
 	// ---- upload the seed jobs
 	if (B.h_jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
 	SeedJobDev *hj = B.h_jobs.as<SeedJobDev>();
@@ -361,8 +368,10 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.qfirst.as<int64_t>(), n_query, n, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
 	                   B.cfirst.as<int64_t>());
 	HIP_TRY(hipGetLastError());
+	const double t_issued = now_ms();
 	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
+	const double t_kernels = now_ms();
 	const int64_t m = out.cfirst[n_query];
 	out.m = m;
 	if (m == 0) return MPA_OK;
@@ -377,6 +386,9 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
+	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
+	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
+	timing_note("    seed: compact + download", now_ms() - t_kernels);
 	return MPA_OK;
 }
 } // namespace mpa

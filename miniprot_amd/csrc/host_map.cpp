@@ -142,10 +142,11 @@ private:
 };
 
 static thread_local int tl_pool_lane = 0;
+static thread_local int tl_thread_div = 1;          // pipeline stages with light host work take a fraction of the threads
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 {
 	std::function<void(int64_t)> f = fn;
-	WorkerPool::get(tl_pool_lane).run(n_threads, n, f);
+	WorkerPool::get(tl_pool_lane).run(std::max(1, n_threads / tl_thread_div), n, f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -762,25 +763,35 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	}
 	const double t0 = now_ms();
 	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seeds(b, b->qs[i]); });
+	timing_note("  A1: seeds of all queries", now_ms() - t0);
 	const int mode = gpu_seeding_mode();
 	if (!seed_ctx || mode == 0 || !prechain_enabled(*opt) || mi->opt.bbit <= 0 || q->n_seq == 0) return b;
-	std::vector<int64_t> qfirst((size_t)q->n_seq + 1, 0);
-	std::vector<size_t> jfirst((size_t)q->n_seq + 1, 0);
+	// (buffers of the seeding thread, reused: fresh multi-MB vectors per batch mean page faults under an address space that
+	// the planner's workers are busy mapping and unmapping)
+	static thread_local std::vector<int64_t> qfirst;
+	static thread_local std::vector<size_t> jfirst;
+	static thread_local std::vector<SeedJob> jobs;
+	qfirst.assign((size_t)q->n_seq + 1, 0), jfirst.assign((size_t)q->n_seq + 1, 0);
 	for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
 	if (mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) return b;
-	std::vector<SeedJob> jobs(jfirst[q->n_seq]);
+	if (jobs.size() < jfirst[q->n_seq]) jobs.resize(jfirst[q->n_seq]);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
-	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
-		int64_t dst = qfirst[i];
-		size_t j = jfirst[i];
+	// (pointers, not the thread_local vectors: the workers have their own, empty, instances of those)
+	SeedJob *const jobs_p = jobs.data();
+	const int64_t *const qfirst_p = qfirst.data();
+	const size_t *const jfirst_p = jfirst.data();
+	parallel_for(b->n_threads, q->n_seq, [&, jobs_p, qfirst_p, jfirst_p](int64_t i) {
+		int64_t dst = qfirst_p[i];
+		size_t j = jfirst_p[i];
 		for (uint64_t kq : b->qs[i].seeds) {
 			const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
-			jobs[j++] = SeedJob{ st, dst, (int32_t)(en - st), (int32_t)(kq >> 32), (int32_t)i };
+			jobs_p[j++] = SeedJob{ st, dst, (int32_t)(en - st), (int32_t)(kq >> 32), (int32_t)i };
 			dst += en - st;
 		}
 	});
 	const double t1 = now_ms();
-	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jobs.size(), b->sparse);
+	timing_note("  A1: seed jobs", t1 - t0);
+	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse);
 	if (rc != MPA_OK) { delete b; return nullptr; }
 	b->seeded_on_device = true;
 	timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
@@ -953,7 +964,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	std::thread seeder([&] {
-		tl_pool_lane = 1;
+		tl_pool_lane = 1, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{	// stay at most one batch ahead of the planner (its result lives in one of two seeding contexts)
 				std::unique_lock<std::mutex> g(mu);
@@ -982,7 +993,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 		}
 	});
 	std::thread finisher([&] {
-		tl_pool_lane = 2;
+		tl_pool_lane = 2, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
@@ -998,6 +1009,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	// The rounds of one batch are dominated by the tails of a few very long DP calls, during which the GPU is nearly
 	// idle; the next batch's rounds fill that space.
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) {
+		tl_thread_div = 4;
 		for (int32_t k = d; k < n_batches; k += n_lanes) {
 			{
 				std::unique_lock<std::mutex> g(mu);
@@ -1015,6 +1027,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
+	tl_thread_div = 1;
 	seeder.join(), planner.join(), finisher.join();
 	ctx_absorb_sibling_stats(ctx);
 	if (rc_all != MPA_OK) {
