@@ -537,9 +537,10 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	extern __shared__ uint32_t lds_raw[];
 	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots and the record ring
 	int16_t *lds_prof = (int16_t*)lds_raw;
-	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 parities][NW] carry of the I scan
-	uint32_t *xH = xY + 2 * NW;                                  // [2 parities][NW] H of the block's last column
-	uint2 *ring = (uint2*)(xH + 2 * NW);                         // [64 rows] {record of half 0, record of half 1}
+	constexpr int RING = NW <= 4 ? 64 : 128;                     // rows of records in LDS: the last wave runs 3 (NW - 1) rows behind the first
+	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 step parities][3 rows][NW] carry of the I scan
+	uint32_t *xH = xY + 6 * NW;                                  // [2 step parities][3 rows][NW] H of the block's last column
+	uint2 *ring = (uint2*)(xH + 6 * NW);                         // [RING rows] {record of half 0, record of half 1}
 	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
 	const ExtWave *wvp = &a.waves[blockIdx.x];
 	const DpConst c = a.c;
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 			lds_prof[(w * 2 + h) * 22 * 64 + k] = gcc < t->pw ? src[aidx * t->pw + gcc] : (int16_t)NEG16;
 		}
 	}
-	if (threadIdx.x < 4 * NW) xY[threadIdx.x] = NEGP;             // xY and xH are contiguous
+	if (threadIdx.x < 12 * NW) xY[threadIdx.x] = NEGP;            // xY and xH are contiguous (NW * 64 threads >= 12 NW)
 	// record ring, filled by the leading wave: rows [0,32) now, then 16 rows at a time (see k_ext)
 	const bool loader = w == 0 && lane < 16;
 	uint2 pf = make_uint2(0, 0);
@@ -598,27 +599,47 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	uint2 rpre = ring[2], rnxt = ring[3];
 	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
 
-	auto row = [&](auto kc, int32_t i, int par) {
+	uint32_t hxv[3];
+	// per-row key: value and column of the best cell of this block, ties to the smallest column.  One packed DPP reduction
+	// covers both halves, the winning column comes from a ballot; the reductions of the rows of a step are independent
+	// dependency chains, so issuing them together hides most of their cross-lane latency.
+	auto keys = [&](int32_t i, int n_rows) {
+		uint32_t bm[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) bm[k] = (uint32_t)__builtin_amdgcn_readlane((int)scan_max_pk<64>(hxv[k]), 63);
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			if (k >= n_rows) break;
+			const uint32_t df = hxv[k] ^ bm[k];
+			const uint64_t e0 = __ballot((df & 0xffffu) == 0), e1 = __ballot((df >> 16) == 0);
+			if (lane == 0) {
+				const int32_t r = i + k;
+				if (r < nl[0] && e0) atomicMax(&rowkey[r], (uint32_t)(lo16(bm[k]) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e0) - 1)));
+				if (r < nl[1] && e1) atomicMax(&rowkey[a.key_stride + r], (uint32_t)(hi16(bm[k]) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e1) - 1)));
+			}
+		}
+	};
+	auto row = [&](auto kc, int32_t i, int par) {                  // par: parity of the (three-row) step this row belongs to
 		constexpr int K = decltype(kc)::value;
 		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
 		if (w == 0) {                                                      // ring maintenance by the leading wave
 			if ((i & 15) == 0) {
 				if (i > 2 && loader) pf = make_uint2(recbase[roff[0] + (uint32_t)i + 32 + lane], recbase[roff[1] + (uint32_t)i + 32 + lane]);
 			} else if ((i & 15) == 12) {
-				if (loader) ring[((i + 20) & 63) + lane] = pf;               // rows [i+20, i+36): written >= NW steps before any wave reads them
+				if (loader) ring[((i + 20) & (RING - 1)) + lane] = pf;       // rows [i+20, i+36): published steps before any wave reads them
 			}
 		}
 		const uint2 rcur = rpre;                                           // records of rows i+1 (rnxt) and i+2 are in flight / landed
 		rpre = rnxt;
-		rnxt = ring[(i + 2) & 63];
+		rnxt = ring[(i + 2) & (RING - 1)];
 		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);
 		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
 		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
 		const uint32_t S = Spre;                                           // looked up during the previous row
 		Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
 		// what the wave to the left produced for this same row in the previous step
-		const uint32_t carry_in = w > 0 ? xY[(par ^ 1) * NW + w - 1] : NEGP;
-		const uint32_t left_h = w > 0 ? xH[(par ^ 1) * NW + w - 1] : NEGP;
+		const uint32_t carry_in = w > 0 ? xY[((par ^ 1) * 3 + K) * NW + w - 1] : NEGP;
+		const uint32_t left_h = w > 0 ? xH[((par ^ 1) * 3 + K) * NW + w - 1] : NEGP;
 		uint32_t h, t, u;
 		h = p_adds(Hs[R3], S);
 		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
@@ -637,29 +658,31 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		h = p_max(h, p_subs(ex, gojge));
 		const uint32_t hs = shift1<64>(h, left_h, lane);
 		Hr[R3] = h, Hs[R3] = hs;
-		if (lane == 63) xY[par * NW + w] = p_max(carry_in, y), xH[par * NW + w] = h;
-		// per-row key: (H + end bonus) of the best column of this block, ties to the smallest column.  One packed
-		// DPP reduction for both halves, then the winning column from a ballot.
-		const uint32_t hx = (p_adds(h, ebv) & keepP) | deadP;
-		const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)scan_max_pk<64>(hx), 63);
-		const uint32_t df = hx ^ bm;
-		const uint64_t e0 = __ballot((df & 0xffffu) == 0), e1 = __ballot((df >> 16) == 0);
-		if (lane == 0) {
-			if (i < nl[0] && e0) atomicMax(&rowkey[i], (uint32_t)(lo16(bm) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e0) - 1)));
-			if (i < nl[1] && e1) atomicMax(&rowkey[a.key_stride + i], (uint32_t)(hi16(bm) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e1) - 1)));
-		}
+		if (lane == 63) xY[(par * 3 + K) * NW + w] = p_max(carry_in, y), xH[(par * 3 + K) * NW + w] = h;
+		// per-row key input: (H + end bonus), dead columns as -32768; reduced for the three rows of a step together (keys())
+		hxv[K] = (p_adds(h, ebv) & keepP) | deadP;
 		if (i == 2 && w == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
 	};
 
-	// wave w runs w rows behind wave 0: w barriers of delay, then one barrier per row, then the remaining
-	// NW-1-w so that every wave passes the same number of barriers.  Step parity = (row + w) & 1.
+	// Wave w runs 3 w rows behind wave 0: one barrier per step of three rows (the exchange slots hold three rows), w
+	// barriers of delay first and NW-1-w at the end so that every wave passes the same number.  Step parity = (step + w) & 1.
 	for (int k = 0; k < w; ++k) lds_barrier();
 	{
+		int par = w & 1;
 		int32_t i = 2;
-		while (i < max_nl) {
-			row(std::integral_constant<int, 0>(), i, (i + w) & 1); lds_barrier(); if (++i >= max_nl) break;
-			row(std::integral_constant<int, 1>(), i, (i + w) & 1); lds_barrier(); if (++i >= max_nl) break;
-			row(std::integral_constant<int, 2>(), i, (i + w) & 1); lds_barrier(); ++i;
+		hxv[0] = hxv[1] = hxv[2] = NEGP;
+		for (; i + 3 <= max_nl; i += 3, par ^= 1) {
+			row(std::integral_constant<int, 0>(), i, par);
+			row(std::integral_constant<int, 1>(), i + 1, par);
+			row(std::integral_constant<int, 2>(), i + 2, par);
+			keys(i, 3);
+			lds_barrier();
+		}
+		if (i < max_nl) {                                                  // one or two rows left
+			row(std::integral_constant<int, 0>(), i, par);
+			if (i + 1 < max_nl) row(std::integral_constant<int, 1>(), i + 1, par);
+			keys(i, max_nl - i);
+			lds_barrier();
 		}
 	}
 	for (int k = w; k < NW - 1; ++k) lds_barrier();
