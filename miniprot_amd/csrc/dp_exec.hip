@@ -327,6 +327,14 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	while ((1ULL << nb) < (uint64_t)mi->n_block + (uint64_t)pp.max_dblock + 2) ++nb;
 	while ((1LL << qb) < n_query) ++qb;
 	if (nb + qb > 64) { set_error("GPU pre-chain: too many queries x blocks for a 64-bit key"); return MPA_ERR_UNSUPPORTED; }
+	{	// the working set is ~60 bytes per anchor; a batch that does not fit stays on the host (the caller falls back)
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const SeedBufs &Bc = ctx->seed;
+			const size_t have = Bc.key[0].cap + Bc.key[1].cap + Bc.val[0].cap + Bc.val[1].cap + Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap;
+			if ((size_t)n * 60 > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
+		}
+	}
 	SeedBufs &B = ctx->seed;
 	if (!ctx->seed_stream) {
 		int least = 0, greatest = 0;

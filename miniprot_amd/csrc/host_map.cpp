@@ -792,6 +792,7 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	const double t1 = now_ms();
 	timing_note("  A1: seed jobs", t1 - t0);
 	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse);
+	if (rc == MPA_ERR_UNSUPPORTED) return b;            // e.g. the batch does not fit the device: seed on the host
 	if (rc != MPA_OK) { delete b; return nullptr; }
 	b->seeded_on_device = true;
 	timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
@@ -823,6 +824,34 @@ static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	mpa_batch_t *b = batch_seed_phase(seed_ctx, mi, opt, q, n_threads);
 	if (b) batch_plan_phase(b);
 	return b;
+}
+
+// Test hook (not in include/mpamd.h): the anchors that survive the pre-chain (map.c:163-192), query by query, computed on the
+// host (ctx == NULL) or with the device seeding stage (seed_exec.hip).  off[n_seq + 1] receives the offsets into *out
+// (malloc'd, mpa_free).  Returns the total or a negative error code.
+int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out)
+{
+	*out = nullptr;
+	const char *saved = getenv("MPA_GPU_SEED");
+	const std::string keep = saved ? saved : "";
+	setenv("MPA_GPU_SEED", ctx ? "1" : "0", 1);
+	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads);
+	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	if (!b) return MPA_ERR_ARG;
+	if (ctx && !b->seeded_on_device && q->n_seq > 0 && prechain_enabled(*opt)) { delete b; set_error("device seeding was not used"); return MPA_ERR_UNSUPPORTED; }
+	std::vector<std::vector<uint64_t>> per((size_t)q->n_seq);
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) {
+		if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, per[i]);
+		else stage_anchors_host(b, b->qs[i], per[i]);
+	});
+	off[0] = 0;
+	for (int32_t i = 0; i < q->n_seq; ++i) off[i + 1] = off[i] + (int64_t)per[i].size();
+	uint64_t *o = (uint64_t*)malloc((size_t)std::max<int64_t>(off[q->n_seq], 1) * 8);
+	for (int32_t i = 0; i < q->n_seq; ++i) memcpy(o + off[i], per[i].data(), per[i].size() * 8);
+	*out = o;
+	const int64_t n = off[q->n_seq];
+	delete b;
+	return n;
 }
 
 mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
