@@ -14,7 +14,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpamd.so")
+LIB_PATH = os.environ.get("MPA_LIB_PATH") or os.path.join(_HERE, "libmpamd.so")   # (override: experiment builds)
 
 F_CIGAR, F_EXT_LEFT, F_EXT_RIGHT = 1, 2, 4
 

@@ -178,7 +178,7 @@ static hipError_t launch_ext_narrow(const ExtArgs &a, const int *first, const in
 
 template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_groups, hipStream_t s)
 {
-	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 12 * NW * 4 + (NW <= 4 ? 64 : 128) * 8;
+	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 12 * NW * 4 + (NW <= 4 ? 64 : 128) * 8 + 128 * (2 * NW + 1) * 4;
 	if (lds > 48 * 1024) {
 		hipError_t e = hipFuncSetAttribute((const void*)k_ext_wide<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;

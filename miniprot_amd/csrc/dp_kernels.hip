@@ -84,6 +84,19 @@ template<int G> __device__ __forceinline__ uint32_t scan_max_pk(uint32_t x)
 	return x;
 }
 
+// wave-wide maximum of unsigned words, valid in lane 63
+__device__ __forceinline__ uint32_t reduce_max_u32(uint32_t x)
+{
+	auto umax = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+	x = umax(x, dpp_mov<DPP_ROW_SHR(1), 0xf>(0u, x));
+	x = umax(x, dpp_mov<DPP_ROW_SHR(2), 0xf>(0u, x));
+	x = umax(x, dpp_mov<DPP_ROW_SHR(4), 0xf>(0u, x));
+	x = umax(x, dpp_mov<DPP_ROW_SHR(8), 0xf>(0u, x));
+	x = umax(x, dpp_mov<DPP_BCAST15, 0xa>(0u, x));
+	x = umax(x, dpp_mov<DPP_BCAST31, 0xc>(0u, x));
+	return x;
+}
+
 // barrier that orders LDS traffic only: outstanding global stores/atomics (vmcnt) keep draining across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -541,6 +554,8 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 step parities][3 rows][NW] carry of the I scan
 	uint32_t *xH = xY + 6 * NW;                                  // [2 step parities][3 rows][NW] H of the block's last column
 	uint2 *ring = (uint2*)(xH + 6 * NW);                         // [RING rows] {record of half 0, record of half 1}
+	constexpr int KS = 2 * NW + 1;                               // dwords per row of the key ring (odd: the flush reads it row-parallel)
+	uint32_t *kring = (uint32_t*)(ring + RING);                  // [128 rows][NW][2 halves] per-row, per-block keys (see keys())
 	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
 	const ExtWave *wvp = &a.waves[blockIdx.x];
 	const DpConst c = a.c;
@@ -600,22 +615,29 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
 
 	uint32_t hxv[3];
-	// per-row key: value and column of the best cell of this block, ties to the smallest column.  One packed DPP reduction
-	// covers both halves, the winning column comes from a ballot; the reductions of the rows of a step are independent
-	// dependency chains, so issuing them together hides most of their cross-lane latency.
+	// Per-row key of this block: the best (H + end bonus) and its column, ties to the smallest column, per half, as
+	// (value + 32768) << 6 | (63 - lane) so that one unsigned wave maximum yields both.  The reductions of the three rows
+	// of a step are independent dependency chains and are issued together; lane 63 drops the results into an LDS ring
+	// [row][block], from which the last wave -- the last to finish a row -- assembles 64 rows at a time (flush_keys) the
+	// per-row keys the replay below consumes.  (Global atomics per row and wave, or assembling the key with scalar code in
+	// the row loop, each cost a quarter of this kernel's time.)
+	const uint32_t lane_tag = 63u - (uint32_t)lane;
 	auto keys = [&](int32_t i, int n_rows) {
-		uint32_t bm[3];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) bm[k] = (uint32_t)__builtin_amdgcn_readlane((int)scan_max_pk<64>(hxv[k]), 63);
+#ifdef EXP_NOKEYS
+		if (i >= 0) return;
+#endif
+		uint32_t k0[3], k1[3];
 #pragma unroll
 		for (int k = 0; k < 3; ++k) {
-			if (k >= n_rows) break;
-			const uint32_t df = hxv[k] ^ bm[k];
-			const uint64_t e0 = __ballot((df & 0xffffu) == 0), e1 = __ballot((df >> 16) == 0);
-			if (lane == 0) {
-				const int32_t r = i + k;
-				if (r < nl[0] && e0) atomicMax(&rowkey[r], (uint32_t)(lo16(bm[k]) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e0) - 1)));
-				if (r < nl[1] && e1) atomicMax(&rowkey[a.key_stride + r], (uint32_t)(hi16(bm[k]) + 32768) << 16 | (0xffffu - (uint32_t)(w * 64 + __ffsll((unsigned long long)e1) - 1)));
+			k0[k] = reduce_max_u32((((hxv[k] & 0xffffu) ^ 0x8000u) << 6) | lane_tag);
+			k1[k] = reduce_max_u32((((hxv[k] >> 16) ^ 0x8000u) << 6) | lane_tag);
+		}
+		if (lane == 63) {
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				if (k >= n_rows) break;
+				uint32_t *slot = kring + ((i + k) & 127) * KS + 2 * w;
+				slot[0] = k0[k], slot[1] = k1[k];
 			}
 		}
 	};
@@ -669,13 +691,32 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	for (int k = 0; k < w; ++k) lds_barrier();
 	{
 		int par = w & 1;
-		int32_t i = 2;
+		int32_t i = 2, flushed = 2;                                        // keys of rows [2, flushed) are in HBM
+		auto flush_keys = [&](int32_t upto) {                              // last wave only: rows [flushed, upto), 64 at a time
+			for (; flushed < upto; flushed += 64) {
+				const int32_t r = flushed + lane;
+				if (r < upto) {
+					const uint32_t *slot = kring + (r & 127) * KS;
+					uint32_t b0 = slot[0], b1 = slot[1];
+					int32_t w0 = 0, w1 = 0;
+#pragma unroll
+					for (int ww = 1; ww < NW; ++ww) {                          // best block, ties to the leftmost
+						const uint32_t v0 = slot[2 * ww], v1 = slot[2 * ww + 1];
+						if ((v0 >> 6) > (b0 >> 6)) b0 = v0, w0 = ww;
+						if ((v1 >> 6) > (b1 >> 6)) b1 = v1, w1 = ww;
+					}
+					rowkey[r] = (b0 >> 6) << 16 | (0xffffu - (uint32_t)(w0 * 64 + 63 - (int32_t)(b0 & 63)));
+					rowkey[a.key_stride + r] = (b1 >> 6) << 16 | (0xffffu - (uint32_t)(w1 * 64 + 63 - (int32_t)(b1 & 63)));
+				}
+			}
+		};
 		hxv[0] = hxv[1] = hxv[2] = NEGP;
 		for (; i + 3 <= max_nl; i += 3, par ^= 1) {
 			row(std::integral_constant<int, 0>(), i, par);
 			row(std::integral_constant<int, 1>(), i + 1, par);
 			row(std::integral_constant<int, 2>(), i + 2, par);
 			keys(i, 3);
+			if (w == NW - 1 && i + 3 - flushed >= 64) flush_keys(flushed + 64);
 			lds_barrier();
 		}
 		if (i < max_nl) {                                                  // one or two rows left
@@ -684,6 +725,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 			keys(i, max_nl - i);
 			lds_barrier();
 		}
+		if (w == NW - 1) flush_keys(max_nl);
 	}
 	for (int k = w; k < NW - 1; ++k) lds_barrier();
 	__threadfence();
