@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np, miniprot_amd as mpa
 al, nl, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+flag = int(sys.argv[4]) if len(sys.argv) > 4 else 4      # 4 = right extension (score only), 1 = global with traceback
 rng = np.random.default_rng(1)
 g = rng.integers(0, 4, nl * n + 1000).astype(np.uint8)
 idx = mpa.Index.from_nt4([g], ["c"])
@@ -14,10 +15,11 @@ q = mpa.Queries([aa[i * al:(i + 1) * al] for i in range(n)])
 tasks = np.zeros(n, mpa.DP_TASK)
 for i in range(n):
     tasks[i]["nt_off"] = i * nl; tasks[i]["vid"] = 0; tasks[i]["nl"] = nl; tasks[i]["qid"] = i; tasks[i]["aa_off"] = 0; tasks[i]["al"] = al
-    tasks[i]["flag"] = 4; tasks[i]["io"] = 29
+    tasks[i]["flag"] = flag; tasks[i]["io"] = 29
 dp = mpa.dpopt_from(mpa.default_mapopt())
 dp.xdrop = 32000                                   # never stop: time all rows
 for it in range(3):
     mpa.dp_run(ctx, idx, dp, q, tasks)
     st = ctx.dp_stats()
-    print("al %d nl %d x %d: ext %.2f ms -> %.1f ns/row" % (al, nl, n, st["ms_ext"], st["ms_ext"] * 1e6 / nl))
+    ms = st["ms_ext"] if flag != 1 else st["ms_glob"]
+    print("al %d nl %d x %d flag %d: %.2f ms -> %.1f ns/row (backtrack %.2f ms)" % (al, nl, n, flag, ms, ms * 1e6 / nl, st["ms_backtrack"]))
