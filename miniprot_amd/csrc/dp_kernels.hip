@@ -102,14 +102,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 #define NEG32 (-(1 << 29))
 __device__ __forceinline__ int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+// The compiler emits mov + hazard nop + v_mov_b32_dpp + v_max per step; VOP2 takes the DPP operand directly, and a lane
+// whose source is out of range (or whose row is masked) is simply not written, i.e. keeps x -- no fill value needed.
 template<int G> __device__ __forceinline__ int32_t scan_max_i32(int32_t x)
 {
-	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(1), 0xf>((uint32_t)NEG32, (uint32_t)x));
-	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(2), 0xf>((uint32_t)NEG32, (uint32_t)x));
-	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(4), 0xf>((uint32_t)NEG32, (uint32_t)x));
-	x = imax(x, (int32_t)dpp_mov<DPP_ROW_SHR(8), 0xf>((uint32_t)NEG32, (uint32_t)x));
-	if (G >= 32) x = imax(x, (int32_t)dpp_mov<DPP_BCAST15, 0xa>((uint32_t)NEG32, (uint32_t)x));
-	if (G == 64) x = imax(x, (int32_t)dpp_mov<DPP_BCAST31, 0xc>((uint32_t)NEG32, (uint32_t)x));
+	asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+	if (G >= 32) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x));
+	if (G == 64) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
 	return x;
 }
 template<int G> __device__ __forceinline__ int32_t shift1_i32(int32_t x, int32_t fill, int lane)
@@ -801,7 +803,7 @@ struct GlobArgs {
 
 #define SEG_BIG (1 << 20)
 
-template<int G>
+template<int G, bool MB>                              // MB: the matrix may span several 64-column blocks (block-major sweep)
 __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv)
 {
 	constexpr int NG = 64 / G;
@@ -814,7 +816,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 	if (tid >= 0) t = a.tasks[tid];
 	else { t.nl = 0, t.al = 1, t.ncol = 8, t.pw = G, t.rec_off = 0, t.prof_off = 0, t.tb_off = 0, t.bnd_off = 0, t.io = 0; }
 	const int32_t nl = t.nl, ncol = t.ncol, slen = ncol >> 3;
-	const int32_t nblk = G == 64 ? (ncol + 63) / 64 : 1;
+	const int32_t nblk = MB ? (ncol + 63) / 64 : 1;
 	const int32_t go = c.go, ge = c.ge, goe = (int16_t)(c.go + c.ge), io = t.io, fs = c.fs;
 	const uint32_t *rec = a.rec + t.rec_off;
 	uint16_t *tb = a.tb + t.tb_off;
@@ -848,7 +850,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		const int32_t seg = slen > 0 ? gc / slen : 0;
 		const bool seg_start = slen > 0 && gc % slen == 0;
 		const int32_t cge = gc * ge, yoff = seg * SEG_BIG + cge;
-		const bool first_blk = blk == 0, last_blk = blk == nblk - 1;
+		const bool first_blk = !MB || blk == 0, last_blk = !MB || blk == nblk - 1;
 
 		int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
 		int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
@@ -859,7 +861,8 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
 		uint32_t rcur = ring[2], rnext = ring[3];
 
-		for (int32_t i = 2; i < wv.max_nl; ++i) {
+		const int32_t max_nl = wv.max_nl;                 // (a register copy: through the reference it is re-loaded, and waited for, every row)
+		for (int32_t i = 2; i < max_nl; ++i) {
 			const bool rowlive = i < nl;
 			if ((i & 15) == 0) { if (loader) pf = rec[i + 16 + col]; }
 			else if ((i & 15) == 12) { if (loader) ring[((i + 4) & 31) + col] = pf; }
@@ -939,13 +942,13 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 {
 	int b = blockIdx.x;
-	if (b < m.cnt[0]) { glob_narrow<16>(a, a.waves[m.first[0] + b]); return; }
+	if (b < m.cnt[0]) { glob_narrow<16, false>(a, a.waves[m.first[0] + b]); return; }
 	b -= m.cnt[0];
-	if (b < m.cnt[1]) { glob_narrow<32>(a, a.waves[m.first[1] + b]); return; }
+	if (b < m.cnt[1]) { glob_narrow<32, false>(a, a.waves[m.first[1] + b]); return; }
 	b -= m.cnt[1];
-	if (b < m.cnt[2]) { glob_narrow<64>(a, a.waves[m.first[2] + b]); return; }
+	if (b < m.cnt[2]) { glob_narrow<64, false>(a, a.waves[m.first[2] + b]); return; }
 	b -= m.cnt[2];
-	glob_narrow<64>(a, a.waves[m.first[3] + b]);
+	glob_narrow<64, true>(a, a.waves[m.first[3] + b]);
 }
 
 // ------------------------------------------------------------------------------------------------
