@@ -83,7 +83,7 @@ struct mpa_ctx_s {
 	hipEvent_t ev[6] = {};
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
-	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff;
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey;
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -446,13 +446,12 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		t.out_idx = (int32_t)k;
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
-			const int cls = ext_class_of(t.ncol);
-			if (cls < 0) { set_error("extension call wider than 1024 columns is not supported yet (al=" + std::to_string(x.al) + ")"); return MPA_ERR_UNSUPPORTED; }
+			const int cls = ext_class_of(t.ncol);                  // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
 			if ((int64_t)x.al * max_mat + (int64_t)t.ncol * opt->ge + std::max(0, opt->end_bonus) > 32000 || opt->go + (int64_t)t.ncol * opt->ge > 32000) {
 				set_error("extension call could saturate int16; not supported"); return MPA_ERR_UNSUPPORTED;
 			}
-			t.pw = kExtClasses[cls].G * kExtClasses[cls].NB;
-			t.pad_ = cls;
+			t.pw = cls >= 0 ? kExtClasses[cls].G * kExtClasses[cls].NB : t.ncol;
+			t.pad_ = cls >= 0 ? cls : 7;
 			ext_ids.push_back((int32_t)k);
 			max_nl_ext = std::max(max_nl_ext, x.nl);
 		} else {
@@ -480,7 +479,13 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		max_nl = std::max(max_nl, t.nl);
 		for (int32_t r = 0; r < t.nl; r += 256) chunks.push_back(PrepChunk{ id, r });
 	};
-	for (int32_t id : ext_ids) layout(id);
+	int64_t hkey_total = 0;                                 // per-row keys (8 B) of the extension calls wider than 1024 columns
+	std::vector<int32_t> huge_ids;
+	for (int32_t id : ext_ids) {
+		layout(id);
+		DTask &t = T[id];
+		if (t.pad_ == 7) t.bnd_off = bnd_total, bnd_total += t.nl, t.tb_off = hkey_total, hkey_total += t.nl, huge_ids.push_back(id);
+	}
 	for (int32_t id : glob_ids) {
 		layout(id);
 		DTask &t = T[id];
@@ -548,7 +553,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	    (rc = ctx->qseq.ensure(q_bytes + 16)) || (rc = ctx->rec.ensure((size_t)rec_total * 4)) || (rc = ctx->prof.ensure((size_t)prof_total * 2 + 16)) ||
 	    (rc = ctx->waves.ensure(sizeof(ExtWave) * (ewaves.size() + 1))) || (rc = ctx->extout.ensure(sizeof(ExtOut) * n)) ||
 	    (rc = ctx->tb.ensure((size_t)tb_max * 2 + 16)) || (rc = ctx->cig.ensure((size_t)cig_total * 4 + 16)) || (rc = ctx->ncig.ensure(n * 4)) ||
-	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->rowkey.ensure((size_t)(n_wide_groups * 2 * key_stride * 4 + 64))) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
+	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->rowkey.ensure((size_t)(n_wide_groups * 2 * key_stride * 4 + 64))) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->hkey.ensure((size_t)hkey_total * 8 + 16 + (sizeof(GlobWave) + 4) * (huge_ids.size() + 1))) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
 		return rc;
 	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, T.data(), sizeof(DTask) * n, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, chunks.data(), sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
@@ -556,6 +561,22 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
 	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));
+	// extension calls wider than 1024 columns: keys (zeroed), then one GlobWave and one list entry per call
+	GlobWave *d_hw = nullptr;
+	int32_t *d_hlist = nullptr;
+	if (!huge_ids.empty()) {
+		HIP_TRY(hipMemsetAsync(ctx->hkey.p, 0, (size_t)hkey_total * 8, s));
+		d_hw = (GlobWave*)((char*)ctx->hkey.p + (((size_t)hkey_total * 8 + 15) & ~(size_t)15));
+		d_hlist = (int32_t*)(d_hw + huge_ids.size());
+		std::vector<GlobWave> hw(huge_ids.size());
+		for (size_t k = 0; k < huge_ids.size(); ++k) {
+			memset(&hw[k], 0, sizeof(GlobWave));
+			hw[k].task[0] = huge_ids[k], hw[k].task[1] = hw[k].task[2] = hw[k].task[3] = -1, hw[k].max_nl = T[huge_ids[k]].nl;
+		}
+		HIP_TRY(hipMemcpyAsync(d_hw, hw.data(), sizeof(GlobWave) * hw.size(), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_hlist, huge_ids.data(), 4 * huge_ids.size(), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));                  // (hw is a local; the calls are rare)
+	}
 
 	DevTables tabs;
 	memcpy(tabs.aa20, tab_aa20(), 256);
@@ -607,6 +628,19 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		end_side();
 		ctx->stats.launches_ext++;
 	}
+	if (!huge_ids.empty()) {                                           // block-major sweep with the traceback kernel's arithmetic, then the replay
+		GlobArgs ha;
+		ha.tasks = ctx->tasks.as<DTask>(), ha.waves = d_hw, ha.rec = ctx->rec.as<uint32_t>(), ha.prof = ctx->prof.as<int16_t>();
+		ha.tb = nullptr, ha.bnd = ctx->bnd.as<int4>(), ha.score = nullptr, ha.c = dc, ha.rowkey64 = ctx->hkey.as<unsigned long long>();
+		hipStream_t st = begin_side(true);
+		hipLaunchKernelGGL(k_ext_huge, dim3((unsigned)huge_ids.size()), dim3(64), (size_t)22 * 64 * 2 + 4 * 32 * 4, st, ha);
+		HIP_TRY(hipGetLastError());
+		hipLaunchKernelGGL(k_ext_replay, dim3((unsigned)huge_ids.size()), dim3(64), 0, st, ctx->tasks.as<DTask>(), d_hlist, (int32_t)huge_ids.size(),
+		                   ctx->hkey.as<unsigned long long>(), ctx->extout.as<ExtOut>(), dc, pen);
+		HIP_TRY(hipGetLastError());
+		end_side();
+		ctx->stats.launches_ext++;
+	}
 	if (ewave_cnt[0] + ewave_cnt[1] + ewave_cnt[2] > 0) {               // the narrow classes share one launch
 		ea.waves = ctx->waves.as<ExtWave>();
 		hipStream_t st = begin_side(true);
@@ -654,7 +688,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		HIP_TRY(hipStreamSynchronize(s));                                 // gwaves/glist are reused by the next round
 		GlobArgs ga;
 		ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
-		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc;
+		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc, ga.rowkey64 = nullptr;
 		// classes 0,1,2,7 share one launch ("narrow"); every wide class has its own
 		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
 			if (cls < 0) { ga.waves = d_gw; return launch_glob_narrow(ga, first, cnt, st); }

@@ -799,11 +799,15 @@ struct GlobArgs {
 	int4 *bnd;            // {prefix of the I scan, prefix of the carry scan, H | h1<<16 (int16 each), I1}
 	int32_t *score;       // per task
 	DpConst c;
+	unsigned long long *rowkey64;   // extension calls wider than 1024 columns only: per-row keys at t.tb_off (see k_ext_huge)
 };
 
 #define SEG_BIG (1 << 20)
 
-template<int G, bool MB>                              // MB: the matrix may span several 64-column blocks (block-major sweep)
+// MB: the matrix may span several 64-column blocks (block-major sweep).  EXT: score-only extension call swept with this
+// kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
+// per-row key (best H + end bonus, first column) that k_ext_replay consumes.
+template<int G, bool MB, bool EXT = false>
 __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv)
 {
 	constexpr int NG = 64 / G;
@@ -819,7 +823,8 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 	const int32_t nblk = MB ? (ncol + 63) / 64 : 1;
 	const int32_t go = c.go, ge = c.ge, goe = (int16_t)(c.go + c.ge), io = t.io, fs = c.fs;
 	const uint32_t *rec = a.rec + t.rec_off;
-	uint16_t *tb = a.tb + t.tb_off;
+	uint16_t *tb = a.tb + (EXT ? 0 : t.tb_off);
+	unsigned long long *rowkey = EXT ? a.rowkey64 + t.tb_off : nullptr;
 	int4 *bnd = a.bnd + t.bnd_off;
 
 	for (int32_t blk = 0; blk < nblk; ++blk) {
@@ -920,11 +925,18 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			pz = imax(pz, bin.y);
 			const int32_t Gc = imax(pz - cge, NEG16);
 			if (Gc > h1) w |= 1 << 9, h = Gc;
-			if (live && rowlive) tb[(int64_t)i * ncol + gc] = (uint16_t)(w | st);
+			if (!EXT) { if (live && rowlive) tb[(int64_t)i * ncol + gc] = (uint16_t)(w | st); }
+			else {
+				// key of this block's row: best (H + end bonus) among the live columns, ties to the smallest column
+				const int32_t hb = h + (gc == t.al - 1 ? c.end_bonus : 0);
+				const uint32_t kk = reduce_max_u32(live ? ((uint32_t)(imax(hb, NEG16) + 32768) << 6) | (63u - (uint32_t)lane) : 0u);
+				if (lane == 63 && rowlive && tid >= 0 && kk != 0)
+					atomicMax(&rowkey[i], (unsigned long long)(kk >> 6) << 32 | (0xffffffffu - (uint32_t)(blk * 64 + 63 - (int32_t)(kk & 63))));
+			}
 			// boundary record for the block to the right
 			if (!last_blk && rowlive && col == G - 1 && tid >= 0)
 				bnd[i] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
-			if (rowlive && i == nl - 1 && gc == t.al - 1 && tid >= 0) a.score[tid] = h;
+			if (!EXT && rowlive && i == nl - 1 && gc == t.al - 1 && tid >= 0) a.score[tid] = h;
 			// rotate
 			const int32_t hs = shift1_i32<G>(h, first_blk ? NEG16 : Hb, lane);
 			H3 = H2, H2 = H1, H1 = h;
@@ -935,7 +947,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			rcur = rnext, rnext = rnn;
 		}
 	}
-	if (tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
+	if (!EXT && tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
 }
 
 // one launch for the narrow traceback shapes (classes 16 / 32 / 64 lanes and the block-major one), see k_ext_narrow
@@ -949,6 +961,68 @@ __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 	if (b < m.cnt[2]) { glob_narrow<64, false>(a, a.waves[m.first[2] + b]); return; }
 	b -= m.cnt[2];
 	glob_narrow<64, true>(a, a.waves[m.first[3] + b]);
+}
+
+// Extension calls wider than 1024 columns: one wave per call, 64-column blocks swept one after the other (each all rows),
+// boundary records through HBM, per-row keys combined across blocks with 64-bit atomic maxima.
+__global__ __launch_bounds__(64) void k_ext_huge(GlobArgs a)
+{
+	glob_narrow<64, true, true>(a, a.waves[blockIdx.x]);
+}
+
+// nasw-sse.c:423-443 replayed over per-row keys ((row max + 32768) << 32 | ~column): best row under the length penalty,
+// x-drop stop.  One wave per call.
+__global__ __launch_bounds__(64) void k_ext_replay(const DTask *tasks, const int32_t *list, int32_t n_list, const unsigned long long *rowkey64,
+                                                   ExtOut *out, DpConst c, PenTable pen)
+{
+	if ((int32_t)blockIdx.x >= n_list) return;
+	const int32_t tid = list[blockIdx.x];
+	const DTask t = tasks[tid];
+	const int lane = threadIdx.x;
+	const unsigned long long *key = rowkey64 + t.tb_off;
+	const int64_t pen_len = 3 * (int64_t)t.al;
+	int32_t G = INT32_MIN, best_i = -1, best_sc = INT32_MIN, best_col = -1;
+	bool stopped = false;
+	for (int32_t base = 2; base < t.nl && !stopped; base += 64) {
+		const int32_t i = base + lane;
+		const bool ok = i < t.nl;
+		const unsigned long long kv = ok ? key[i] : 0ULL;
+		int32_t pv = 0;
+		{
+			const int64_t x = (int64_t)i - pen_len;
+			int k = 0;
+			while (k + 1 < MPA_PEN_MAX && x >= (int64_t)pen.x[k + 1]) ++k;
+			pv = pen.val[k];
+		}
+		const int32_t sc = (int32_t)(kv >> 32) - 32768;
+		const int32_t v = ok ? sc - pv : INT32_MIN;
+		int32_t m = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(m, off); if (lane >= off) m = imax(m, o); }
+		m = imax(m, G);
+		const int32_t up = __shfl_up(m, 1);
+		const bool imp = ok && v > (lane == 0 ? G : up);
+		const bool brk = ok && (int64_t)m - (int64_t)v > c.xdrop;
+		const uint64_t bm = __ballot(brk);
+		const int first_brk = bm ? __ffsll((unsigned long long)bm) - 1 : 64;
+		const uint64_t im = __ballot(imp) & (first_brk >= 63 ? ~0ULL : ((2ULL << first_brk) - 1));
+		if (im) {
+			const int last = 63 - __clzll((long long)im);
+			best_i = base + last;
+			G = __shfl(v, last);
+			best_sc = __shfl(sc, last);
+			best_col = (int32_t)(0xffffffffu - (uint32_t)__shfl((int)(uint32_t)kv, last));
+		}
+		if (bm) stopped = true;
+	}
+	if (lane == 0) {
+		ExtOut o;
+		o.nt_len = best_i + 1;
+		o.aa_len = best_i < 0 ? 0 : best_col + 1;
+		o.score = best_sc;
+		o.flags = (best_i >= 0 && best_col >= t.al) ? 1 : 0;
+		out[tid] = o;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

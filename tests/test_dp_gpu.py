@@ -76,3 +76,19 @@ def test_traceback_rounds(ctx, oracle_built, monkeypatch):
     pairs = [make_task(rng, max_intron=2000) for _ in range(200)]
     run_case(c2, pairs, P, rng, modes=("cigar",))
     c2.close()
+
+
+def test_extension_wider_than_1024_columns(ctx, oracle_built):
+    """maximum sizes: extension calls beyond the 1024 columns of k_ext_wide<16> go through k_ext_huge (the traceback kernel's
+    int32 arithmetic, 64-column blocks swept one after the other) + k_ext_replay; global calls of that width use the
+    block-major traceback class.  Mixed with ordinary calls in one batch."""
+    rng = np.random.default_rng(16)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = []
+    for al in (1025, 1030, 1100, 1600, 2500):
+        pairs.append(make_task(rng, al=al, p_indel=0.002, flank=int(rng.choice([30, 400]))))
+    pairs += [make_task(rng) for _ in range(40)]
+    run_case(ctx, pairs, P, rng)
+    # x-drop that really stops a wide extension, and a different end bonus
+    P2 = refbind.DpParams(refbind.mapping_matrix(23), xdrop=30, end_bonus=11)
+    run_case(ctx, [make_task(rng, al=1300, p_indel=0.01, flank=2000) for _ in range(3)], P2, rng)
