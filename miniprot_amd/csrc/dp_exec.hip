@@ -447,9 +447,11 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
 			const int cls = ext_class_of(t.ncol);                  // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
-			if ((int64_t)x.al * max_mat + (int64_t)t.ncol * opt->ge + std::max(0, opt->end_bonus) > 32000 || opt->go + (int64_t)t.ncol * opt->ge > 32000) {
-				set_error("extension call could saturate int16; not supported"); return MPA_ERR_UNSUPPORTED;
-			}
+			// The packed kernels run their gap scan on h + j*ge with saturating adds, which is only the reference's value while
+			// nothing can reach the int16 limits; calls that could (more than ~2900 columns with BLOSUM62, hence always of the
+			// "huge" class) are swept by k_ext_huge, whose int32 arithmetic clamps every operation like the reference does.
+			const bool may_saturate = (int64_t)x.al * max_mat + (int64_t)t.ncol * opt->ge + std::max(0, opt->end_bonus) > 32000 || opt->go + (int64_t)t.ncol * opt->ge > 32000;
+			if (may_saturate && cls >= 0) { set_error("extension call could saturate int16 in the packed kernels; not supported with these scores"); return MPA_ERR_UNSUPPORTED; }
 			t.pw = cls >= 0 ? kExtClasses[cls].G * kExtClasses[cls].NB : t.ncol;
 			t.pad_ = cls >= 0 ? cls : 7;
 			ext_ids.push_back((int32_t)k);

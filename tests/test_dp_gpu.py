@@ -92,3 +92,12 @@ def test_extension_wider_than_1024_columns(ctx, oracle_built):
     # x-drop that really stops a wide extension, and a different end bonus
     P2 = refbind.DpParams(refbind.mapping_matrix(23), xdrop=30, end_bonus=11)
     run_case(ctx, [make_task(rng, al=1300, p_indel=0.01, flank=2000) for _ in range(3)], P2, rng)
+
+
+def test_extension_that_saturates_int16(ctx, oracle_built):
+    """scores beyond 32767: the reference's int16 arithmetic saturates; k_ext_huge clamps every operation the same way"""
+    rng = np.random.default_rng(17)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    pairs = [make_task(rng, al=3300, p_indel=0.001, flank=50),              # cannot use the packed kernels (al * max score > 32000), no saturation yet
+             make_task(rng, al=6800, p_indel=0.0, p_sub=0.0, p_intron=0.0, p_fs=0.0, p_n=0.0, flank=40)]     # identical: the score runs into the int16 ceiling
+    run_case(ctx, pairs, P, rng, modes=("right", "left"))
