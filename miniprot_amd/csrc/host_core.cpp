@@ -359,40 +359,32 @@ static inline int32_t link_score(uint64_t cur, uint64_t prev, const ChainParams 
 // buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
 // The view may therefore leave out anchors that are alone in their neighbourhood (v.pos != nullptr).
 // Returns false if the preconditions do not hold (the caller then builds and sorts the full list).
-static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, std::vector<Pair64> &tail)
+struct SparseItem { int64_t pos; Pair64 e; };        // an element that is not a root, and the slot it occupies
+
+// The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest
+// key present) everywhere except at `items` (ascending pos).  Appends the non-roots in their final order.
+static void replay_low_digit(int64_t n, int k0, const std::vector<SparseItem> &items, std::vector<Pair64> &out)
 {
-	const int64_t n = v.n_total;
-	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return false;
+	const size_t m = items.size(), base = out.size();
+	if (m == 0) return;
 	size_t cnt[256];
 	memset(cnt, 0, sizeof(cnt));
-	int64_t m = 0;
-	for (int64_t i = 0; i < v.m; ++i)
-		if (v.pred[i] >= 0) {
-			if (v.f[i] > 255 || v.f[i] <= p.kmer) return false;   // (f > kmer always holds for a chained anchor; belt and braces)
-			++cnt[v.f[i]], ++m;
-		}
-	const int64_t n_root = n - m;
-	const Pair64 some_root{ (uint64_t)p.kmer, ~0ULL };
-	tail.assign((size_t)m, some_root);
-	if (m == 0) return true;
-	// the slots [n_root, n) as they are before the sort; view entry i sits at position pos[i] (dense view: i)
-	int64_t first_tail = v.m;                          // first view entry at or behind n_root
-	if (!v.pos) first_tail = std::min<int64_t>(n_root, v.m);
-	else first_tail = std::lower_bound(v.pos, v.pos + v.m, (int32_t)std::min<int64_t>(n_root, INT32_MAX)) - v.pos;
-	for (int64_t i = first_tail; i < v.m; ++i) {
-		const int64_t q = v.pos ? v.pos[i] : i;
-		tail[(size_t)(q - n_root)] = Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i };
-	}
+	for (const SparseItem &it : items) ++cnt[it.e.x & 0xff];
+	const int64_t n_root = n - (int64_t)m;
+	out.resize(base + m, Pair64{ (uint64_t)k0, ~0ULL });
+	Pair64 *tail = out.data() + base;
+	// the slots [n_root, n) as they are before the pass
+	size_t first_tail = 0;
+	while (first_tail < m && items[first_tail].pos < n_root) ++first_tail;
+	for (size_t i = first_tail; i < m; ++i) tail[items[i].pos - n_root] = items[i].e;
 	size_t cursor[256], limit[256];
 	{
 		size_t at = 0;
 		for (int d = 0; d < 256; ++d) cursor[d] = at, at += cnt[d], limit[d] = at;
 	}
-	const int k0 = p.kmer;
 	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
-	for (int64_t i = 0; i < first_tail; ++i) {
-		if (v.pred[i] < 0) continue;
-		Pair64 carried{ (uint64_t)(int64_t)v.f[i], (uint64_t)i };
+	for (size_t i = 0; i < first_tail; ++i) {
+		Pair64 carried = items[i].e;
 		int d = (int)(carried.x & 0xff);
 		do {
 			const Pair64 placed = carried;
@@ -414,6 +406,95 @@ static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, s
 			d = (int)(carried.x & 0xff);
 		} while (d != k);
 		tail[cursor[k]++] = carried;
+	}
+}
+
+static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, std::vector<Pair64> &out)
+{
+	const int64_t n = v.n_total;
+	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return false;
+	static thread_local std::vector<SparseItem> items, moved, merged;
+	items.clear();
+	int32_t max_f = 0;
+	for (int64_t i = 0; i < v.m; ++i)
+		if (v.pred[i] >= 0) {
+			if (v.f[i] <= p.kmer) return false;           // (f > kmer always holds for a chained anchor; belt and braces)
+			max_f = std::max(max_f, v.f[i]);
+			items.push_back(SparseItem{ v.pos ? (int64_t)v.pos[i] : i, Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } });
+		}
+	out.clear();
+	if (max_f < 256) { replay_low_digit(n, p.kmer, items, out); return true; }
+	if (max_f >= 65536) return false;
+	// ---- two digit levels.  Level 1 (shift 8): bucket 0 = all scores below 256 (the roots among them) is the region
+	// [0, c0); walking it moves the high scores found there into the heads of their buckets behind c0, and what they
+	// displace from there -- low scores -- into the holes they leave.
+	size_t cnt8[256];
+	memset(cnt8, 0, sizeof(cnt8));
+	int64_t m_hi = 0;
+	for (const SparseItem &it : items) if (it.e.x >= 256) ++cnt8[it.e.x >> 8 & 0xff], ++m_hi;
+	const int64_t c0 = n - m_hi;
+	static thread_local std::vector<Pair64> tail8;
+	const uint64_t kAbsent = ~0ULL;
+	tail8.assign((size_t)m_hi, Pair64{ (uint64_t)p.kmer, kAbsent });
+	{	// slots [c0, n) as they are: every view element there, roots included (their identity never matters)
+		int64_t i = v.m;
+		if (!v.pos) i = std::min<int64_t>(c0, v.m);
+		else i = std::lower_bound(v.pos, v.pos + v.m, (int32_t)std::min<int64_t>(c0, INT32_MAX)) - v.pos;
+		for (; i < v.m; ++i) tail8[(size_t)((v.pos ? (int64_t)v.pos[i] : i) - c0)] = Pair64{ (uint64_t)(int64_t)v.f[i], v.pred[i] >= 0 ? (uint64_t)i : kAbsent };
+	}
+	size_t cursor[256], limit[256], start[256];
+	{
+		size_t at = 0;
+		for (int d = 0; d < 256; ++d) start[d] = cursor[d] = at, at += d ? cnt8[d] : 0, limit[d] = at;
+	}
+	moved.clear(), merged.clear();
+	for (const SparseItem &it : items) {
+		if (it.pos >= c0) break;
+		if (it.e.x < 256) continue;                        // a low score inside region 0 stays where it is
+		Pair64 carried = it.e;
+		int d = (int)(carried.x >> 8 & 0xff);
+		do {
+			const Pair64 placed = carried;
+			carried = tail8[cursor[d]];
+			tail8[cursor[d]++] = placed;
+			d = (int)(carried.x >> 8 & 0xff);
+		} while (d != 0);
+		if (carried.y != kAbsent) moved.push_back(SparseItem{ it.pos, carried });   // a chained anchor with a low score: it now sits in the hole
+	}
+	for (int k = 1; k < 256;) {                             // buckets 1..255 (same walk as pairs_digit_pass)
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(tail8[cursor[k]].x >> 8 & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = tail8[cursor[k]];
+		do {
+			const Pair64 placed = carried;
+			carried = tail8[cursor[d]];
+			tail8[cursor[d]++] = placed;
+			d = (int)(carried.x >> 8 & 0xff);
+		} while (d != k);
+		tail8[cursor[k]++] = carried;
+	}
+	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
+	{
+		size_t a = 0, b = 0;
+		while (a < items.size() && items[a].pos < c0) {
+			if (items[a].e.x >= 256) { ++a; continue; }
+			while (b < moved.size() && moved[b].pos < items[a].pos) merged.push_back(moved[b++]);
+			merged.push_back(items[a++]);
+		}
+		while (b < moved.size()) merged.push_back(moved[b++]);
+	}
+	if (c0 > 64) replay_low_digit(c0, p.kmer, merged, out);
+	else {                                                  // a short bucket is insertion-sorted: stable
+		std::stable_sort(merged.begin(), merged.end(), [](const SparseItem &x, const SparseItem &y) { return x.e.x < y.e.x; });
+		for (const SparseItem &it : merged) out.push_back(it.e);
+	}
+	// ---- level 2 inside the other buckets (all of it is present): digit pass or insertion sort, as the reference recurses
+	for (int d = 1; d < 256; ++d) {
+		Pair64 *b = tail8.data() + start[d], *e = b + cnt8[d];
+		if (cnt8[d] > 64) pairs_digit_pass(b, e, 0);
+		else if (cnt8[d] > 1) pairs_insertion(b, e);
+		out.insert(out.end(), b, e);
 	}
 	return true;
 }

@@ -34,6 +34,20 @@ def _anchors(rng, n, n_block, qlen, n_planted):
     return np.unique(a)
 
 
+def _long_chains(rng, n_block, n_copies, where):
+    """the same long collinear fragment (chain score well above 255) planted several times: equal high scores, placed at
+    the start / end / anywhere of the block range so that they fall inside and behind the first bucket's region"""
+    m = int(rng.choice([50, 90, 160]))
+    dq = np.cumsum(rng.integers(1, 4, m))
+    out = []
+    for c in range(n_copies):
+        b0 = {"start": 3 + 40 * c, "end": n_block - 400 + 40 * c, "any": int(rng.integers(0, n_block - 100))}[where]
+        jitter = 0 if rng.random() < 0.6 else int(rng.integers(0, 2))
+        x = (b0 + (dq * 3) // 256).astype(np.uint64)
+        out.append((x << np.uint64(32)) | (10 + jitter + dq).astype(np.uint64))
+    return np.concatenate(out)
+
+
 def test_chain_anchors_matches_oracle(oracle_built):
     o, L = refbind.ora(), mpa.lib()
     L.mpa_dbg_chain.restype = C.c_int32
@@ -43,8 +57,8 @@ def test_chain_anchors_matches_oracle(oracle_built):
     rng = np.random.default_rng(11)
     pre = [256, 256, 256, 25, 1000000, 2, 0, 0.75, 1, 6, 8]
     n_sparse = 0
-    for it in range(300):
-        kind = it % 4
+    for it in range(360):
+        kind = it % 5
         if kind == 0:     # sparse: almost every anchor is alone (the large-genome regime), a few chains
             a = _anchors(rng, int(rng.choice([70, 500, 5000, 60000])), 3000000, 400, int(rng.choice([0, 3, 40])))
         elif kind == 1:   # dense: everything chains with everything, many ties
@@ -53,6 +67,9 @@ def test_chain_anchors_matches_oracle(oracle_built):
             a = _anchors(rng, 2000, 3000000, 400, 0)
             hot = _anchors(rng, 300, 40, 300, 30) + (np.uint64(0 if rng.random() < 0.5 else 2999000) << np.uint64(32))
             a = np.unique(np.concatenate([a, hot]))
+        elif kind == 4:   # equal chain scores above 255 (two digit levels of the chain-end sort), few or many other anchors
+            bg = _anchors(rng, int(rng.choice([0, 40, 3000, 40000])), 3000000, 900, int(rng.choice([0, 30])))
+            a = np.unique(np.concatenate([bg, _long_chains(rng, 3000000, int(rng.integers(1, 5)), str(rng.choice(["start", "end", "any"])))]))
         else:
             a = _anchors(rng, int(rng.choice([0, 1, 30, 64, 65, 66])), 2000, 200, 3)
         args = list(pre)
@@ -86,8 +103,8 @@ def test_prechain_through_sparse_view_matches_oracle(oracle_built):
     L.mpa_dbg_prechain_sparse.argtypes = [C.c_int32] * 3 + [C.c_float] + [C.c_int32] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     rng = np.random.default_rng(12)
     big_f = 0
-    for it in range(300):
-        kind = it % 5
+    for it in range(360):
+        kind = it % 6
         if kind == 0:
             a = _anchors(rng, int(rng.choice([70, 500, 5000, 60000])), 3000000, 400, int(rng.choice([0, 3, 40])))
         elif kind == 1:
@@ -101,6 +118,9 @@ def test_prechain_through_sparse_view_matches_oracle(oracle_built):
             dq = np.cumsum(rng.integers(1, 4, m))
             x = (5000 + (dq * 3) // 256).astype(np.uint64)
             a = np.unique(np.concatenate([_anchors(rng, 3000, 3000000, 900, 5), (x << np.uint64(32)) | (10 + dq).astype(np.uint64)]))
+        elif kind == 5:
+            bg = _anchors(rng, int(rng.choice([0, 40, 3000, 40000])), 3000000, 900, int(rng.choice([0, 30])))
+            a = np.unique(np.concatenate([bg, _long_chains(rng, 3000000, int(rng.integers(1, 5)), str(rng.choice(["start", "end", "any"])))]))
         else:
             a = _anchors(rng, int(rng.choice([0, 1, 30, 64, 65, 66])), 2000, 200, 3)
         max_iter = int(rng.choice([1000000, 1000000, 20]))
