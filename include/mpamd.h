@@ -212,7 +212,7 @@ int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_q
                        const mpa_result_t *r, char **out);
 
 /* mp_write_output() in full (format.c:453-473): PAF and/or GFF3 (MPA_MF_GFF, format.c:360-412) or GTF (MPA_MF_GTF,
- * format.c:414-451) according to opt->flag.  *id_io is the running hit counter of the output file (map.c:306): pass the
+ * format.c:414-451), plus the residue rows of --aln / --trans (MPA_MF_SHOW_RESIDUE / _TRANS, format.c:189-331), according to opt->flag.  *id_io is the running hit counter of the output file (map.c:306): pass the
  * same variable for every batch of a run, starting at 0.  The caller prints "##gff-version 3" once per file (map.c:338). */
 int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                           const mpa_result_t *r, int64_t *id_io, char **out);

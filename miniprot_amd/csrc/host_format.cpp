@@ -114,6 +114,87 @@ static void put_paf(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt
 	s.push_back('\n');
 }
 
+// --aln / --trans (format.c:189-331): the alignment as four parallel rows -- target nucleotides (##ATN), their
+// translation (##ATA), the match line (##AAS) and the query residues (##AQA) -- and the translated target alone (##STA).
+// One text column per nucleotide; introns in lower case, abridged to max_intron_flank bases on either side when long.
+static void put_residues(std::string &s, const mpa_idx_s *mi, const mpa_mapopt_t &opt, const char *aa, const mpa_hit_t &h, const uint32_t *cig)
+{
+	if (!h.has_aln) return;
+	static const char UC[] = "ACGTN", LC[] = "acgtn";
+	const char *i2c = "ARNDCQEGHILKMFPSTWYV*X";
+	const uint8_t *aa20 = tab_aa20();
+	const int32_t flank = opt.max_intron_flank;
+	std::vector<uint8_t> ntv((size_t)(h.ve - h.vs + 3));
+	const int64_t l_nt = fetch_nt(mi, (int32_t)h.vid, h.vs, h.ve + 3, ntv.data());   // three more bases when the contig has them
+	const uint8_t *nt = ntv.data();
+	std::string atn = "##ATN\t", ata = "##ATA\t", aas = "##AAS\t", aqa = "##AQA\t", sta = "##STA\t";
+	auto col = [&](char a, char b, char c, char d) { atn.push_back(a), ata.push_back(b), aas.push_back(c), aqa.push_back(d); };
+	auto match_char = [&](uint8_t t_aa, char q) {
+		const uint8_t q_aa = aa20[(uint8_t)q];
+		return t_aa == q_aa ? '|' : opt.mat[t_aa * opt.asize + q_aa] > 0 ? '+' : ' ';
+	};
+	int32_t nl = 0, al = h.qs;
+	for (int32_t k = 0; k < h.n_cigar; ++k) {
+		const int32_t op = cig[k] & 0xf, len = (int32_t)(cig[k] >> 4);
+		if (op == 0) {                                       // M: codon against residue
+			for (int32_t l = 0; l < len; ++l, nl += 3, ++al) {
+				const uint8_t t = codon_aa3(nt + nl);
+				sta.push_back(i2c[t]);
+				col(UC[nt[nl]], i2c[t], match_char(t, aa[al]), (char)toupper(aa[al]));
+				col(UC[nt[nl + 1]], '.', ' ', ' ');
+				col(UC[nt[nl + 2]], '.', ' ', ' ');
+			}
+		} else if (op == 1) {                                // I: residues without target
+			for (int32_t l = 0; l < len; ++l, ++al) col('-', '-', ' ', (char)toupper(aa[al])), col('-', '.', ' ', ' '), col('-', '.', ' ', ' ');
+		} else if (op == 2) {                                // D: codons without residue
+			for (int32_t l = 0; l < len; ++l, nl += 3) {
+				const uint8_t t = codon_aa3(nt + nl);
+				sta.push_back(i2c[t]);
+				col(UC[nt[nl]], i2c[t], ' ', '-'), col(UC[nt[nl + 1]], '.', ' ', ' '), col(UC[nt[nl + 2]], '.', ' ', ' ');
+			}
+		} else if (op == 10) {                               // F: frameshift deletion
+			for (int32_t l = 0; l < len; ++l, ++nl) col(UC[nt[nl]], '!', ' ', ' ');
+		} else if (op == 11) {                               // G: frameshift match, one residue over `len` bases
+			for (int32_t l = 0; l < len; ++l, ++nl) col(UC[nt[nl]], '$', ' ', l == 0 ? (char)toupper(aa[al]) : ' ');
+			++al;
+		} else if (op == 3 || op == 12 || op == 13) {        // N / U / V: intron in phase 0 / 1 / 2
+			const int32_t intron = op == 3 ? len : len - 3;
+			if (op != 3) {                                     // the split codon: 1 (U) or 2 (V) bases before the intron, the rest after
+				const uint8_t c3[3] = { nt[nl], op == 12 ? nt[nl + len - 2] : nt[nl + 1], nt[nl + len - 1] };
+				const uint8_t t = codon_aa3(c3);
+				sta.push_back(i2c[t]);
+				col(UC[nt[nl]], i2c[t], match_char(t, aa[al]), (char)toupper(aa[al]));
+				++nl;
+				if (op == 13) col(UC[nt[nl]], '.', ' ', ' '), ++nl;
+				++al;
+			}
+			if (intron <= flank * 2) {
+				for (int32_t l = 0; l < intron; ++l) col(LC[nt[nl + l]], ' ', ' ', ' ');
+			} else {
+				for (int32_t l = 0; l < flank; ++l) col(LC[nt[nl + l]], ' ', ' ', ' ');
+				col('~', ' ', ' ', ' ');
+				std::string num;
+				put_int(num, intron);
+				for (char ch : num) col(ch, ' ', ' ', ' ');
+				col('~', ' ', ' ', ' ');
+				for (int32_t l = 0; l < flank; ++l) col(LC[nt[nl + intron - flank + l]], ' ', ' ', ' ');
+			}
+			nl += intron;
+			if (op != 3) {
+				col(UC[nt[nl]], '.', ' ', ' '), ++nl;
+				if (op == 12) col(UC[nt[nl]], '.', ' ', ' '), ++nl;
+			}
+		}
+	}
+	if (l_nt == h.ve - h.vs + 3 && sta.back() != '*') {       // one more codon: the stop, if the alignment ends right before it
+		const uint8_t t = codon_aa3(nt + nl);
+		sta.push_back(i2c[t]);
+		col(UC[nt[nl]], i2c[t], ' ', ' '), col(UC[nt[nl + 1]], '.', ' ', ' '), col(UC[nt[nl + 2]], '.', ' ', ' ');
+	}
+	if (opt.flag & MPA_MF_SHOW_RESIDUE) s += atn, s += '\n', s += ata, s += '\n', s += aas, s += '\n', s += aqa, s += '\n';
+	if (opt.flag & MPA_MF_SHOW_TRANS) s += sta, s += '\n';
+}
+
 static void put_id(std::string &s, const char *prefix, const char *mid, int64_t id)     // "%s<mid>%.6ld"
 {
 	char buf[32];
@@ -242,9 +323,13 @@ static int64_t format_batch(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const 
 		for (int64_t j = 0; j < n_reg && j < opt->out_n; ++j) {
 			if (!passes(i, j, best_sc)) continue;
 			++id;
-			if (opt->flag & MPA_MF_GTF) put_gtf(s, mi, *opt, qlen, h[j], feats + h[j].feat_off, id);
-			else {
+			const bool residues = (opt->flag & (MPA_MF_SHOW_RESIDUE | MPA_MF_SHOW_TRANS)) != 0;
+			if (opt->flag & MPA_MF_GTF) {
+				if (residues) put_paf(s, mi, *opt, names[i], seq, qlen, &h[j], cig), put_residues(s, mi, *opt, seq, h[j], cig + h[j].cigar_off);
+				put_gtf(s, mi, *opt, qlen, h[j], feats + h[j].feat_off, id);
+			} else {
 				if (!(opt->flag & MPA_MF_NO_PAF)) put_paf(s, mi, *opt, names[i], seq, qlen, &h[j], cig);
+				if (residues) put_residues(s, mi, *opt, seq, h[j], cig + h[j].cigar_off);
 				if (opt->flag & MPA_MF_GFF) put_gff(s, mi, *opt, names[i], qlen, h[j], feats + h[j].feat_off, id, (int32_t)j + 1);
 			}
 		}
@@ -285,6 +370,5 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 extern "C" int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                                      const mpa_result_t *r, int64_t *id_io, char **out)
 {
-	if (opt->flag & (MPA_MF_SHOW_RESIDUE | MPA_MF_SHOW_TRANS)) { set_error("--aln/--trans output is not implemented"); *out = nullptr; return MPA_ERR_UNSUPPORTED; }
 	return format_batch(mi, opt, q, names, r, id_io, out);
 }

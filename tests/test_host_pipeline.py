@@ -87,6 +87,16 @@ def test_dpp3_gff_identical(oracle_built):
     assert hashlib.md5(out).hexdigest() == "d08d9caa27b8bd896ee4f14824597c54"
 
 
+def test_dpp3_aln_trans_gtf_identical(oracle_built):
+    """config 1 with --aln --trans --gtf: PAF line + residue rows (##ATN/##ATA/##AAS/##AQA), translation (##STA), GTF"""
+    idx = mpa.Index.from_fasta(golden.path("DPP3-hs.gen.fa.gz"))
+    names, seqs = read_fasta(golden.path("DPP3-mm.pep.fa.gz"))
+    mo = mpa.default_mapopt()
+    mo.flag |= 0x80 | 0x100 | 0x20
+    out = map_batch(idx, mo, mpa.Queries(seqs, names), oracle_executor)
+    assert out == open(golden.path("dpp3_aln_trans_gtf.ref.txt"), "rb").read()
+
+
 @pytest.mark.parametrize("case", golden.SYNTH_CASES, ids=[c["name"] for c in golden.SYNTH_CASES])
 def test_synthetic_paf_identical(oracle_built, case):
     contigs, prots, names = golden.synth_inputs(case)
