@@ -37,6 +37,8 @@ extern "C" {
 #define MPA_F_CIGAR      0x1
 #define MPA_F_EXT_LEFT   0x2
 #define MPA_F_EXT_RIGHT  0x4
+#define MPA_F_SS_SKIP0   0x8   /* splice-score track only: nt_off is the first position of the window the reference cut its ss[] for
+                                  (align.c:270-274); mp_ntseq_spsc_get() never sets the score of that position (ntseq.c:144-151) */
 
 /* mapping flags = MP_F_* (miniprot.h:8-17) */
 #define MPA_MF_NO_SPLICE    0x1
@@ -103,6 +105,12 @@ int64_t mpa_idx_genome_len(const mpa_idx_t *mi);                /* nt->l_seq */
 const mpa_idxopt_t *mpa_idx_opt(const mpa_idx_t *mi);
 /* mp_ntseq_get_by_v (ntseq.c:108-114): nt4 codes of [st,en) on strand-oriented contig vid=cid<<1|rev */
 int64_t mpa_idx_get_nt(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out);
+/* --spsc (mp_ntseq_read_spsc ntseq.c:234-296 + mp_set_spsc index.c:239-248): read splice scores "ctg offset +|- D|A score"
+ * (plain or gzip) into a per-strand track, clamp them to the bound mp_set_spsc derives from *mo, and unless keep_io raise
+ * mo->io / io_end by 10.  Call before mpa_idx_to_device().  Returns the number of scores kept or a negative error code. */
+int64_t mpa_idx_set_spsc(mpa_idx_t *mi, const char *fn, mpa_mapopt_t *mo, int keep_io);
+/* mp_ntseq_spsc_get_by_v (ntseq.c:153-159): the ss[] bytes of [st,en) on vid; 0xff = no score, else (score+64)<<1 | is_acceptor */
+int64_t mpa_idx_get_spsc(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out);
 /* upload the packed genome (and later the k-mer index) to the context's device; idempotent */
 int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi);
 
@@ -113,6 +121,7 @@ typedef struct {
 	int32_t sp[6];                  /* already scaled (align.c:59) */
 	float ie_coef;
 	int8_t mat[484];
+	int32_t sp_null_bonus;          /* with a splice-score track: what a position without a score costs (nasw-sse.c:143-146) */
 } mpa_dpopt_t;
 void mpa_dpopt_from_mapopt(const mpa_mapopt_t *mo, mpa_dpopt_t *dp);  /* mp_map2ns_opt, align.c:50-60 */
 

@@ -46,7 +46,8 @@ class MapOpt(C.Structure):
 
 class DpOpt(C.Structure):
     _fields_ = [("go", C.c_int32), ("ge", C.c_int32), ("fs", C.c_int32), ("xdrop", C.c_int32),
-                ("end_bonus", C.c_int32), ("sp", C.c_int32 * 6), ("ie_coef", C.c_float), ("mat", C.c_int8 * 484)]
+                ("end_bonus", C.c_int32), ("sp", C.c_int32 * 6), ("ie_coef", C.c_float), ("mat", C.c_int8 * 484),
+                ("sp_null_bonus", C.c_int32)]
 
 
 class QBatch(C.Structure):
@@ -121,6 +122,8 @@ def lib():
             ("mpa_result_hit_off", C.POINTER(C.c_int64), [C.c_void_p]),
             ("mpa_result_cigars", C.POINTER(C.c_uint32), [C.c_void_p]),
             ("mpa_result_destroy", None, [C.c_void_p]),
+            ("mpa_idx_set_spsc", C.c_int64, [C.c_void_p, C.c_char_p, C.POINTER(MapOpt), C.c_int]),
+            ("mpa_idx_get_spsc", C.c_int64, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
             ("mpa_map_batches", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MapOpt), C.c_int32, C.POINTER(QBatch),
                                           C.POINTER(C.POINTER(C.c_char_p)), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
@@ -235,6 +238,22 @@ class Index:
 
     def genome_len(self):
         return lib().mpa_idx_genome_len(self.h)
+
+    has_spsc = False
+
+    def set_spsc(self, path, mo, keep_io=False):
+        """--spsc: load a splice-score file (mp_set_spsc); adjusts mo.io / mo.io_end unless keep_io.  Before to_device()."""
+        n = lib().mpa_idx_set_spsc(self.h, path.encode(), C.byref(mo), 1 if keep_io else 0)
+        if n < 0:
+            raise MpaError(last_error())
+        self.has_spsc = True
+        return n
+
+    def get_spsc(self, vid, st, en):
+        """the ss[] bytes the reference hands the DP for the window [st,en) of vid, or None without a track"""
+        out = np.zeros(max(en - st, 1), dtype=np.uint8)
+        n = lib().mpa_idx_get_spsc(self.h, vid, st, en, out.ctypes.data)
+        return None if n < 0 else out[:n]
 
     def get_nt(self, vid, st, en):
         buf = np.zeros(max(en - st, 0), dtype=np.uint8)

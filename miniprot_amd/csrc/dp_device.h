@@ -62,12 +62,15 @@ struct GlobWave {
 struct DpConst {         // scalar scoring parameters, passed by value
 	int32_t go, ge, fs, xdrop, end_bonus;
 	int32_t sp[6];
+	int32_t sp_null_bonus;   // splice-score track only
 };
 
 struct DevGenome {
 	const uint8_t *seq;      // 4-bit packed genome
 	const int64_t *ctg_off;  // [n_ctg]
 	const int64_t *ctg_len;  // [n_ctg]
+	const uint8_t *spsc;     // splice-score track [2][l_seq] or nullptr (--spsc)
+	int64_t l_seq;
 };
 
 } // namespace mpa

@@ -48,6 +48,7 @@ struct DeviceIndex {
 	uint8_t *seq = nullptr;
 	int64_t *ctg_off = nullptr, *ctg_len = nullptr;
 	uint32_t *kb = nullptr;                   // k-mer occurrence lists (block ids), uploaded on first GPU seeding call
+	uint8_t *spsc = nullptr;                  // splice-score track (--spsc), uploaded with the genome when the index has one
 };
 
 struct HostPinned {
@@ -110,6 +111,10 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	HIP_TRY(hipMemcpy(d->seq, mi->seq.data(), mi->seq.size(), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(d->ctg_off, off.data(), n * 8, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(d->ctg_len, len.data(), n * 8, hipMemcpyHostToDevice));
+	if (!mi->spsc.empty()) {
+		HIP_TRY(hipMalloc((void**)&d->spsc, mi->spsc.size() + 16));
+		HIP_TRY(hipMemcpy(d->spsc, mi->spsc.data(), mi->spsc.size(), hipMemcpyHostToDevice));
+	}
 	mi->dev = d;
 	return MPA_OK;
 }
@@ -120,6 +125,7 @@ void dev_free_index(mpa_idx_s *mi)
 	(void)hipSetDevice(mi->dev->device);
 	(void)hipFree(mi->dev->seq); (void)hipFree(mi->dev->ctg_off); (void)hipFree(mi->dev->ctg_len);
 	if (mi->dev->kb) (void)hipFree(mi->dev->kb);
+	if (mi->dev->spsc) (void)hipFree(mi->dev->spsc);
 	delete mi->dev;
 	mi->dev = nullptr;
 }
@@ -587,7 +593,8 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	DpConst dc;
 	dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
 	for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
-	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len };
+	dc.sp_null_bonus = opt->sp_null_bonus;
+	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, mi->dev->spsc, mi->l_seq };
 
 	// ---- K3: per-row records and profiles
 	HIP_TRY(hipEventRecord(ctx->ev[0], s));

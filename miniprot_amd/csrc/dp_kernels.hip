@@ -234,6 +234,33 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 		}
 	}
 #undef B_
+	if (g.spsc) {
+		// --spsc: the score track adjusts the penalties (nasw-sse.c:138-152, left: 189-203).  ss[p] belongs to window position p
+		// (forward); forward calls shift it onto donor/acceptor[p-1], the reversed left extension onto [nl-1-p] with the two
+		// roles swapped.  int8 wrap-around as in the reference's arrays.
+		const uint8_t *track = g.spsc + (rev ? g.l_seq : 0) + off;
+		const int32_t max_spsc = (t.io + 1) / 2 - 1;
+		auto ss_at = [&](int32_t p) -> int32_t {             // -1: outside what the reference reads
+			if (p < (left ? 0 : 1) || p >= nl) return -1;
+			if (p == 0 && (t.flag & 8)) return 0xff;           // MPA_F_SS_SKIP0
+			return track[t.nt_off + p];
+		};
+		auto adjust = [&](int32_t v, int32_t ss, bool for_acceptor_entry) -> int32_t {
+			if (ss < 0) return v;
+			if (ss == 0xff) return (int8_t)(v - c.sp_null_bonus);
+			if (((ss & 1) != 0) != for_acceptor_entry) return v;
+			int32_t spsc = (int8_t)(ss >> 1) - 64;
+			if (spsc > max_spsc) spsc = max_spsc;
+			return (int8_t)(v - spsc);
+		};
+		if (!left) {
+			don = adjust(don, ss_at(i + 2), false);          // donor[i+1] <- ss[i+2] (donor entries)
+			acc = adjust(acc, ss_at(i + 1), true);           // acceptor[i] <- ss[i+1] (acceptor entries)
+		} else {
+			don = adjust(don, ss_at(nl - 2 - i), true);      // "donor"[i+1] of the reversed string <- acceptor entries at nl-1-(i+1)
+			acc = adjust(acc, ss_at(nl - 1 - i), false);     // "acceptor"[i] <- donor entries at nl-1-i
+		}
+	}
 	rec[t.rec_off + i] = make_rec(nas * PROF_AA_STRIDE_REC, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
 }
 

@@ -620,7 +620,7 @@ static void plan_round1(mpa_batch_s *b, QueryState &qs)
 		AlignPlan &pl = qs.plans[pi];
 		const Region &r = qs.regs[pl.reg];
 		pl.t_left = (int32_t)qs.local1.size();
-		qs.local1.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT, opt.io));
+		qs.local1.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT | MPA_F_SS_SKIP0, opt.io));   // starts at the window's first position
 		if (pl.has_right) {
 			pl.t_right = (int32_t)qs.local1.size();
 			qs.local1.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
@@ -662,7 +662,7 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, con
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
 				pl.t_left2 = (int32_t)next.size();
-				next.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT, opt.io_end));
+				next.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT | (as_alt == pl.as ? MPA_F_SS_SKIP0 : 0), opt.io_end));
 			}
 			if (pl.has_right) {
 				pl.r_nt = mine[pl.t_right].nt_len, pl.r_aa = mine[pl.t_right].aa_len;

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <thread>
+#include <zlib.h>
+#include <unordered_map>
 #include "mpa_internal.h"
 #include "host_core.h"
 
@@ -217,5 +219,78 @@ const char *mpa_idx_ctg_name(const mpa_idx_t *mi, int32_t cid) { return mi->ctg[
 int64_t mpa_idx_genome_len(const mpa_idx_t *mi) { return mi->l_seq; }
 const mpa_idxopt_t *mpa_idx_opt(const mpa_idx_t *mi) { return &mi->opt; }
 int64_t mpa_idx_get_nt(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out) { return fetch_nt(mi, vid, st, en, out); }
+
+// mp_set_spsc (index.c:239-248) + mp_ntseq_read_spsc (ntseq.c:234-296).  The reference keeps sorted (position, score) lists
+// per strand and expands them per alignment window; here the track is dense, one byte per strand-local position (0xff = no
+// score, else (score + 64) << 1 | is_acceptor, the larger byte winning where several lines name a position), so that the
+// device can index it directly.
+int64_t mpa_idx_set_spsc(mpa_idx_t *mi, const char *fn, mpa_mapopt_t *mo, int keep_io)
+{
+	if (!fn) return 0;
+	if (!keep_io) mo->io += 10, mo->io_end += 10;
+	int32_t max_sc = (mo->io + 1) / 2 - 1;
+	if (max_sc > mo->io - mo->go) max_sc = mo->io - mo->go;
+	if (max_sc > mo->sp_max_bonus) max_sc = mo->sp_max_bonus;
+	if (max_sc > 63) max_sc = 63;
+	gzFile fp = gzopen(fn, "rb");
+	if (!fp) { set_error(std::string("cannot open ") + fn); return MPA_ERR_IO; }
+	std::unordered_map<std::string, int32_t> cid_of;
+	for (size_t i = 0; i < mi->ctg.size(); ++i) cid_of.emplace(mi->ctg[i].name, (int32_t)i);
+	mi->spsc.assign((size_t)mi->l_seq * 2, 0xff);
+	if (mi->dev) dev_free_index(mi);                         // a resident copy without the track is stale
+	int64_t n_kept = 0;
+	std::string line;
+	char buf[65536];
+	auto take_line = [&]() -> bool {                        // one line of any length, without its terminator
+		line.clear();
+		for (;;) {
+			if (!gzgets(fp, buf, sizeof(buf))) return !line.empty();
+			line += buf;
+			if (!line.empty() && line.back() == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+		}
+	};
+	while (take_line()) {
+		const char *f[5];
+		int n_f = 0;
+		f[n_f++] = line.c_str();
+		for (size_t k = 0; k < line.size() && n_f < 5; ++k) if (line[k] == '\t') line[k] = 0, f[n_f++] = line.c_str() + k + 1;
+		if (n_f < 5) continue;                               // not enough fields
+		{	// the fifth field ends at the next tab, if any
+			char *e = const_cast<char*>(strchr(f[4], '\t'));
+			if (e) *e = 0;
+		}
+		const int64_t pos_in = atol(f[1]);
+		const int strand = f[2][0] == '+' ? 1 : -1;          // (ntseq.c:262: anything but '+' counts as the reverse strand)
+		const int type = f[3][0] == 'D' ? 0 : f[3][0] == 'A' ? 1 : -1;
+		int32_t score = atoi(f[4]);
+		if (score > max_sc) score = max_sc;
+		if (score < -max_sc) score = -max_sc;
+		auto it = cid_of.find(f[0]);
+		if (it == cid_of.end() || type < 0 || pos_in < 0) continue;
+		const Contig &c = mi->ctg[it->second];
+		const int64_t pos = strand < 0 ? c.len - pos_in : pos_in;
+		if (pos > 0 && pos < c.len) {                        // scores at the contig ends are ignored
+			uint8_t &slot = mi->spsc[(size_t)(strand > 0 ? 0 : mi->l_seq) + (size_t)(c.off + pos)];
+			const uint8_t v = (uint8_t)((score + 64) << 1 | type);
+			if (slot == 0xff || slot < v) slot = v;
+			++n_kept;
+		}
+	}
+	gzclose(fp);
+	return n_kept;
+}
+
+int64_t mpa_idx_get_spsc(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out)
+{
+	const int32_t cid = vid >> 1;
+	if (mi->spsc.empty() || cid < 0 || cid >= (int32_t)mi->ctg.size()) return -1;
+	const Contig &c = mi->ctg[cid];
+	if (st < 0 || en < 0 || st >= c.len) return -1;
+	if (en > c.len) en = c.len;
+	memset(out, 0xff, (size_t)(en - st));
+	const uint8_t *t = mi->spsc.data() + (size_t)((vid & 1) ? mi->l_seq : 0) + (size_t)c.off;
+	for (int64_t p = st + 1; p < en; ++p) out[p - st] = t[p];       // the window's first position never gets a score (ntseq.c:144-151)
+	return en - st;
+}
 
 } // extern "C"

@@ -46,6 +46,7 @@ struct mpa_idx_s {
 	std::vector<uint32_t> kb;        // global block ids
 	std::vector<uint32_t> bo;        // per (contig,strand) block offset, 2*n_ctg+1 entries (index.c:11-26)
 	uint32_t n_block = 0;
+	std::vector<uint8_t> spsc;       // splice-score track (--spsc), empty if none: [strand][l_seq], indexed by contig offset + strand-local position
 	mpa::DeviceIndex *dev = nullptr; // genome resident in HBM (set by mpa_idx_to_device)
 };
 

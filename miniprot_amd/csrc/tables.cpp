@@ -178,7 +178,7 @@ void mpa_dpopt_from_mapopt(const mpa_mapopt_t *mo, mpa_dpopt_t *dp)
 	static const int32_t models[3][6] = { {0,0,0,0,0,0}, {8,15,21,30,0,0}, {8,15,21,30,4,4} };
 	int m = mo->sp_model < 0 || mo->sp_model > 2 ? 0 : mo->sp_model;
 	dp->go = mo->go, dp->ge = mo->ge, dp->fs = mo->fs, dp->xdrop = mo->xdrop, dp->end_bonus = mo->end_bonus;
-	dp->ie_coef = mo->ie_coef;
+	dp->ie_coef = mo->ie_coef, dp->sp_null_bonus = mo->sp_null_bonus;
 	for (int i = 0; i < 6; ++i) dp->sp[i] = (int32_t)(models[m][i] * mo->sp_scale + .499f);
 	memcpy(dp->mat, mo->mat, 484);
 }

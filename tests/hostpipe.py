@@ -37,7 +37,17 @@ def oracle_executor(idx, queries, dpopt, tasks):
         aa = queries.seqs[int(t["qid"])][int(t["aa_off"]): int(t["aa_off"]) + int(t["al"])]
         P = refbind.DpParams(mat, go=dpopt.go, ge=dpopt.ge, io=int(t["io"]), fs=dpopt.fs, xdrop=dpopt.xdrop,
                              end_bonus=dpopt.end_bonus, sp=tuple(dpopt.sp), ie_coef=dpopt.ie_coef)
-        nt_len, aa_len, score, cig = refbind.ora_nasw(bytes(nt), aa, P, int(t["flag"]))
+        ss = None
+        if idx.has_spsc:
+            # the reference cuts ss[] once per alignment window and hands sub-windows to the DP (align.c:270-327): every position
+            # but the window's first carries its score; MPA_F_SS_SKIP0 marks the calls that start at that first position
+            st = int(t["nt_off"])
+            ss = idx.get_spsc(int(t["vid"]), st - 1, st + int(t["nl"]))[1:] if st > 0 else idx.get_spsc(int(t["vid"]), 0, int(t["nl"]))
+            ss = ss.copy()
+            if int(t["flag"]) & 8:
+                ss[0] = 0xff
+            P.sp_null_bonus = dpopt.sp_null_bonus
+        nt_len, aa_len, score, cig = refbind.ora_nasw(bytes(nt), aa, P, int(t["flag"]) & 7, ss)
         rst[k] = (nt_len, aa_len, score, len(cig), len(pool))
         pool.extend(cig)
     return rst, np.array(pool if pool else [0], dtype=np.uint32)

@@ -98,11 +98,14 @@ def test_dpp3_aln_trans_gtf_identical(oracle_built):
 
 
 @pytest.mark.parametrize("case", golden.SYNTH_CASES, ids=[c["name"] for c in golden.SYNTH_CASES])
-def test_synthetic_paf_identical(oracle_built, case):
+def test_synthetic_paf_identical(oracle_built, case, tmp_path):
     contigs, prots, names = golden.synth_inputs(case)
     idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
-    paf = map_batch(idx, golden.mapopt_for(case), mpa.Queries(prots, names), oracle_executor, n_threads=4)
+    mo = golden.mapopt_for(case)
+    if "spsc" in case:
+        idx.set_spsc(golden.write_spsc(case, contigs, str(tmp_path / "spsc.tsv")), mo)
+    paf = map_batch(idx, mo, mpa.Queries(prots, names), oracle_executor, n_threads=4)
     paf = golden.file_header(case) + paf
     ref = open(golden.path(case["name"] + ".ref.paf"), "rb").read()
     if paf != ref:

@@ -45,7 +45,8 @@ def main():
             fa, faa = os.path.join(tmp, "g.fa"), os.path.join(tmp, "p.fa")
             gen_synth.write_fasta_nt(fa, contigs)
             gen_synth.write_fasta_aa(faa, prots, names)
-            out = run_ref(case["flags"] + [fa, faa])
+            extra = ["--spsc=" + golden.write_spsc(case, contigs, os.path.join(tmp, "spsc.tsv"))] if "spsc" in case else []
+            out = run_ref(case["flags"] + extra + [fa, faa])
             open(golden.path(case["name"] + ".ref.paf"), "wb").write(out)
             print(case["name"], len(out), "bytes", out.count(b"\n"), "lines")
     # DP vectors
