@@ -101,3 +101,34 @@ def test_extension_that_saturates_int16(ctx, oracle_built):
     pairs = [make_task(rng, al=3300, p_indel=0.001, flank=50),              # cannot use the packed kernels (al * max score > 32000), no saturation yet
              make_task(rng, al=6800, p_indel=0.0, p_sub=0.0, p_intron=0.0, p_fs=0.0, p_n=0.0, flank=40)]     # identical: the score runs into the int16 ceiling
     run_case(ctx, pairs, P, rng, modes=("right", "left"))
+
+
+def test_splice_score_track(ctx, oracle_built, tmp_path):
+    """--spsc at the operator level: the track resident next to the genome, applied by k_prep_rows, against the oracle fed
+    the same ss[] bytes per call (all three modes, both strands, with and without MPA_F_SS_SKIP0)"""
+    import golden
+    from dputil import build_workload, dpopt_from_params, compare
+    rng = np.random.default_rng(18)
+    P = refbind.DpParams(refbind.mapping_matrix(23), io=39, sp_null_bonus=-7)
+    pairs = [make_task(rng, max_intron=600, flank=int(rng.choice([20, 200]))) for _ in range(160)]
+    contigs, queries, tasks, meta = build_workload(pairs, rng, io=39, io_alt=29)
+    tasks["flag"] |= np.where((tasks["flag"] == mpa.F_EXT_LEFT) & (rng.random(len(tasks)) < 0.5), 8, 0).astype(tasks["flag"].dtype)
+    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
+    mo = mpa.default_mapopt()
+    idx.set_spsc(golden.write_spsc({"spsc": 77}, contigs, str(tmp_path / "s.tsv")), mo, keep_io=True)
+    idx.to_device(ctx)
+    dp = dpopt_from_params(P)
+    dp.sp_null_bonus = P.sp_null_bonus
+    rst, cig = mpa.dp_run(ctx, idx, dp, queries, tasks)
+    expect = []
+    for t, (k, fl, io) in zip(tasks, meta):
+        st, nl, vid = int(t["nt_off"]), int(t["nl"]), int(t["vid"])
+        ss = (idx.get_spsc(vid, st - 1, st + nl)[1:] if st > 0 else idx.get_spsc(vid, 0, nl)).copy()
+        if int(t["flag"]) & 8:
+            ss[0] = 0xff
+        PP = refbind.DpParams(P.mat, io=io, sp_null_bonus=P.sp_null_bonus)
+        nt = bytes(idx.get_nt(vid, st, st + nl))
+        expect.append(refbind.ora_nasw(nt, pairs[k][1], PP, fl, ss))
+    bad, msg = compare(rst, cig, expect, meta, pairs)
+    idx.close()
+    assert not bad, "%d/%d DP calls differ from the oracle\n%s" % (len(bad), len(tasks), msg)
