@@ -69,6 +69,8 @@ struct HostPinned {
 struct SeedBufs {
 	DevBuf jobs, key[2], val[2], f, pred, mark, flag, idx, tmp, qfirst, cfirst, o_pos, o_f, o_pred, o_a;
 	HostPinned h_jobs, h_pos, h_f, h_pred, h_a;
+	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
+	HostPinned h_rhits;
 };
 
 
@@ -403,6 +405,78 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
 	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
 	timing_note("    seed: compact + download", now_ms() - t_kernels);
+	return MPA_OK;
+}
+} // namespace mpa
+
+namespace mpa {
+// Refinement scan of a mini-batch's region windows on the device (k_refine_scan).  qw_first/qwords: the distinct k-mer words
+// of every query.  out.first[w] .. out.first[w+1]: the hits (hash << 32 | window position) of window w, unsorted.
+// MPA_ERR_UNSUPPORTED (the caller scans on the host): a query with more words than the LDS hash set takes, k too large.
+int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t n_query, const int64_t *qw_first, const uint32_t *qwords,
+                    int64_t n_win, const RefineWindow *wins, RefineHits &out)
+{
+	out.first.assign((size_t)n_win + 1, 0);
+	out.hits.clear();
+	if (n_win == 0) return MPA_OK;
+	if (kmer < 1 || kmer > 7 || min_aa_len > (REFINE_HALO - 3 * kmer) / 3 + kmer) { set_error("refinement scan: parameters outside the device kernel's range"); return MPA_ERR_UNSUPPORTED; }
+	int64_t max_words = 0;
+	for (int32_t q = 0; q < n_query; ++q) max_words = std::max(max_words, qw_first[q + 1] - qw_first[q]);
+	int hs_log2 = 10;
+	while ((1LL << hs_log2) < 2 * max_words) ++hs_log2;
+	if (hs_log2 > 13) { set_error("refinement scan: query too long for the LDS k-mer set"); return MPA_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
+	SeedBufs &B = ctx->seed;
+	if (!ctx->seed_stream) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
+	}
+	hipStream_t s = ctx->seed_stream;
+	std::vector<RefineWindowDev> dw((size_t)n_win);
+	std::vector<RefineChunk> chunks;
+	int64_t n_pos = 0;
+	for (int64_t k = 0; k < n_win; ++k) {
+		dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
+		for (int32_t st = 0; st < wins[k].len; st += REFINE_CHUNK) chunks.push_back(RefineChunk{ (int32_t)k, st });
+		n_pos += wins[k].len;
+	}
+	if (chunks.empty()) return MPA_OK;
+	const unsigned long long cap = (unsigned long long)(n_pos / 64 + (1 << 20));   // ~0.04 % of the positions hit on random sequence
+	const int64_t n_words = qw_first[n_query];
+	int rc;
+	if ((rc = B.r_win.ensure(dw.size() * sizeof(RefineWindowDev))) || (rc = B.r_chunk.ensure(chunks.size() * sizeof(RefineChunk))) ||
+	    (rc = B.r_qfirst.ensure(((size_t)n_query + 1) * 8)) || (rc = B.r_words.ensure((size_t)n_words * 4 + 16)) ||
+	    (rc = B.r_hits.ensure((size_t)cap * 16)) || (rc = B.r_count.ensure(16))) return rc;
+	HIP_TRY(hipMemcpyAsync(B.r_win.p, dw.data(), dw.size() * sizeof(RefineWindowDev), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(B.r_chunk.p, chunks.data(), chunks.size() * sizeof(RefineChunk), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(B.r_qfirst.p, qw_first, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(B.r_words.p, qwords, (size_t)n_words * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(B.r_count.p, 0, 16, s));
+	RefineTab rt;
+	for (int c = 0; c < 64; ++c) rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
+	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, nullptr, mi->l_seq };
+	const size_t lds = ((size_t)4 << hs_log2) + REFINE_CHUNK + 2 * REFINE_HALO;
+	HIP_TRY(hipStreamSynchronize(s));                       // (dw / chunks are locals)
+	hipLaunchKernelGGL(k_refine_scan, dim3((unsigned)chunks.size()), dim3(256), lds, s, dg, B.r_win.as<RefineWindowDev>(), B.r_chunk.as<RefineChunk>(),
+	                   B.r_qfirst.as<int64_t>(), B.r_words.as<uint32_t>(), rt, kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap);
+	HIP_TRY(hipGetLastError());
+	unsigned long long n_hits = 0;
+	HIP_TRY(hipMemcpyAsync(&n_hits, B.r_count.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (n_hits > cap) { set_error("refinement scan: more hits than the buffer holds"); return MPA_ERR_UNSUPPORTED; }
+	if (n_hits == 0) return MPA_OK;
+	if ((rc = B.h_rhits.ensure((size_t)n_hits * 16)) != MPA_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(B.h_rhits.p, B.r_hits.p, (size_t)n_hits * 16, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	// group by window (counting sort)
+	const uint4 *h = B.h_rhits.as<uint4>();
+	for (unsigned long long k = 0; k < n_hits; ++k) ++out.first[(size_t)h[k].x + 1];
+	for (int64_t k = 0; k < n_win; ++k) out.first[(size_t)k + 1] += out.first[(size_t)k];
+	out.hits.resize((size_t)n_hits);
+	std::vector<int64_t> at(out.first.begin(), out.first.end() - 1);
+	for (unsigned long long k = 0; k < n_hits; ++k) out.hits[(size_t)at[h[k].x]++] = (uint64_t)h[k].z << 32 | h[k].y;
 	return MPA_OK;
 }
 } // namespace mpa

@@ -280,6 +280,14 @@ void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32
 	if (i < len) step(i, 1), ++i;
 	if (i < len) step(i, 2), ++i;
 	close(0), close(1), close(2);
+	refine_pairs_from_hits(hits, qk, max_ava, a);
+}
+
+// second half of the refinement seeding: hits = (hash << 32 | window position) of the window k-mers whose hash the query
+// has, in any order (sorted here); all pairs per hash unless there are too many (map.c:112-125)
+void refine_pairs_from_hits(std::vector<uint64_t> &hits, const std::vector<uint64_t> &qk, int32_t max_ava, std::vector<uint64_t> &a)
+{
+	a.clear();
 	if (hits.empty()) return;
 	sort_u64(hits.data(), hits.data() + hits.size());
 	size_t q0 = 0;

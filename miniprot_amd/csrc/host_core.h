@@ -28,6 +28,8 @@ void sketch_nt4(const uint8_t *seq, int64_t len, int32_t min_aa_len, int32_t kme
 void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32_t kmer, const std::vector<uint64_t> &qk_sorted,
                        const uint64_t *filter, int32_t max_ava, std::vector<uint64_t> &hits_scratch, std::vector<uint64_t> &a);
 
+void refine_pairs_from_hits(std::vector<uint64_t> &hits, const std::vector<uint64_t> &qk_sorted, int32_t max_ava, std::vector<uint64_t> &a);
+
 // ---- chaining (chain.c) -----------------------------------------------------------------------------
 struct ChainParams {
 	int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;

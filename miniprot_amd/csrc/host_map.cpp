@@ -56,6 +56,8 @@ struct QueryState {
 	std::vector<Region> regs;
 	std::vector<AlignPlan> plans;
 	std::vector<uint64_t> seeds;         // kept seeds (query position << 32 | index bucket), ascending; only between the seeding sub-stages
+	std::vector<uint64_t> ext_refine;    // per region: window extension limits of the refinement (between the planning sub-stages)
+	int64_t win0 = 0;                    // first refinement window of this query in the batch's list (device refinement)
 	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
@@ -188,10 +190,10 @@ struct RefineQuery {
 		return f;
 	}
 	std::vector<uint32_t> words;                      // packed k-mer words of the query (bitmap keys)
-	RefineQuery(const char *aa, int32_t l_aa, int32_t k) : kmer(k) {
+	RefineQuery(const char *aa, int32_t l_aa, int32_t k, bool want_filter = true) : kmer(k) {
 		sketch_protein(aa, l_aa, k, 0, qk);
 		sort_u64(qk.data(), qk.data() + qk.size());
-		if (k <= 6) {
+		if (k <= 6 && want_filter) {
 			filter = &thread_filter(k);
 			const uint8_t *aa13 = tab_aa13();
 			const uint32_t mask = (1U << 4 * k) - 1;
@@ -207,7 +209,9 @@ struct RefineQuery {
 	~RefineQuery() { if (filter) for (uint32_t w : words) (*filter)[w >> 6] = 0; }
 };
 
-static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, Region &r, int32_t extl, int32_t extr)
+// dev_hits != nullptr: the window was scanned on the device (dev_refine_scan); its k-mer hits are (hash << 32 | position)
+static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, Region &r, int32_t extl, int32_t extr,
+                          const uint64_t *dev_hits = nullptr, int64_t n_dev_hits = 0)
 {
 	const int32_t kmer = opt.kmer2, is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	const int64_t ctg_len = mi->ctg[r.vid >> 1].len;
@@ -215,10 +219,17 @@ static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Re
 	const int64_t ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
 	static thread_local std::vector<uint8_t> nt;
 	static thread_local std::vector<uint64_t> sd, a;
-	nt.resize((size_t)(ae - as));
 	g_acc[13] += 1000000LL * 1;                                // (count of refined regions, printed /1e6/threads)
-	{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
-	if (rq.filter) {
+	if (dev_hits) {
+		AccTimer tm(11);
+		sd.assign(dev_hits, dev_hits + n_dev_hits);
+		refine_pairs_from_hits(sd, rq.qk, opt.max_ava, a);
+	} else if (nt.resize((size_t)(ae - as)), true) {
+		AccTimer tm(8);
+		fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data());
+	}
+	if (dev_hits) {
+	} else if (rq.filter) {
 		AccTimer tm(9);
 		refine_seed_pairs(nt.data(), ae - as, mi->opt.min_aa_len, kmer, rq.qk, rq.filter->data(), opt.max_ava, sd, a);
 	} else {
@@ -513,7 +524,7 @@ static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const Prec
 }
 
 // (3) everything else up to and including the alignment plans (map.c:185-226)
-static void stage_chain_to_plan(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
+static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
@@ -524,22 +535,40 @@ static void stage_chain_to_plan(mpa_batch_s *b, QueryState &qs, std::vector<uint
 	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
 	{ AccTimer tm(3); chain_anchors(cp, a, u); }
 	std::vector<Region> &regs = qs.regs;
-	std::vector<uint64_t> ext;
-	{
-		AccTimer tm(4);
-		regions_from_chains(mi, u, a, regs);
-		sort_regions(regs);
-		assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
-		select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
-		// refinement at base resolution (map.c:205-222)
-		extension_limits(nullptr, regs, &a, 100, opt.max_ext, ext);
-	}
+	AccTimer tm(4);
+	regions_from_chains(mi, u, a, regs);
+	sort_regions(regs);
+	assign_parents(opt.mask_level, opt.mask_len, regs, mi->opt.kmer);
+	select_secondary(opt.pri_ratio * opt.pri_ratio, mi->opt.kmer * 2, opt.best_n, regs);
+	// refinement at base resolution (map.c:205-222): its windows
+	extension_limits(nullptr, regs, &a, 100, opt.max_ext, qs.ext_refine);
+}
+
+// the window mp_refine_reg() re-seeds (map.c:36-41)
+static inline void refine_window(const mpa_idx_s *mi, const Region &r, uint64_t ext, int64_t *as, int64_t *ae)
+{
+	const int64_t ctg_len = mi->ctg[r.vid >> 1].len;
+	const int32_t extl = (int32_t)(ext >> 32), extr = (int32_t)ext;
+	*as = r.vs > extl ? r.vs - extl : 0;
+	*ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
+}
+
+// (4) refinement of every region (with the device's scan results if there are any), then the alignment plans
+static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh)
+{
+	const mpa_idx_s *mi = b->mi;
+	const mpa_mapopt_t &opt = b->opt;
+	std::vector<Region> &regs = qs.regs;
+	std::vector<uint64_t> &ext = qs.ext_refine;
 	{
 		AccTimer tm(5);
 		std::vector<Region> kept;
-		RefineQuery rq(qs.seq, qs.qlen, opt.kmer2);
+		RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
 		for (size_t i = 0; i < regs.size(); ++i) {
-			refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
+			if (rh) {
+				const int64_t w = qs.win0 + (int64_t)i;
+				refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i], rh->hits.data() + rh->first[w], rh->first[w + 1] - rh->first[w]);
+			} else refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
 			if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
 		}
 		regs.swap(kept);
@@ -802,18 +831,80 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 
 // Phase 2: pre-chain (host: anchors, sort, forward pass, extraction; after device seeding: extraction only), chaining,
 // regions, refinement, alignment plans.  b->sparse (pinned memory of the seeding context) is not needed afterwards.
-static void batch_plan_phase(mpa_batch_s *b)
+static int gpu_refine_mode()
+{
+	const char *e = getenv("MPA_GPU_REFINE");           // 0 / 1 / unset = by the size of the batch
+	return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}
+static const int64_t kDeviceRefineMinBases = 100000000;     // below this the host's own scan is as fast as the round trip
+
+// the packed k-mer words of a query (RefineQuery::words without the bitmap)
+static void query_words(const char *aa, int32_t l_aa, int32_t k, std::vector<uint32_t> &w)
+{
+	const uint8_t *aa13 = tab_aa13();
+	const uint32_t mask = (1U << 4 * k) - 1;
+	uint32_t x = 0;
+	w.clear();
+	for (int32_t i = 0, run = 0; i < l_aa; ++i) {
+		const uint32_t c = aa13[(uint8_t)aa[i]];
+		if (c >= 14) { run = 0, x = 0; continue; }
+		x = (x << 4 | c) & mask;
+		if (++run >= k) w.push_back(x);
+	}
+}
+
+static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 {
 	const double t0 = now_ms();
-	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t i) {
+	const int64_t n_q = (int64_t)b->qs.size();
+	parallel_for(b->n_threads, n_q, [&](int64_t i) {
 		static thread_local std::vector<uint64_t> a;
 		if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, a);
 		else stage_anchors_host(b, b->qs[i], a);
-		stage_chain_to_plan(b, b->qs[i], a);
+		stage_chain_to_windows(b, b->qs[i], a);
+	});
+	b->sparse = PrechainSparse();
+	// the refinement scan of all windows on the device, if the batch is worth the round trip
+	RefineHits rh;
+	bool on_device = false;
+	const int mode = gpu_refine_mode();
+	if (rctx && mode != 0 && b->opt.kmer2 <= 6) {
+		static thread_local std::vector<RefineWindow> wins;
+		static thread_local std::vector<int64_t> qw_first;
+		static thread_local std::vector<uint32_t> qwords;
+		wins.clear();
+		int64_t n_bases = 0;
+		for (int64_t i = 0; i < n_q; ++i) {
+			QueryState &qs = b->qs[i];
+			qs.win0 = (int64_t)wins.size();
+			for (size_t r = 0; r < qs.regs.size(); ++r) {
+				int64_t as, ae;
+				refine_window(b->mi, qs.regs[r], qs.ext_refine[r], &as, &ae);
+				wins.push_back(RefineWindow{ as, (int32_t)i, (int32_t)qs.regs[r].vid, (int32_t)(ae - as) });
+				n_bases += ae - as;
+			}
+		}
+		if (!wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
+			std::vector<uint32_t> w;
+			qw_first.assign((size_t)n_q + 1, 0), qwords.clear();
+			for (int64_t i = 0; i < n_q; ++i) {
+				query_words(b->qs[i].seq, b->qs[i].qlen, b->opt.kmer2, w);
+				qwords.insert(qwords.end(), w.begin(), w.end());
+				qw_first[i + 1] = (int64_t)qwords.size();
+			}
+			const double t1 = now_ms();
+			const int rc = dev_refine_scan(rctx, const_cast<mpa_idx_s*>(b->mi), b->opt.kmer2, b->mi->opt.min_aa_len, (int32_t)n_q, qw_first.data(), qwords.data(),
+			                               (int64_t)wins.size(), wins.data(), rh);
+			timing_note("  refinement scan on the GPU", now_ms() - t1);
+			on_device = rc == MPA_OK;                         // anything else: scan on the host
+		}
+	}
+	const RefineHits *rhp = on_device ? &rh : nullptr;
+	parallel_for(b->n_threads, n_q, [&, rhp](int64_t i) {
+		stage_refine_to_plan(b, b->qs[i], rhp);
 		AccTimer tm(7);
 		plan_round1(b, b->qs[i]);
 	});
-	b->sparse = PrechainSparse();
 	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
 	if (b->opt.flag & MPA_MF_NO_ALIGN) b->round = 4;
@@ -822,7 +913,7 @@ static void batch_plan_phase(mpa_batch_s *b)
 static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
 {
 	mpa_batch_t *b = batch_seed_phase(seed_ctx, mi, opt, q, n_threads);
-	if (b) batch_plan_phase(b);
+	if (b) batch_plan_phase(b, seed_ctx);
 	return b;
 }
 
@@ -1015,7 +1106,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes); });
 				if (rc_all != MPA_OK) return;
 			}
-			batch_plan_phase(slot[k].b);
+			batch_plan_phase(slot[k].b, seed_ctx[k & 1]);
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].begun = true, ++n_planned;
 			cv.notify_all();

@@ -71,6 +71,10 @@ struct PrechainSparse {              // result for a mini-batch: the anchors tha
 	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call
 	const uint64_t *a = nullptr;
 };
+struct RefineWindow { int64_t as; int32_t qid, vid, len; };    // strand-local window [as, as + len) on vid, refined for query qid
+struct RefineHits { std::vector<int64_t> first; std::vector<uint64_t> hits; };
+int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t n_query, const int64_t *qw_first, const uint32_t *qwords,
+                    int64_t n_win, const RefineWindow *wins, RefineHits &out);
 struct ChainParams;
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
                          const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out);

@@ -141,4 +141,93 @@ __global__ __launch_bounds__(256) void k_seed_bounds(const int64_t *qfirst, int3
 	cfirst[q] = i < n ? (int64_t)idx[i] : (n > 0 ? (int64_t)idx[n - 1] + flag[n - 1] : 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Refinement scan (map.c:97-111 = mp_sketch_nt4 + mp_sketch_clean_orf at k = kmer2, every k-mer, base resolution): which
+// positions of a region's window end a k-mer that the query also has?  One workgroup per 2048-position chunk of a window;
+// the query's k-mer words sit in an LDS hash set, the chunk's bases (with a halo wide enough to decide the minimum ORF
+// length) in LDS as well.  A thread forms the k-mer that ENDS at its position directly from five codons -- no rolling
+// state, so chunks are independent.  Hits go to one global list (window, position, hash); the host groups and pairs them.
+// ------------------------------------------------------------------------------------------------
+struct RefineWindowDev { int64_t as; int32_t qid, vid, len, pad; };
+struct RefineChunk { int32_t win, start; };
+struct RefineTab { uint8_t t[64]; };                  // codon -> reduced residue (ns_tab_codon13), 0xff for a stop codon
+#define REFINE_CHUNK 2048
+#define REFINE_HALO 112
+
+__device__ __forceinline__ uint32_t d_hash32_mask(uint32_t key, uint32_t mask)     // mp_hash32_mask (sketch.c:7-16)
+{
+	key = (key + ~(key << 15)) & mask;
+	key ^= key >> 10;
+	key = (key + (key << 3)) & mask;
+	key ^= key >> 6;
+	key = (key + ~(key << 11)) & mask;
+	key ^= key >> 16;
+	return key;
+}
+
+__global__ __launch_bounds__(256) void k_refine_scan(DevGenome g, const RefineWindowDev *wins, const RefineChunk *chunks, const int64_t *qw_first, const uint32_t *qwords,
+                                                     RefineTab rt, int32_t kmer, int32_t min_aa_len, int32_t hs_log2, uint4 *hits, unsigned long long *n_hits, unsigned long long cap)
+{
+	extern __shared__ uint32_t lds_refine[];
+	const int32_t HS = 1 << hs_log2;
+	uint32_t *table = lds_refine;                                   // [HS] open addressing, 0xffffffff = empty
+	uint8_t *base = (uint8_t*)(table + HS);                         // [REFINE_CHUNK + 2 * REFINE_HALO] nt4 codes, 15 = outside the window
+	__shared__ uint8_t tab[64];                                    // codon -> reduced residue, 0xff = stop
+	const RefineChunk ch = chunks[blockIdx.x];
+	const RefineWindowDev w = wins[ch.win];
+	const int cid = w.vid >> 1, rev = w.vid & 1;
+	const int64_t off = g.ctg_off[cid], clen = g.ctg_len[cid];
+	if (threadIdx.x < 64) tab[threadIdx.x] = rt.t[threadIdx.x];
+	for (int k = threadIdx.x; k < HS; k += 256) table[k] = 0xffffffffu;
+	for (int k = threadIdx.x; k < REFINE_CHUNK + 2 * REFINE_HALO; k += 256) {
+		const int64_t p = (int64_t)ch.start - REFINE_HALO + k;        // window-local
+		base[k] = (p < 0 || p >= w.len) ? 15 : (uint8_t)strand_base(g.seq, off, clen, rev, w.as + p);
+	}
+	__syncthreads();
+	for (int64_t k = qw_first[w.qid] + threadIdx.x; k < qw_first[w.qid + 1]; k += 256) {
+		const uint32_t word = qwords[k];
+		uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);
+		for (;;) {
+			const uint32_t old = atomicCAS(&table[slot], 0xffffffffu, word);
+			if (old == 0xffffffffu || old == word) break;
+			slot = (slot + 1) & (HS - 1);
+		}
+	}
+	__syncthreads();
+	const uint32_t mask = (1u << (4 * kmer)) - 1;
+	auto codon_at = [&](int e) -> uint32_t {                          // reduced residue of the codon whose last base is LDS index e; 0xff if none
+		const uint32_t b0 = base[e - 2], b1 = base[e - 1], b2 = base[e];
+		if ((b0 | b1 | b2) > 3) return 0xffu;
+		return tab[b0 << 4 | b1 << 2 | b2];
+	};
+	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
+		const int32_t pos = ch.start + t * 256 + (int32_t)threadIdx.x;   // window-local position of the k-mer's last base
+		if (pos >= w.len) continue;
+		const int e = pos - ch.start + REFINE_HALO;
+		uint32_t word = 0;
+		bool ok = true;
+		for (int c = kmer - 1; c >= 0; --c) {
+			const uint32_t r = codon_at(e - 3 * c);
+			if (r == 0xffu) { ok = false; break; }
+			word = word << 4 | r;
+		}
+		if (!ok) continue;
+		word &= mask;
+		bool found = false;
+		for (uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);; slot = (slot + 1) & (HS - 1)) {
+			const uint32_t v = table[slot];
+			if (v == word) { found = true; break; }
+			if (v == 0xffffffffu) break;
+		}
+		if (!found) continue;
+		// the open reading frame around the k-mer must be at least min_aa_len codons long (sketch.c:64-100)
+		int32_t n = kmer;
+		for (int q = e - 3 * kmer; n < min_aa_len && q >= 2 && codon_at(q) != 0xffu; q -= 3) ++n;
+		for (int q = e + 3; n < min_aa_len && q < REFINE_CHUNK + 2 * REFINE_HALO && codon_at(q) != 0xffu; q += 3) ++n;
+		if (n < min_aa_len) continue;
+		const unsigned long long at = atomicAdd(n_hits, 1ULL);
+		if (at < cap) hits[at] = make_uint4((uint32_t)ch.win, (uint32_t)pos, d_hash32_mask(word, mask), 0u);
+	}
+}
+
 } // namespace mpa
