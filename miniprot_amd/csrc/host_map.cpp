@@ -917,6 +917,42 @@ static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	return b;
 }
 
+// Test hook (not in include/mpamd.h): the refinement scan of n_win windows [as, as + len) on vid for ONE query, on the host
+// (ctx == NULL: refine_seed_pairs' scan) or on the device (k_refine_scan).  first[n_win + 1] / *out (mpa_free): the hits
+// (hash << 32 | window position) of every window, sorted.
+int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, const char *aa, int32_t l_aa, int32_t n_win, const int32_t *vid, const int64_t *as,
+                            const int32_t *len, int64_t *first, uint64_t **out)
+{
+	*out = nullptr;
+	std::vector<std::vector<uint64_t>> per((size_t)n_win);
+	if (ctx) {
+		std::vector<RefineWindow> wins((size_t)n_win);
+		for (int32_t k = 0; k < n_win; ++k) wins[k] = RefineWindow{ as[k], 0, vid[k], len[k] };
+		std::vector<uint32_t> w;
+		query_words(aa, l_aa, kmer, w);
+		const int64_t qw_first[2] = { 0, (int64_t)w.size() };
+		RefineHits rh;
+		const int rc = dev_refine_scan(ctx, const_cast<mpa_idx_s*>(mi), kmer, mi->opt.min_aa_len, 1, qw_first, w.data(), n_win, wins.data(), rh);
+		if (rc != MPA_OK) return rc;
+		for (int32_t k = 0; k < n_win; ++k) per[k].assign(rh.hits.begin() + rh.first[k], rh.hits.begin() + rh.first[k + 1]);
+	} else {
+		RefineQuery rq(aa, l_aa, kmer);
+		std::vector<uint8_t> nt;
+		std::vector<uint64_t> a;
+		for (int32_t k = 0; k < n_win; ++k) {
+			nt.resize((size_t)std::max(len[k], 1));
+			fetch_nt(mi, vid[k], as[k], as[k] + len[k], nt.data());
+			refine_seed_pairs(nt.data(), len[k], mi->opt.min_aa_len, kmer, rq.qk, rq.filter->data(), INT32_MAX, per[k], a);
+		}
+	}
+	first[0] = 0;
+	for (int32_t k = 0; k < n_win; ++k) std::sort(per[k].begin(), per[k].end()), first[k + 1] = first[k] + (int64_t)per[k].size();
+	uint64_t *o = (uint64_t*)malloc((size_t)std::max<int64_t>(first[n_win], 1) * 8);
+	for (int32_t k = 0; k < n_win; ++k) memcpy(o + first[k], per[k].data(), per[k].size() * 8);
+	*out = o;
+	return first[n_win];
+}
+
 // Test hook (not in include/mpamd.h): the anchors that survive the pre-chain (map.c:163-192), query by query, computed on the
 // host (ctx == NULL) or with the device seeding stage (seed_exec.hip).  off[n_seq + 1] receives the offsets into *out
 // (malloc'd, mpa_free).  Returns the total or a negative error code.

@@ -58,3 +58,56 @@ def test_device_seeding_equals_host_seeding(seed):
         assert off_h[-1] > 0
     idx.close()
     ctx.close()
+
+
+def test_device_refinement_scan_equals_host_scan():
+    """k_refine_scan against the host's window scan: windows of awkward lengths (chunk size 2048 +-1, shorter than a k-mer),
+    at contig ends, on both strands, over sequence rich in N and in stop codons, and a query that is made of the
+    windows' own translations (many hits) -- the same (hash, position) sets"""
+    rng = np.random.default_rng(5)
+    L = mpa.lib()
+    L.mpa_dbg_refine_hits.restype = C.c_int64
+    L.mpa_dbg_refine_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    # a contig without stop codons in frame 0 for long stretches (long ORFs), N islands, and random sequence
+    codons = [c for c in range(64) if c not in (48, 50, 56)]             # all but TAA TAG TGA
+    orf = np.array([[c >> 4, c >> 2 & 3, c & 3] for c in rng.choice(codons, 6000)], dtype=np.uint8).reshape(-1)
+    g = np.concatenate([rng.integers(0, 4, 3000).astype(np.uint8), orf, rng.integers(0, 4, 9000).astype(np.uint8), orf[::-1].copy() ^ 3, rng.integers(0, 4, 500).astype(np.uint8)])
+    for at in rng.integers(0, len(g) - 40, 25):
+        g[at:at + int(rng.integers(1, 30))] = 4
+    idx = mpa.Index.from_nt4([g, rng.integers(0, 4, 700).astype(np.uint8)], ["c1", "c2"])
+    ctx = mpa.Context(0)
+    idx.to_device(ctx)
+    # the query: translation of stretches of the contig, so that many window k-mers are in its k-mer set
+    aa_of = {}
+    names, seqs = [], []
+    import refbind
+    nt_fwd = idx.get_nt(0, 3000, 3000 + 9000)
+    codon_tab = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF"
+    prot = "".join("X" if max(nt_fwd[i:i + 3]) > 3 else codon_tab[int(nt_fwd[i]) << 4 | int(nt_fwd[i + 1]) << 2 | int(nt_fwd[i + 2])]
+                   for i in range(0, 2400, 3)).replace("*", "X").encode()
+    wins = []
+    clen = [len(g), 700]
+    for ln in (0, 5, 14, 15, 16, 89, 90, 2047, 2048, 2049, 4096, 6000, 20000):
+        for vid in (0, 1):
+            st = int(rng.integers(0, max(clen[0] - ln, 1)))
+            wins.append((vid, st, min(ln, clen[0] - st)))
+    wins += [(0, 0, clen[0]), (1, 0, clen[0]), (0, clen[0] - 3000, 3000), (1, clen[0] - 2100, 2100), (2, 0, 700), (3, 100, 600)]
+    vid = np.array([w[0] for w in wins], np.int32)
+    as_ = np.array([w[1] for w in wins], np.int64)
+    ln_ = np.array([w[2] for w in wins], np.int32)
+
+    def run(c):
+        first = np.zeros(len(wins) + 1, np.int64)
+        out = C.c_void_p()
+        n = L.mpa_dbg_refine_hits(c.h if c else None, idx.h, 5, prot, len(prot), len(wins), vid.ctypes.data, as_.ctypes.data, ln_.ctypes.data, first.ctypes.data, C.byref(out))
+        assert n >= 0, mpa.last_error()
+        a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), (max(n, 1),))[:n].copy()
+        L.mpa_free(out)
+        return first, a
+
+    fh, ah = run(None)
+    fd, ad = run(ctx)
+    assert np.array_equal(fh, fd) and np.array_equal(ah, ad)
+    assert fh[-1] > 500                                                   # the windows over the ORF stretch do hit
+    idx.close()
+    ctx.close()
