@@ -164,7 +164,7 @@ def main():
                 traffic = json.load(open(pmc)).get("k_ext_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_ext<G,NB>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": "k_ext_narrow + k_ext_wide<NW>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": ext_launches, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": ext_bytes / ext_launches,
                     "valu_int16": {"gcups": gcups, "ops_per_cell": OPS_PER_CELL_EXT, "achieved_ops_per_s": gcups * 1e9 * OPS_PER_CELL_EXT,

@@ -2,12 +2,14 @@
 //
 // A batch of ns_global_gs16b() calls (nasw.h:135; call sites align.c:73,288,293,322,327) is turned into
 //   1. one k_prep_rows / k_prep_prof launch (per-row records + query profiles, written once to HBM),
-//   2. one k_ext<G,NB> launch per shape class for the score-only extension calls, with up to 8 calls
-//      packed per wavefront and calls sorted by window length so that co-resident calls finish together,
-//   3. k_glob<G> launches for the calls that need a CIGAR, chunked by traceback memory, each followed by
-//      k_backtrack,
-// all on the context's own HIP stream, bracketed by HIP events (mpa_dp_last_stats feeds bench.py's
-// roofline record).  There is no CPU fallback here by design.
+//   2. one k_ext_narrow launch (16/32/64 lanes per call, up to 8 calls packed per wavefront) and one k_ext_wide<NW>
+//      launch per wide shape class for the score-only extension calls, calls sorted by window length so that
+//      co-resident calls finish together (k_ext_huge + k_ext_replay for calls wider than 1024 columns),
+//   3. k_glob_narrow / k_glob_wide<NW> launches for the calls that need a CIGAR, chunked by traceback memory, each
+//      followed by k_backtrack,
+// every launch on its own HIP stream of the context, bracketed by HIP events (mpa_dp_last_stats feeds bench.py's
+// roofline record).  The seeding-stage drivers (dev_prechain_forward, dev_refine_scan; kernels in seed_exec.hip) live
+// here too.  There is no CPU fallback here by design.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <mutex>
@@ -162,7 +164,7 @@ static int build_pen_table(float coef, int32_t max_x, PenTable *pt)
 }
 
 struct ExtClass { int G, NB; };
-// classes 0..2: k_ext<G,1>, several calls per wave.  classes 3..6: k_ext_wide<NB>, NB waves per pair of calls.
+// classes 0..2: k_ext_narrow, several calls per wave.  classes 3..6: k_ext_wide<NW>, NW waves per pair of calls.
 static const ExtClass kExtClasses[] = { {16, 1}, {32, 1}, {64, 1}, {64, 2}, {64, 4}, {64, 8}, {64, 16} };
 static const int kNumExtClasses = 7;
 

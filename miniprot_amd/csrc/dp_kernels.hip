@@ -2,8 +2,8 @@
 //
 // What they replace in the reference (lh3/miniprot v0.18-r281):
 //   k_prep_rows / k_prep_prof  ns_prep_seq, ns_prep_seq_left, ns_prep_nas, ns_gen_prof   nasw-sse.c:91-224
-//   k_ext<G,NB>                ns_global_gs16b score-only / extension loop               nasw-sse.c:349-443
-//   k_glob<G>                  ns_global_gs16b traceback loop                             nasw-sse.c:444-542
+//   k_ext_narrow / k_ext_wide  ns_global_gs16b score-only / extension loop               nasw-sse.c:349-443
+//   k_glob_narrow / _wide      ns_global_gs16b traceback loop                             nasw-sse.c:444-542
 //   k_backtrack                ns_backtrack + ns_fix_tiny_UV                              nasw-sse.c:30-89
 //
 // Mapping to the hardware (DESIGN.md has the full argument):
@@ -652,9 +652,6 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	// the row loop, each cost a quarter of this kernel's time.)
 	const uint32_t lane_tag = 63u - (uint32_t)lane;
 	auto keys = [&](int32_t i, int n_rows) {
-#ifdef EXP_NOKEYS
-		if (i >= 0) return;
-#endif
 		uint32_t k0[3], k1[3];
 #pragma unroll
 		for (int k = 0; k < 3; ++k) {
@@ -1055,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_ext_replay(const DTask *tasks, const int
 // ------------------------------------------------------------------------------------------------
 // K2-wide: the same traceback DP for matrices of 65..64*NW columns with one wave per 64-column block, the
 // waves skewed by one row (see k_ext_wide); the boundary record travels through LDS instead of HBM and
-// the block-major passes of k_glob<64> collapse into one sweep of nl + NW steps.
+// the block-major passes of the narrow kernel collapse into one sweep of nl + NW steps.
 // ------------------------------------------------------------------------------------------------
 template<int NW>
 __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
