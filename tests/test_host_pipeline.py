@@ -37,6 +37,25 @@ def test_no_device_is_a_loud_error():
     assert rc == -1 and not res.value
 
 
+def test_error_paths_report_instead_of_guessing(tmp_path):
+    """error behaviour of the C ABI: NULL / negative code + a message, never a silent default"""
+    L = mpa.lib()
+    L.mpa_idx_restore.restype = C.c_void_p
+    assert not L.mpa_idx_restore(b"/nonexistent/ref.mpi") and b"cannot open" in L.mpa_last_error()
+    junk = tmp_path / "junk.mpi"
+    junk.write_bytes(b"not an index at all" * 10)
+    assert not L.mpa_idx_restore(str(junk).encode()) and L.mpa_last_error()
+    idx = mpa.Index.from_nt4([np.zeros(500, np.uint8)], ["c"])       # genome only: no k-mer table yet
+    q = mpa.Queries([b"MKTAYIAKQR"], ["x"])
+    L.mpa_batch_begin.restype = C.c_void_p
+    assert not L.mpa_batch_begin(idx.h, C.byref(mpa.default_mapopt()), C.byref(q.c), 1) and b"k-mer table" in L.mpa_last_error()
+    mo = mpa.default_mapopt()
+    with pytest.raises(mpa.MpaError):
+        idx.set_spsc(str(tmp_path / "missing.tsv"), mo)
+    assert mo.io == 29 + 10                                            # (mp_set_spsc raises io before it reads the file, index.c:243)
+    idx.close()
+
+
 def test_product_does_not_link_the_oracle():
     out = subprocess.run(["ldd", mpa.LIB_PATH], capture_output=True, text=True).stdout
     assert "mporacle" not in out and "miniprot_ref" not in out
