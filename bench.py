@@ -174,7 +174,7 @@ def main():
     # ---- CPU baseline: the reference itself (oracle/_ref/miniprot, built from /root/reference) on a bounded sample
     cpu = None
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniprot")
-    if not a.no_cpu_baseline and a.cpu_sample > 0 and os.path.exists(ref_bin):
+    if world == 1 and not a.no_cpu_baseline and a.cpu_sample > 0 and os.path.exists(ref_bin):   # (rank 0 at N=1 only)
         tmp = "/tmp/mpa_bench_%d" % os.getpid()
         os.makedirs(tmp, exist_ok=True)
         mpi = os.path.join(tmp, "g.mpi")
