@@ -220,13 +220,13 @@ static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Re
 	static thread_local std::vector<uint8_t> nt;
 	static thread_local std::vector<uint64_t> sd, a;
 	g_acc[13] += 1000000LL * 1;                                // (count of refined regions, printed /1e6/threads)
-	if (dev_hits) {
+	if (dev_hits) {                                            // the window was scanned on the device
 		AccTimer tm(11);
 		sd.assign(dev_hits, dev_hits + n_dev_hits);
 		refine_pairs_from_hits(sd, rq.qk, opt.max_ava, a);
-	} else if (nt.resize((size_t)(ae - as)), true) {
-		AccTimer tm(8);
-		fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data());
+	} else {
+		nt.resize((size_t)(ae - as));
+		{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
 	}
 	if (dev_hits) {
 	} else if (rq.filter) {
