@@ -119,6 +119,11 @@ void set_error(const std::string &msg) { g_err = msg; }
 
 using namespace mpa;
 
+// The DP executor keeps up to 16 kernels of a round on separate streams, two rounds at a time in a stream of batches; HIP's
+// default of 4 hardware queues would serialise them.  The runtime reads the variable when it initialises, so it is set when the
+// library is loaded, unless the host application has chosen a value itself.
+__attribute__((constructor)) static void mpa_default_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" {
 
 const char *mpa_last_error(void) { return g_err.c_str(); }
