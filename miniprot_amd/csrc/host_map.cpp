@@ -61,6 +61,8 @@ struct QueryState {
 	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
+	std::vector<mpa_dp_task_t> local2;   // likewise for round 2 (the retries)
+	int64_t base2 = 0;
 };
 
 } // namespace mpa
@@ -679,9 +681,9 @@ static void emit_round1(mpa_batch_s *b)
 static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
 {
 	const mpa_mapopt_t &opt = b->opt;
-	std::vector<mpa_dp_task_t> next;
-	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
+	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t qi) {
 		QueryState &qs = b->qs[qi];
+		qs.local2.clear();
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
 			const Region &r = qs.regs[pl.reg];
@@ -690,20 +692,25 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, con
 			pl.l_nt = mine[pl.t_left].nt_len, pl.l_aa = mine[pl.t_left].aa_len;
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
-				pl.t_left2 = (int32_t)next.size();
-				next.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT | (as_alt == pl.as ? MPA_F_SS_SKIP0 : 0), opt.io_end));
+				pl.t_left2 = (int32_t)qs.local2.size();
+				qs.local2.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT | (as_alt == pl.as ? MPA_F_SS_SKIP0 : 0), opt.io_end));
 			}
 			if (pl.has_right) {
 				pl.r_nt = mine[pl.t_right].nt_len, pl.r_aa = mine[pl.t_right].aa_len;
 				if (pl.r_aa < qs.qlen - pl.mid_qe && pl.r_nt < opt.max_ext && opt.io > opt.io_end) {
 					const int64_t l_ext = std::min<int64_t>(pl.ae - pl.mid_ve, opt.max_ext);
-					pl.t_right2 = (int32_t)next.size();
-					next.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
-					}
+					pl.t_right2 = (int32_t)qs.local2.size();
+					qs.local2.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
+				}
 			}
 		}
+	});
+	b->tasks.clear();
+	for (QueryState &qs : b->qs) {
+		qs.base2 = (int64_t)b->tasks.size();
+		b->tasks.insert(b->tasks.end(), qs.local2.begin(), qs.local2.end());
+		std::vector<mpa_dp_task_t>().swap(qs.local2);
 	}
-	b->tasks.swap(next);
 }
 
 static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
@@ -715,8 +722,9 @@ static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
 			Region &r = qs.regs[pl.reg];
-			if (pl.t_left2 >= 0 && rst[pl.t_left2].aa_len == pl.as1) pl.l_nt = rst[pl.t_left2].nt_len, pl.l_aa = rst[pl.t_left2].aa_len;
-			if (pl.t_right2 >= 0 && rst[pl.t_right2].aa_len == qs.qlen - pl.mid_qe) pl.r_nt = rst[pl.t_right2].nt_len, pl.r_aa = rst[pl.t_right2].aa_len;
+			const mpa_dp_rst_t *mine = rst ? rst + qs.base2 : nullptr;    // this query's slice of the round-2 results
+			if (pl.t_left2 >= 0 && mine[pl.t_left2].aa_len == pl.as1) pl.l_nt = mine[pl.t_left2].nt_len, pl.l_aa = mine[pl.t_left2].aa_len;
+			if (pl.t_right2 >= 0 && mine[pl.t_right2].aa_len == qs.qlen - pl.mid_qe) pl.r_nt = mine[pl.t_right2].nt_len, pl.r_aa = mine[pl.t_right2].aa_len;
 			// region start after the left extension (align.c:297-300); its span is the first mp_align_seq() call
 			r.vs = pl.vs1 - pl.l_nt;
 			r.qs = pl.as1 - pl.l_aa;
@@ -907,7 +915,13 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	});
 	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
-	if (b->opt.flag & MPA_MF_NO_ALIGN) b->round = 4;
+	if (b->opt.flag & MPA_MF_NO_ALIGN) { b->round = 4; return; }
+	// the round-1 task list is part of planning too: in a stream it is ready before a DP lane picks the batch up
+	const double t1 = now_ms();
+	emit_round1(b);
+	timing_note("emit round 1", now_ms() - t1);
+	b->round = 1;
+	if (b->tasks.empty()) { take_round3(b, nullptr, nullptr); b->round = 4; }   // nothing to align at all
 }
 
 static mpa_batch_t *batch_begin_impl(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
