@@ -94,6 +94,7 @@ struct mpa_ctx_s {
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
 	std::vector<mpa_ctx_s*> siblings;         // extra contexts on the same device for concurrent sub-batches (owned)
 	SeedBufs seed;                            // buffers of the GPU seeding stage (seed_exec.hip)
+	int side_off = 0;                         // first side stream a round uses (lets the DP lanes of a stream of batches sit on different hardware queues)
 	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
 };
 
@@ -289,6 +290,7 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 	}
 	return ctx->siblings[k - 1];
 }
+void ctx_set_side_offset(mpa_ctx_t *ctx, int off) { ctx->side_off = off; }
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
 	for (mpa_ctx_s *sb : ctx->siblings) {
@@ -688,13 +690,13 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 	static const int n_streams = [] { const char *e = getenv("MPA_SIDE_STREAMS"); int v = e ? atoi(e) : mpa_ctx_s::kSide; return v < 1 ? 1 : v > mpa_ctx_s::kSide ? mpa_ctx_s::kSide : v; }();
 	auto begin_side = [&](bool is_ext) -> hipStream_t {
 		const int k = n_side++;
-		hipStream_t st = ctx->side[k % n_streams];
+		hipStream_t st = ctx->side[(k + ctx->side_off) % n_streams];
 		(void)hipStreamWaitEvent(st, ctx->fork_ev, 0);
 		(void)hipEventRecord(ctx->lev[2 * k], st);
 		launches.push_back(Launch{ k, is_ext });
 		return st;
 	};
-	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[k % n_streams]); };
+	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[(k + ctx->side_off) % n_streams]); };
 
 	// ---- K1: extension calls
 	ExtArgs ea;

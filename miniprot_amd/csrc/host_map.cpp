@@ -63,6 +63,8 @@ struct QueryState {
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
 	std::vector<mpa_dp_task_t> local2;   // likewise for round 2 (the retries)
 	int64_t base2 = 0;
+	std::vector<mpa_dp_task_t> local_gap;   // anchor-gap traceback calls when they are deferred to round 3 (mpa_batch_s::defer_gaps)
+	int64_t base_gap = 0;
 };
 
 } // namespace mpa
@@ -86,6 +88,9 @@ struct mpa_batch_s {
 	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
 	std::vector<QueryState> qs;
 	std::vector<mpa_dp_task_t> tasks;
+	bool defer_gaps = false;         // the traceback calls between kept anchors go out with round 3 instead of round 1: the same
+	                                 // work, but a round then has at most ~3 long kernels in flight, which lets three batches share
+	                                 // the hardware queues (MPA_DEFER_GAPS)
 	bool seeded_on_device = false;   // between the two seeding phases: `sparse` holds the device's pre-chain result
 	PrechainSparse sparse;
 };
@@ -661,7 +666,7 @@ static void plan_round1(mpa_batch_s *b, QueryState &qs)
 			if (!(r.a[i] >> 31 & 1)) continue;
 			const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
 			pl.gaps.emplace_back();
-			make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, qs.qid, (int32_t)pi, qs.local1, pl.gaps.back());
+			make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, qs.qid, (int32_t)pi, b->defer_gaps ? qs.local_gap : qs.local1, pl.gaps.back());
 			ne0 = ne1, ae0 = ae1;
 		}
 	}
@@ -688,7 +693,7 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, con
 			AlignPlan &pl = qs.plans[pi];
 			const Region &r = qs.regs[pl.reg];
 			const mpa_dp_rst_t *mine = rst + qs.base1;                 // this query's slice of the round-1 results
-			for (Segment &g : pl.gaps) store_result(g, mine, pool);
+			if (!b->defer_gaps) for (Segment &g : pl.gaps) store_result(g, mine, pool);
 			pl.l_nt = mine[pl.t_left].nt_len, pl.l_aa = mine[pl.t_left].aa_len;
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
@@ -737,6 +742,12 @@ static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 			}
 		}
 	}
+	if (b->defer_gaps)
+		for (QueryState &qs : b->qs) {
+			qs.base_gap = (int64_t)next.size();
+			next.insert(next.end(), qs.local_gap.begin(), qs.local_gap.end());
+			std::vector<mpa_dp_task_t>().swap(qs.local_gap);
+		}
 	b->tasks.swap(next);
 }
 
@@ -750,6 +761,7 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 			r.cigar.clear();
 			if (pl.has_left_span) store_result(pl.left_span, rst, pool);
 			if (pl.has_right_span) store_result(pl.right_span, rst, pool);
+			if (b->defer_gaps && rst) for (Segment &g : pl.gaps) store_result(g, rst + qs.base_gap, pool);
 			auto add = [&](const Segment &s) {
 				for (uint32_t c : s.cigar) append_cigar(r.cigar, c & 0xf, (int32_t)(c >> 4));
 				score += s.score;
@@ -794,6 +806,7 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	mpa_batch_s *b = new mpa_batch_s();
 	b->mi = mi, b->opt = *opt, b->q = *q, b->n_threads = n_threads > 1 ? n_threads : 1;
 	mpa_dpopt_from_mapopt(opt, &b->dpopt);
+	{ const char *e = getenv("MPA_DEFER_GAPS"); b->defer_gaps = e ? atoi(e) != 0 : false; }
 	b->qs.resize(q->n_seq);
 	for (int32_t i = 0; i < q->n_seq; ++i) {
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
@@ -1128,6 +1141,9 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	n_lanes = std::max(1, std::min(n_lanes, 4));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
+	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
+	// third context land on the queues of the second one's (measured, rocprofv3 queue ids), three further on they do not
+	{ const char *e = getenv("MPA_LANE2_SIDE_OFF"); if (n_lanes > 2) ctx_set_side_offset(lane_ctx[2], e ? atoi(e) : 3); }
 	// the seeder's own streams and buffers, two sets: the result of batch k is consumed while batch k+1 is on the device
 	mpa_ctx_t *seed_ctx[2] = { ctx_sibling(ctx, n_lanes), ctx_sibling(ctx, n_lanes + 1) };
 	if (!seed_ctx[0] || !seed_ctx[1]) return MPA_ERR_HIP;

@@ -62,6 +62,7 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi);
 void dev_free_index(mpa_idx_s *mi);
 mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);
+void ctx_set_side_offset(mpa_ctx_t *ctx, int off);   // which of its side streams a DP round starts with
 
 // ---- GPU seeding (seed_exec.hip + the driver in dp_exec.hip) --------------------------------------
 struct SeedJob { int64_t kb_off, dst; int32_t cnt, qpos, qid; };   // one kept seed: its occurrence list and where its anchors go
