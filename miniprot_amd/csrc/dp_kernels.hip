@@ -828,6 +828,13 @@ struct GlobArgs {
 
 #define SEG_BIG (1 << 20)
 
+// (x << 4 | 15 - k): the maximum over such keys is the best value and, among equal values, the smallest state index k --
+// the outcome of the reference's chain of strict '>' comparisons (nasw-sse.c:451-519) without ten compare/select pairs
+__device__ __forceinline__ int32_t st_key(int32_t x, int k) { return (int32_t)((uint32_t)x << 4) + (15 - k); }
+__device__ __forceinline__ int32_t imax3(int32_t a, int32_t b, int32_t c) { return imax(imax(a, b), c); }
+// (acc << 1) | (d < 0): collects "a > b" flags as the sign bits of b - a, one v_alignbit_b32 each
+__device__ __forceinline__ uint32_t push_neg(uint32_t acc, int32_t d) { return __builtin_amdgcn_alignbit(acc, (uint32_t)d, 31); }
+
 // MB: the matrix may span several 64-column blocks (block-major sweep).  EXT: score-only extension call swept with this
 // kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
 // per-row key (best H + end bonus, first column) that k_ext_replay consumes.
@@ -908,17 +915,19 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			int32_t w = 0, st = 0, h, tt, u;
 			// candidates other than I
 			const int32_t M = s_add(H3s, S);
-			u = s_sub(H3, go); if (D3 > u) w |= 1 << 5;
+			u = s_sub(H3, go); const int32_t dD = u - D3;                   // direction bits: "old value wins" = sign of new - old
 			const int32_t Dn = s_sub(imax(u, D3), gei);
-			tt = s_sub(s_sub(H1, io), dm1); if (A > tt) w |= 1 << 6;
+			tt = s_sub(s_sub(H1, io), dm1); const int32_t dA = tt - A;
 			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
 			u = s_sub(H1s, io);
-			tt = s_sub(u, d0); if (B > tt) w |= 1 << 7;
+			tt = s_sub(u, d0); const int32_t dB = tt - B;
 			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
-			tt = s_sub(u, dp1); if (C > tt) w |= 1 << 8;
+			tt = s_sub(u, dp1); const int32_t dC = tt - C;
 			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
 			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
-			const int32_t nonI = imax(imax(imax(M, Dn), imax(Av, Bv)), imax(imax(Cv, F6), imax(imax(F7, F8), F9)));
+			const int32_t knon = imax3(imax3(st_key(M, 0), st_key(Dn, 2), st_key(Av, 3)), imax3(st_key(Bv, 4), st_key(Cv, 5), st_key(F6, 6)),
+			                            imax3(st_key(F7, 7), st_key(F8, 8), st_key(F9, 9)));
+			const int32_t nonI = knon >> 4;
 			// first-pass I: the chain restarts at every lane start of the striped reference (segments of slen columns)
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
 			int32_t pex = shift1_i32<G>(py, NEG32, lane);
@@ -926,29 +935,23 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			const int32_t py_tot = imax(bin.x, __shfl(py, grp * G + G - 1));
 			const int32_t I1 = imax(pex - yoff - go, NEG16);
 			// ordered choice of the state, strict '>' keeps the earlier one (nasw-sse.c:451-519)
-			h = M;
-			if (I1 > h) st = 1, h = I1;
-			if (Dn > h) st = 2, h = Dn;
-			if (Av > h) st = 3, h = Av;
-			if (Bv > h) st = 4, h = Bv;
-			if (Cv > h) st = 5, h = Cv;
-			if (F6 > h) st = 6, h = F6;
-			if (F7 > h) st = 7, h = F7;
-			if (F8 > h) st = 8, h = F8;
-			if (F9 > h) st = 9, h = F9;
-			const int32_t h1 = h;
+			const int32_t kbest = imax(knon, st_key(I1, 1));
+			st = 15 - (kbest & 15);
+			const int32_t h1 = kbest >> 4;
 			// left neighbour's first-pass (h, I)
 			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
 			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
 			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
-			if (il > s_sub(hl, go)) w |= 1 << 4;
+			const int32_t dI = s_sub(hl, go) - il;
 			// carry of I across lane starts (the reference's lazy-F loop) as a second prefix max
 			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
 			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
 			int32_t pz = scan_max_i32<G>(z);
 			pz = imax(pz, bin.y);
 			const int32_t Gc = imax(pz - cge, NEG16);
-			if (Gc > h1) w |= 1 << 9, h = Gc;
+			h = imax(h1, Gc);
+			// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go
+			w = (int32_t)(push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), dI) << 4);
 			if (!EXT) { if (live && rowlive) tb[(int64_t)i * ncol + gc] = (uint16_t)(w | st); }
 			else {
 				// key of this block's row: best (H + end bonus) among the live columns, ties to the smallest column
@@ -1119,43 +1122,39 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
 			int32_t wd = 0, st = 0, h, tt, u;
 			const int32_t M = s_add(H3s, S);
-			u = s_sub(H3, go); if (D3 > u) wd |= 1 << 5;
+			u = s_sub(H3, go); const int32_t dD = u - D3;                   // direction bits: "old value wins" = sign of new - old
 			const int32_t Dn = s_sub(imax(u, D3), gei);
-			tt = s_sub(s_sub(H1, io), dm1); if (A > tt) wd |= 1 << 6;
+			tt = s_sub(s_sub(H1, io), dm1); const int32_t dA = tt - A;
 			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
 			u = s_sub(H1s, io);
-			tt = s_sub(u, d0); if (B > tt) wd |= 1 << 7;
+			tt = s_sub(u, d0); const int32_t dB = tt - B;
 			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
-			tt = s_sub(u, dp1); if (C > tt) wd |= 1 << 8;
+			tt = s_sub(u, dp1); const int32_t dC = tt - C;
 			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
 			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
-			const int32_t nonI = imax(imax(imax(M, Dn), imax(Av, Bv)), imax(imax(Cv, F6), imax(imax(F7, F8), F9)));
+			const int32_t knon = imax3(imax3(st_key(M, 0), st_key(Dn, 2), st_key(Av, 3)), imax3(st_key(Bv, 4), st_key(Cv, 5), st_key(F6, 6)),
+			                            imax3(st_key(F7, 7), st_key(F8, 8), st_key(F9, 9)));
+			const int32_t nonI = knon >> 4;
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
 			int32_t pex = shift1_i32<G>(py, NEG32, lane);
 			pex = imax(pex, bin.x);
 			const int32_t py_tot = imax(bin.x, __shfl(py, 63));
 			const int32_t I1 = imax(pex - yoff - go, NEG16);
-			h = M;
-			if (I1 > h) st = 1, h = I1;
-			if (Dn > h) st = 2, h = Dn;
-			if (Av > h) st = 3, h = Av;
-			if (Bv > h) st = 4, h = Bv;
-			if (Cv > h) st = 5, h = Cv;
-			if (F6 > h) st = 6, h = F6;
-			if (F7 > h) st = 7, h = F7;
-			if (F8 > h) st = 8, h = F8;
-			if (F9 > h) st = 9, h = F9;
-			const int32_t h1 = h;
+			const int32_t kbest = imax(knon, st_key(I1, 1));
+			st = 15 - (kbest & 15);
+			const int32_t h1 = kbest >> 4;
 			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
 			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
 			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
-			if (il > s_sub(hl, go)) wd |= 1 << 4;
+			const int32_t dI = s_sub(hl, go) - il;
 			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
 			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
 			int32_t pz = scan_max_i32<G>(z);
 			pz = imax(pz, bin.y);
 			const int32_t Gc = imax(pz - cge, NEG16);
-			if (Gc > h1) wd |= 1 << 9, h = Gc;
+			h = imax(h1, Gc);
+			// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go
+			wd = (int32_t)(push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), dI) << 4);
 			if (live) tb[(int64_t)i * ncol + gc] = (uint16_t)(wd | st);
 			if (lane == 63) xB[par * NW + w] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
 			if (i == nl - 1 && gc == t.al - 1) a.score[tid] = h;
