@@ -84,17 +84,35 @@ template<int G> __device__ __forceinline__ uint32_t scan_max_pk(uint32_t x)
 	return x;
 }
 
-// wave-wide maximum of unsigned words, valid in lane 63
+// wave-wide maximum of unsigned words, valid in lane 63.  VOP2 takes the DPP operand directly; a lane without a source (or in
+// a masked row) is not written, i.e. keeps its value -- no fill needed (cf. scan_max_i32).
 __device__ __forceinline__ uint32_t reduce_max_u32(uint32_t x)
 {
-	auto umax = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-	x = umax(x, dpp_mov<DPP_ROW_SHR(1), 0xf>(0u, x));
-	x = umax(x, dpp_mov<DPP_ROW_SHR(2), 0xf>(0u, x));
-	x = umax(x, dpp_mov<DPP_ROW_SHR(4), 0xf>(0u, x));
-	x = umax(x, dpp_mov<DPP_ROW_SHR(8), 0xf>(0u, x));
-	x = umax(x, dpp_mov<DPP_BCAST15, 0xa>(0u, x));
-	x = umax(x, dpp_mov<DPP_BCAST31, 0xc>(0u, x));
+	asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	    "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
 	return x;
+}
+
+// six such reductions at once, step by step across the six: every DPP read is five instructions behind the write it depends
+// on, so the chains need no wait states between their steps
+__device__ __forceinline__ void reduce_max_u32_x6(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &e, uint32_t &f)
+{
+#define MPA_STEP6(ctrl) \
+	"v_max_u32_dpp %0, %0, %0 " ctrl "\n\tv_max_u32_dpp %1, %1, %1 " ctrl "\n\tv_max_u32_dpp %2, %2, %2 " ctrl "\n\t" \
+	"v_max_u32_dpp %3, %3, %3 " ctrl "\n\tv_max_u32_dpp %4, %4, %4 " ctrl "\n\tv_max_u32_dpp %5, %5, %5 " ctrl "\n\t"
+	asm("s_nop 1\n\t"
+	    MPA_STEP6("row_shr:1 row_mask:0xf bank_mask:0xf")
+	    MPA_STEP6("row_shr:2 row_mask:0xf bank_mask:0xf")
+	    MPA_STEP6("row_shr:4 row_mask:0xf bank_mask:0xf")
+	    MPA_STEP6("row_shr:8 row_mask:0xf bank_mask:0xf")
+	    MPA_STEP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+	    MPA_STEP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+	    : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef MPA_STEP6
 }
 
 // barrier that orders LDS traffic only: outstanding global stores/atomics (vmcnt) keep draining across it
@@ -655,9 +673,10 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		uint32_t k0[3], k1[3];
 #pragma unroll
 		for (int k = 0; k < 3; ++k) {
-			k0[k] = reduce_max_u32((((hxv[k] & 0xffffu) ^ 0x8000u) << 6) | lane_tag);
-			k1[k] = reduce_max_u32((((hxv[k] >> 16) ^ 0x8000u) << 6) | lane_tag);
+			k0[k] = (((hxv[k] & 0xffffu) ^ 0x8000u) << 6) | lane_tag;
+			k1[k] = (((hxv[k] >> 16) ^ 0x8000u) << 6) | lane_tag;
 		}
+		reduce_max_u32_x6(k0[0], k1[0], k0[1], k1[1], k0[2], k1[2]);
 		if (lane == 63) {
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {
