@@ -94,6 +94,8 @@ typedef struct mpa_idx_s mpa_idx_t;
 mpa_idx_t *mpa_idx_restore(const char *fn);                     /* mp_idx_restore, index.c:204 */
 /* genome-only index from nt4 codes (A0 C1 G2 T3 N4) held in memory, contigs concatenated; no k-mer table */
 mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4);
+/* mp_idx_build (index.c:97-136): index of a FASTA genome (plain or gzip) with the given parameters */
+mpa_idx_t *mpa_idx_build(const char *fasta_fn, const mpa_idxopt_t *io, int n_threads);
 /* k-mer table of a genome-only index: build_worker + build_bidx (index.c:52-95) */
 int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads);
 int mpa_idx_dump(const char *fn, const mpa_idx_t *mi);          /* mp_idx_dump, index.c:189: byte-identical file */

@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include "mpa_internal.h"
 #include "host_core.h"
+#include "fasta.h"
 
 namespace mpa {
 
@@ -103,7 +104,11 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 	bool ok = rd(fp, magic, 4) && memcmp(magic, kMagic, 4) == 0;
 	ok = ok && rd(fp, &mi->opt, 1) && rd(fp, &mi->n_kb, 1) && rd(fp, hdr, 2) && rd(fp, &mi->l_seq, 1);
 	if (ok && set_trans_code((int)mi->opt.trans_code) < 0) ok = false;
-	if (ok) {
+	// the header sizes come from a file: refuse nonsense before it turns into an allocation (and an exception across the C ABI)
+	if (ok) ok = hdr[0] >= 0 && hdr[1] >= 0 && mi->l_seq >= 0 && mi->n_kb >= 0 && mi->opt.kmer >= 1 && mi->opt.kmer <= 7 &&
+	             mi->opt.mod_bit >= 0 && mi->opt.mod_bit < 4 * mi->opt.kmer && mi->opt.bbit >= 0 && mi->opt.bbit < 31 &&
+	             (int64_t)hdr[0] * 8 <= (int64_t)1 << 40 && mi->l_seq <= (int64_t)1 << 40 && mi->n_kb <= (int64_t)1 << 40;
+	if (ok) try {
 		const int32_t n_ctg = hdr[0], l_name = hdr[1];
 		mi->ctg.resize(n_ctg);
 		int64_t off = 0;
@@ -124,7 +129,8 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 		mi->ki.resize(n_bucket);
 		mi->kb.resize((size_t)mi->n_kb);
 		ok = ok && rd(fp, mi->ki.data(), n_bucket) && rd(fp, mi->kb.data(), mi->kb.size());
-	}
+		if (ok && off != mi->l_seq) ok = false;
+	} catch (const std::exception&) { ok = false; }
 	fclose(fp);
 	if (!ok) { set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
 	compute_block_offsets(mi);
@@ -168,6 +174,31 @@ mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64
 	for (int64_t p = 0; p < off; ++p) mi->seq[p >> 1] |= (uint8_t)((nt4[p] > 4 ? 4 : nt4[p]) << ((p & 1) * 4));
 	mi->ki.assign((size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit), 0);
 	compute_block_offsets(mi);
+	return mi;
+}
+
+// mp_idx_build (index.c:97-136) = mp_ntseq_read (ntseq.c:29-75) + the k-mer table: FASTA (plain or gzip) -> index.
+mpa_idx_t *mpa_idx_build(const char *fn, const mpa_idxopt_t *io, int n_threads)
+{
+	FastaReader rd(fn);
+	if (!rd.ok()) { set_error(std::string("cannot open ") + fn); return nullptr; }
+	if (set_trans_code((int)io->trans_code) < 0) return nullptr;
+	mpa_idx_s *mi = new mpa_idx_s();
+	mi->opt = *io;
+	const uint8_t *nt4 = tab_nt4();
+	std::string name, comment, seq;
+	int64_t off = 0;
+	while (rd.next(name, comment, seq)) {
+		Contig c;
+		c.off = off, c.len = (int64_t)seq.size(), c.name = name;
+		mi->ctg.push_back(c);
+		mi->names.insert(mi->names.end(), name.c_str(), name.c_str() + name.size() + 1);
+		mi->seq.resize((size_t)((off + c.len + 1) >> 1), 0);
+		for (size_t i = 0; i < seq.size(); ++i, ++off) mi->seq[(size_t)off >> 1] |= (uint8_t)(nt4[(uint8_t)seq[i]] << ((off & 1) * 4));
+	}
+	mi->l_seq = off;
+	compute_block_offsets(mi);
+	mpa_idx_build_kmers(mi, n_threads > 1 ? n_threads : 1);
 	return mi;
 }
 
@@ -231,6 +262,13 @@ int64_t mpa_idx_set_spsc(mpa_idx_t *mi, const char *fn, mpa_mapopt_t *mo, int ke
 	int32_t max_sc = (mo->io + 1) / 2 - 1;
 	if (max_sc > mo->io - mo->go) max_sc = mo->io - mo->go;
 	if (max_sc > mo->sp_max_bonus) max_sc = mo->sp_max_bonus;
+	return mpa::idx_read_spsc(mi, fn, max_sc);
+}
+} // extern "C"
+
+// mp_ntseq_read_spsc (ntseq.c:234-296): the score file into the dense per-strand track, scores clamped to +-max_sc
+int64_t mpa::idx_read_spsc(mpa_idx_s *mi, const char *fn, int32_t max_sc)
+{
 	if (max_sc > 63) max_sc = 63;
 	gzFile fp = gzopen(fn, "rb");
 	if (!fp) { set_error(std::string("cannot open ") + fn); return MPA_ERR_IO; }
@@ -279,6 +317,8 @@ int64_t mpa_idx_set_spsc(mpa_idx_t *mi, const char *fn, mpa_mapopt_t *mo, int ke
 	gzclose(fp);
 	return n_kept;
 }
+
+extern "C" {
 
 int64_t mpa_idx_get_spsc(const mpa_idx_t *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out)
 {

@@ -56,6 +56,7 @@ inline uint8_t nt_at(const mpa_idx_s *mi, int64_t p) { return mi->seq[p >> 1] >>
 // strand-local window fetch; same contract as mp_ntseq_get_by_v (ntseq.c:108-114)
 int64_t fetch_nt(const mpa_idx_s *mi, int32_t vid, int64_t st, int64_t en, uint8_t *out);
 int32_t block2vid(const mpa_idx_s *mi, uint32_t blk);        // mp_idx_block2pos (index.c:28-44)
+int64_t idx_read_spsc(mpa_idx_s *mi, const char *fn, int32_t max_sc);   // mp_ntseq_read_spsc (ntseq.c:234-296)
 
 // ---- device executor (mpa_dp.hip) ----------------------------------------------------------------
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi);

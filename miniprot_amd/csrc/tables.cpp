@@ -14,10 +14,21 @@
 namespace mpa {
 
 const char *const kAA = "ARNDCQEGHILKMFPSTWYV*X";
-// reduced 4-bit alphabet used for seeding (nasw-tab.c:12): similar residues share a code, '*'=14, 'X'=15
-static const uint8_t kReduce[22] = { 0, 2, 4, 4, 6, 5, 5, 8, 3, 10, 11, 2, 11, 12, 7, 1, 1, 13, 12, 10, 14, 15 };
 
-static uint8_t g_nt4[256], g_aa20[256], g_aa13[256], g_codon[64], g_codon13[64];
+} // namespace mpa
+
+// The tables are the reference's public globals as well (miniprot.h:149-151, nasw.h:55-58): a program written against the
+// reference reads ns_tab_* directly, so they are the storage and the mpa:: accessors point at them.
+extern "C" {
+uint8_t ns_tab_nt4[256], ns_tab_aa20[256], ns_tab_aa13[256], ns_tab_codon[64], ns_tab_codon13[64];
+// reduced 4-bit alphabet used for seeding (nasw-tab.c:12): similar residues share a code, '*'=14, 'X'=15
+uint8_t ns_tab_a2r[22] = { 0, 2, 4, 4, 6, 5, 5, 8, 3, 10, 11, 2, 11, 12, 7, 1, 1, 13, 12, 10, 14, 15 };
+static char kNtI2c[] = "ACGTN", kAaI2c[] = "ARNDCQEGHILKMFPSTWYV*X";
+char *ns_tab_nt_i2c = kNtI2c, *ns_tab_aa_i2c = kAaI2c;
+}
+
+namespace mpa {
+static uint8_t *const g_nt4 = ns_tab_nt4, *const g_aa20 = ns_tab_aa20, *const g_aa13 = ns_tab_aa13, *const g_codon = ns_tab_codon, *const g_codon13 = ns_tab_codon13;
 static std::once_flag g_once;
 static int g_code = 1;
 
@@ -31,6 +42,25 @@ static const char *ncbi_aas(int code)
 	case 4:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
 	case 5:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG";
 	case 6:  return "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 9:  return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+	case 10: return "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 12: return "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 13: return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG";
+	case 14: return "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+	case 15: return "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 16: return "FFLLSSSSYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 21: return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG";
+	case 22: return "FFLLSS*SYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 23: return "FF*LSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 24: return "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG";
+	case 25: return "FFLLSSSSYY**CCGWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 26: return "FFLLSSSSYY**CC*WLLLAPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 27: case 28: return "FFLLSSSSYYQQCCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 29: return "FFLLSSSSYYYYCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 30: return "FFLLSSSSYYEECC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 31: return "FFLLSSSSYYEECCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 32: return "FFLLSSSSYY*WCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+	case 33: return "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG";
 	default: return nullptr;
 	}
 }
@@ -43,7 +73,7 @@ static void fill_codon(const char *aas)
 			for (int c = 0; c < 4; ++c) {
 				int idx = tcag[a] << 4 | tcag[b] << 2 | tcag[c];
 				g_codon[idx] = g_aa20[(uint8_t)aas[a * 16 + b * 4 + c]];
-				g_codon13[idx] = kReduce[g_codon[idx]];
+				g_codon13[idx] = ns_tab_a2r[g_codon[idx]];
 			}
 }
 
@@ -58,12 +88,14 @@ static void init_tables()
 	for (int i = 0; i < 22; ++i) {
 		uint8_t up = (uint8_t)kAA[i], lo = (up >= 'A' && up <= 'Z') ? (uint8_t)(up | 0x20) : up;
 		g_aa20[i] = g_aa20[up] = g_aa20[lo] = (uint8_t)i;
-		g_aa13[i] = g_aa13[up] = g_aa13[lo] = kReduce[i];
+		g_aa13[i] = g_aa13[up] = g_aa13[lo] = ns_tab_a2r[i];
 	}
 	fill_codon(ncbi_aas(1));
 }
 
 static void ensure() { std::call_once(g_once, init_tables); }
+// a program that reads ns_tab_* directly expects them filled without calling into the library first
+__attribute__((constructor)) static void tables_at_load() { ensure(); }
 const uint8_t *tab_nt4() { ensure(); return g_nt4; }
 const uint8_t *tab_aa20() { ensure(); return g_aa20; }
 const uint8_t *tab_aa13() { ensure(); return g_aa13; }
@@ -82,7 +114,8 @@ int set_trans_code(int code)
 
 // BLOSUM62 over ARNDCQEGHILKMFPSTWYV*X (the NCBI matrix re-ordered to the alphabet above; '*' vs
 // anything = -4, '*' vs '*' = 1, X column from the NCBI matrix).
-static const int8_t kBlosum62[484] = {
+} // namespace mpa
+extern "C" int8_t ns_mat_blosum62[484] = {
 	 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0,-4, 0,
 	-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3,-4,-1,
 	-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3,-4,-1,
@@ -106,7 +139,8 @@ static const int8_t kBlosum62[484] = {
 	-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4, 1,-4,
 	 0,-1,-1,-1,-2,-1,-1,-1,-1,-1,-1,-1,-1,-1,-2, 0, 0,-2,-1,-1,-4,-1
 };
-const int8_t *blosum62() { return kBlosum62; }
+namespace mpa {
+const int8_t *blosum62() { return ns_mat_blosum62; }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool timing_on() { static int on = -1; if (on < 0) { const char *e = getenv("MPA_TIMING"); on = e && *e && *e != '0'; } return on != 0; }

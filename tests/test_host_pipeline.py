@@ -19,8 +19,15 @@ def test_library_exports_every_declared_symbol():
     names = sorted(set(re.findall(r"\b(mpa_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) > 30
     L = mpa.lib()
-    missing = [n for n in names if not hasattr(L, n)]
-    assert not missing, "declared in include/mpamd.h but not exported: %s" % missing
+    # the reference-signature entry points and globals of include/miniprot.h / include/nasw.h (boundary #1/#2 under the reference's names)
+    for h in ("miniprot.h", "nasw.h"):
+        txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(refbind.ROOT, "include", h)).read(), flags=re.S)
+        txt = re.sub(r"static inline[^{]*\{.*?\n\}", "", txt, flags=re.S)
+        names += sorted(set(re.findall(r"\b((?:mp|ns)_[a-z0-9_]+)\s*\(", txt)))
+        names += re.findall(r"\*?((?:mp|ns)_[a-z0-9_]+)(?:\[\d+\])?(?=[,;])", " ".join(l for l in txt.split("\n") if l.startswith("extern ")))
+    missing = [n for n in sorted(set(names)) if not hasattr(L, n)]
+    assert not missing, "declared in include/ but not exported: %s" % missing
+    assert "mp_map" in names and "ns_global_gs16b" in names and "ns_tab_codon" in names
 
 
 def test_no_device_is_a_loud_error():
@@ -60,7 +67,9 @@ def test_product_does_not_link_the_oracle():
     out = subprocess.run(["ldd", mpa.LIB_PATH], capture_output=True, text=True).stdout
     assert "mporacle" not in out and "miniprot_ref" not in out
     syms = subprocess.run(["nm", "-D", mpa.LIB_PATH], capture_output=True, text=True).stdout
-    assert "mpo_" not in syms and "ns_global_gs16b" not in syms
+    # (ns_global_gs16b / mp_map ARE exported since round 2 -- by miniprot_amd/csrc/compat.cpp, on top of the HIP path;
+    #  what must not be there is anything of the checker: the oracle's mpo_* or the reference's internals)
+    assert "mpo_" not in syms and "mp_chain" not in syms and "ns_global_gs32b" not in syms and "radix_sort_mp" not in syms
 
 
 def test_mapopt_defaults_match_reference_layout():

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--min-exons", type=int, default=1)
     ap.add_argument("--imin", type=int, default=70)
     ap.add_argument("--n-frac", type=float, default=0.0)
+    ap.add_argument("--paralog-frac", type=float, default=0.0)
     ap.add_argument("--mu", type=float, default=7.5)
     ap.add_argument("--sigma", type=float, default=1.5)
     ap.add_argument("--imax", type=int, default=50000)
@@ -42,15 +43,30 @@ def main():
     ap.add_argument("--ref", action="store_true", help="also run oracle/_ref/miniprot on the same .mpi and compare bytes")
     ap.add_argument("--no-gpu", action="store_true", help="(debug) skip our mapper")
     ap.add_argument("--tmp", default="/tmp/mpa_scale")
+    ap.add_argument("--save", default="", help="write <prefix>.mpi and <prefix>.faa (index + proteins) and exit: inputs for --load")
+    ap.add_argument("--load", default="", help="skip generation and index build: restore <prefix>.mpi, read <prefix>.faa")
     a = ap.parse_args()
     ncpu = os.cpu_count() or 1
     thr = a.threads or max(1, min(128, ncpu))
     t0 = time.time()
-    contigs, prots, names = gen_synth.generate(int(a.genome_mb * 1e6), a.n_ctg, a.n_prot, a.seed, mu=a.mu, sigma=a.sigma, imin=a.imin, imax=a.imax, n_frac=a.n_frac, min_exons=a.min_exons)
-    t1 = time.time()
-    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(a.n_ctg)])
-    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, max(8, thr)))
-    t2 = time.time()
+    if a.load:
+        idx = mpa.Index.restore(a.load + ".mpi")
+        names, prots = [], []
+        for line in open(a.load + ".faa", "rb"):
+            (names if line.startswith(b">") else prots).append(line[1:].strip().decode() if line.startswith(b">") else line.strip())
+        t1 = t2 = time.time()
+        contigs = None
+    else:
+      contigs, prots, names = gen_synth.generate(int(a.genome_mb * 1e6), a.n_ctg, a.n_prot, a.seed, mu=a.mu, sigma=a.sigma, imin=a.imin, imax=a.imax, n_frac=a.n_frac, min_exons=a.min_exons, paralog_frac=a.paralog_frac)
+      t1 = time.time()
+      idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(a.n_ctg)])
+      mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, max(8, thr)))
+      t2 = time.time()
+    if a.save:
+        idx.dump(a.save + ".mpi")
+        gen_synth.write_fasta_aa(a.save + ".faa", prots, names)
+        print("saved %s.mpi / .faa (generate %.1fs, index %.1fs)" % (a.save, t1 - t0, t2 - t1), file=sys.stderr)
+        return
     mo = mpa.default_mapopt(); mo.flag |= 4
     if a.set_I:
         mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
