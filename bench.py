@@ -1,34 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- aligned protein residues/sec of the MI355X-native miniprot hot path.
+"""bench.py -- aligned protein residues/sec of the MI355X-native miniprot hot path on BASELINE.json's headline workload.
 
-A "step" is one pass of the whole per-query hot path (seed -> chain -> refine -> spliced DP on the GPU ->
-CIGAR/statistics -> PAF text) over one batch of synthetic proteins against a synthetic genome whose index
-is already resident in HBM.  Workload = BASELINE.json configs[1]: synthetic 50 Mbp genome x 1k ~400 aa
-proteins, prebuilt index, flags `-u` (generator: tools/gen_synth.py).
+Workload (default, `--config 3` = BASELINE.json configs[2], the one `metric` is quoted on): synthetic 3 Gbp human-like genome
+(24 contigs x 125 Mbp, 5 % N runs, 2 % tandem pseudo-paralogs of planted genes) x 20 000 proteins (~400 aa, 15 % diverged),
+flags `-I -u` (max_intron from the genome size, options.c:31-37), generator miniprot_amd/synth.py, index
+built once and resident in HBM before the timed region.  The 20 000 proteins are 10 distinct mini-batches of 2 000.
 
-    python bench.py --gpus 1 --steps 20 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+A "step" is one pass of the whole per-query hot path (seed -> chain -> refine -> spliced DP on the GPU -> CIGAR/statistics ->
+PAF text) over ONE mini-batch.  The K timed steps are the mini-batches k mod 10, handed to mpa_map_batches() as one stream
+(what miniprot's own batch loop, map.c:273-345, would call): pipeline fill and drain are inside the timed region.  Every
+output line of every timed step is compared with the reference's output for the same proteins (`paf_identical`).
 
-The K steps are K mini-batches handed to mpa_map_batches() as one stream (the library pipelines host seeding, GPU DP
-rounds and formatting across consecutive batches; --no-stream times one blocking mpa_map_batch() call per step).
+    python bench.py                                    # N=1, config 3, 40 steps (4 passes over the 20 000 proteins)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
-N>1: proteins are sharded over ranks (one process per GPU, no data-path collective); every rank maps
-its own shard of the same size (weak scaling) and the PAF text is gathered to rank 0 over RCCL.
-Prints ONE JSON line on rank 0.
+N>1 (BASELINE.json configs[3]): the SAME job -- the same K mini-batches of the same proteins -- dealt round-robin over the ranks
+(one process per GPU, index replicated, no collective on the data path), output gathered to rank 0 over RCCL in input order
+(miniprot_amd/dist.py): strong scaling.  Rank 0 builds genome and index once; the other ranks restore the .mpi from /dev/shm.
+`--config 2` / `--config 5` run the 50 Mbp x 1k and the long-intron (-G 500k) workloads instead; at N=1 they are also
+recorded as extra keys of the config-3 line unless --no-extra.  Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the DP executor runs one kernel class per stream; let them overlap
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
@@ -36,6 +38,18 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 VALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2 (packed) x 2.4 GHz  (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
 VALU_I16_PEAK = 256 * 4 * 32 * 2 * 2.4e9
 OPS_PER_CELL_EXT = 32            # int16 ops per DP cell, score-only loop of the reference
+OPS_PER_CELL_GLOB = 65           # with traceback
+
+CONFIGS = {
+    2: dict(name="config 2: synthetic 50 Mbp genome (1 contig) x 1 000 proteins, flags -u", genome_mb=50, n_ctg=1, n_prot=1000, seed=12, batch=1000,
+            gen=dict(), flags=["-u"]),
+    3: dict(name="config 3: synthetic 3 Gbp human-like genome (24 contigs x 125 Mbp, 5 % N runs, 2 % tandem pseudo-paralogs) x 20 000 proteins, flags -I -u",
+            genome_mb=3000, n_ctg=24, n_prot=20000, seed=3, batch=2000,
+            gen=dict(mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02), flags=["-I", "-u"]),
+    5: dict(name="config 5: long-intron stress, 3 Gbp genome x 2 000 proteins with >= 4 exons, introns to 450 kb, flags -G 500k -u",
+            genome_mb=3000, n_ctg=24, n_prot=2000, seed=3, batch=500,
+            gen=dict(mu=10.5, sigma=1.2, imin=1000, imax=450000, min_exons=4, n_frac=0.05, paralog_frac=0.02), flags=["-G", "500000", "-u"]),
+}
 
 
 def aligned_residues(paf):
@@ -47,19 +61,143 @@ def aligned_residues(paf):
     return n
 
 
+def mapopt_for(mpa, idx, flags):
+    import ctypes as C
+    mo = mpa.default_mapopt()
+    it = iter(flags)
+    for f in it:
+        if f == "-u":
+            mo.flag |= 0x4
+        elif f == "-I":
+            mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+        elif f == "-G":
+            mo.max_intron = mo.bw = int(next(it))
+    return mo
+
+
+class Workload:
+    """Genome index + protein mini-batches of one config.  Rank 0 generates and indexes; with several ranks the index and the
+    proteins travel through a directory in /dev/shm (mpa_idx_dump / mpa_idx_restore), so the host work is done once."""
+
+    def __init__(self, mpa, cfg, rank, world, barrier, share_dir, n_threads, scale=1.0):
+        from miniprot_amd import synth
+        self.cfg, self.mpa = cfg, mpa
+        t0 = time.time()
+        mpi, faa = os.path.join(share_dir, "g.mpi"), os.path.join(share_dir, "p.faa")
+        self.mpi, self.faa = mpi, faa
+        if rank == 0:
+            n_prot = max(10, int(cfg["n_prot"] * scale))
+            contigs, prots, names = synth.generate(int(cfg["genome_mb"] * 1e6 * scale), cfg["n_ctg"], n_prot, cfg["seed"], **cfg["gen"])
+            self.t_generate = time.time() - t0
+            t1 = time.time()
+            self.idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
+            del contigs
+            mpa._check(mpa.lib().mpa_idx_build_kmers(self.idx.h, max(2, n_threads)))
+            self.t_index = time.time() - t1
+            synth.write_fasta_aa(faa, prots, names)
+            self.idx.dump(mpi)                                # for the other ranks and for the reference binary
+        barrier()
+        if rank != 0:
+            self.idx = mpa.Index.restore(mpi)
+            names, prots = [], []
+            for line in open(faa, "rb"):
+                (names if line.startswith(b">") else prots).append(line[1:].strip().decode() if line.startswith(b">") else line.strip())
+            self.t_generate = self.t_index = 0.0
+        self.prots, self.names = prots, names
+        b = cfg["batch"]
+        self.batches = [mpa.Queries(prots[i:i + b], names[i:i + b]) for i in range(0, len(prots), b)]
+        self.batch_of = {}
+        for k, q in enumerate(self.batches):
+            for n in q.names:
+                self.batch_of[n.encode()] = k
+        self.mo = mapopt_for(mpa, self.idx, cfg["flags"])
+        self.t_setup = time.time() - t0
+
+    def reference(self, ncpu):
+        """oracle/_ref/miniprot (the reference itself, compiled from /root/reference) on the whole protein set, same .mpi, all
+        host cores; wall time minus an index-load-only run.  Returns (record, per-batch reference text)."""
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniprot")
+        if not os.path.exists(ref_bin):
+            return None, None
+        empty = os.path.join(os.path.dirname(self.faa), "empty.faa")
+        open(empty, "w").close()
+        cmd = [ref_bin, "-t%d" % ncpu] + self.cfg["flags"] + [self.mpi]
+        def timed(q):
+            t = time.time()
+            out = subprocess.run(cmd + [q], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            return time.time() - t, out
+        t_load = min(timed(empty)[0] for _ in range(2))
+        t_run, out = timed(self.faa)
+        per = [[] for _ in self.batches]
+        for line in out.split(b"\n"):
+            if line:
+                per[self.batch_of[line.split(b"\t", 1)[0]]].append(line + b"\n")
+        per = [b"".join(x) for x in per]
+        res = aligned_residues(out)
+        rec = {"value": res / max(t_run - t_load, 1e-6), "unit": "aligned residues/s", "cores": ncpu, "kind": "reference",
+               "sample": "the whole workload: %d proteins, oracle/_ref/miniprot -t%d %s on the same .mpi; wall %.2f s minus index load %.2f s; %d residues aligned"
+                         % (len(self.prots), ncpu, " ".join(self.cfg["flags"]), t_run, t_load, res),
+               "wall_s": t_run, "index_load_s": t_load, "md5": hashlib.md5(out).hexdigest()}
+        return rec, per
+
+
+def run_stream(mpa, mdist, wl, ctx, n_steps, n_threads, rank, world, device):
+    """n_steps mini-batches (k mod n_distinct) of the job, this rank's share through mpa_map_batches, text to rank 0."""
+    nb = len(wl.batches)
+    def map_mine(ks):
+        return mpa.map_batches(ctx, wl.idx, wl.mo, [wl.batches[k % nb] for k in ks], n_threads)
+    texts, _ = mdist.run_sharded(n_steps, rank, world, device, False, map_mine, None, None)
+    return texts
+
+
+def measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, sync):
+    run_stream(mpa, mdist, wl, ctx, warmup, n_threads, rank, world, device)
+    ctx.dp_stats(total=True, reset=True)
+    sync()
+    t1 = time.time()
+    texts = run_stream(mpa, mdist, wl, ctx, steps, n_threads, rank, world, device)
+    sync()
+    return time.time() - t1, texts, ctx.dp_stats(total=True)
+
+
+def roofline_record(st, elapsed, world):
+    if st["launches_ext"] <= 0 or st["ms_ext"] <= 0:
+        return None
+    n, ms = st["launches_ext"], st["ms_ext"]
+    ops_ext = OPS_PER_CELL_EXT * st["cells_ext"]
+    ach = ops_ext / (ms * 1e-3)                               # int16 ops/s while an extension kernel is running (per launch)
+    hbm = st["alg_bytes_ext"] / (ms * 1e-3) / 1e9
+    wall_ops = (ops_ext + OPS_PER_CELL_GLOB * st["cells_glob"]) / elapsed
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            d = json.load(open(pmc))
+            traffic, src = d.get("k_ext_hbm_bytes_per_launch"), "profiles/pmc_latest.json: separate rocprofv3 --pmc passes (tools/pmc_round.sh), NOT measured in this run; workload %s" % d.get("workload", "config 2")
+        except Exception:
+            pass
+    return {"kernel": "k_ext_narrow + k_ext_wide<NW> (score-only extension sweep, > 80 % of all DP cells)", "bound": "valu-int16",
+            "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
+            "traffic": traffic, "traffic_source": src,
+            "launches": n, "avg_launch_ms": ms / n, "cells_per_launch": st["cells_ext"] / n, "ops_per_cell": OPS_PER_CELL_EXT,
+            "gcups_per_launch": st["cells_ext"] / (ms * 1e-3) / 1e9,
+            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": st["alg_bytes_ext"] / n,
+                    "note": "algorithmic bytes (packed window + protein + result, SURVEY.md 8(d)) / launch time: the score-only DP is not HBM-bound"},
+            "wall": {"achieved": wall_ops / 1e12, "frac": wall_ops / VALU_I16_PEAK / max(world, 1), "unit": "Tops/s",
+                     "note": "all DP ops of the timed steps (32/cell score-only + 65/cell traceback) / elapsed wall time / GPUs: includes every host stage and idle gap"},
+            "note": "per-launch durations are HIP-event times of kernels that run CONCURRENTLY on several streams (sum over launches > wall time)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genome-mb", type=float, default=50.0)
-    ap.add_argument("--n-prot", type=int, default=1000)
-    ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = all cores / ranks)")
-    ap.add_argument("--cpu-sample", type=int, default=200, help="proteins in the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-replicas", type=int, default=20, help="the CPU baseline maps the protein set this many times over (one FASTA)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--scale", type=float, default=1.0, help="(debug) shrink genome and protein set by this factor; the line is then NOT the named config")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = all cores / ranks, at most 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stream", action="store_true", help="one blocking mpa_map_batch() call per step instead of handing the K steps "
-                    "to mpa_map_batches() as a pipelined stream of mini-batches")
+    ap.add_argument("--no-extra", action="store_true", help="N=1, config 3: skip the config-2 and config-5 records")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,145 +212,103 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DP kernels have no CPU fallback")
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
 
     import miniprot_amd as mpa
     from miniprot_amd import dist as mdist
-    import gen_synth
-    from hostpipe import map_batch_gpu
 
     ncpu = os.cpu_count() or 1
-    # host threads for the non-DP stages: share the cores between the ranks; beyond ~128 threads SMT contention loses
     n_threads = a.threads if a.threads > 0 else max(1, min(128, ncpu // max(world, 1)))
 
-    # ---- inputs (untimed): genome, index, proteins.  Every rank builds the same genome; proteins of a
-    # rank are that rank's shard (same planted genes, rank-specific divergence), so per-GPU work is fixed.
-    t0 = time.time()
-    contigs, prots0, names0, planted = gen_synth.generate(int(a.genome_mb * 1e6), 1, a.n_prot, 12, return_planted=True)
-    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
-    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, max(2, n_threads)))
-    if rank == 0:
-        prots, names = prots0, names0
-    else:                                                 # same planted genes, rank-specific divergence
-        rng = np.random.default_rng(1000 + rank)
-        prots, names = [gen_synth.mutate(rng, pr) for pr in planted], ["r%d_%s" % (rank, n) for n in names0]
-    q = mpa.Queries(prots, names)
-    ctx = mpa.Context(local_rank)
-    idx.to_device(ctx)
-    mo = mpa.default_mapopt()
-    mo.flag |= 0x4                                        # -u: print unmapped queries too
-    t_setup = time.time() - t0
-
-    def step():
-        return map_batch_gpu(ctx, idx, mo, q, n_threads)
-
-    def sync():
+    def barrier():
         if dist is not None:
             dist.barrier()
+
+    def sync():
+        barrier()
         torch.cuda.synchronize()
 
-    def run_steps(k):
-        """k steps = k mini-batches of the same 1000 proteins, handed to the library as a stream (mpa_map_batches -- what
-        miniprot's own batch loop, map.c:273-345, would call): the host seeding of batch i+1 and the formatting of batch i-1
-        overlap the GPU DP rounds of batch i, and two batches are in their DP rounds at a time (the rounds of one batch are
-        dominated by the tails of a few very long DP calls).  Every step's work, pipeline fill and drain included, happens
-        inside the timed region.  --no-stream: one blocking mpa_map_batch() + format per step."""
-        if k <= 0:
-            return b""
-        if a.no_stream:
-            out = b""
-            for _ in range(k):
-                out = step()
-            return out
-        return mpa.map_batches(ctx, idx, mo, [q] * k, n_threads)[-1]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    share_root = os.path.join(base, "mpa_bench_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
 
-    paf = run_steps(a.warmup)
-    ctx.dp_stats(total=True, reset=True)
-    sync()
-    t1 = time.time()
-    paf = run_steps(a.steps)
-    sync()
-    elapsed = time.time() - t1
-    st = ctx.dp_stats(total=True)                         # accumulated over the DP rounds of the timed steps
-    dp_ms = {"prep": st["ms_prep"], "ext": st["ms_ext"], "glob": st["ms_glob"], "backtrack": st["ms_backtrack"]}
-    ext_launches, ext_bytes, ext_cells, glob_cells = st["launches_ext"], st["alg_bytes_ext"], st["cells_ext"], st["cells_glob"]
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        all_paf = mdist.gather_bytes(paf, rank, world, torch.device("cuda", local_rank))   # the final hit gather (RCCL)
-    else:
-        all_paf = [paf]
-
-    if rank != 0:
+    def run_config(cid, steps, warmup, with_cpu):
+        cfg = CONFIGS[cid]
+        share = os.path.join(share_root, "c%d" % cid)
+        if rank == 0:
+            os.makedirs(share, exist_ok=True)
+        barrier()
+        wl = Workload(mpa, cfg, rank, world, barrier, share, n_threads, a.scale)
+        ctx = mpa.Context(local_rank)
+        wl.idx.to_device(ctx)
+        elapsed, texts, st = measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, sync)
         if dist is not None:
-            dist.destroy_process_group()
-        return
-    residues = sum(aligned_residues(p) for p in all_paf)
-    value = residues * a.steps / elapsed
-    ms_per_step = elapsed / a.steps * 1e3
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            tot = torch.tensor([st[k] for k in ("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext")] + [st["ms_ext"]], dtype=torch.float64, device=device)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            for k, v in zip(("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext", "ms_ext"), tot.tolist()):
+                st[k] = v
+        rec = None
+        if rank == 0:
+            nb = len(wl.batches)
+            res_of = {}
+            residues = 0
+            for k, t in enumerate(texts):
+                if k % nb not in res_of or k < nb:
+                    res_of[k % nb] = aligned_residues(t)
+                residues += res_of[k % nb]
+            one_pass = b"".join(texts[k] for k in range(min(nb, len(texts))))
+            cpu, identical = None, None
+            if with_cpu and not a.no_cpu_baseline:
+                cpu, per = wl.reference(ncpu)
+                if cpu is not None:
+                    bad = [k for k, t in enumerate(texts) if t != per[k % nb]]
+                    identical = not bad
+                    cpu["paf_identical"] = identical
+                    cpu["lines_compared"] = sum(t.count(b"\n") for t in texts)
+                    cpu["first_differing_step"] = bad[0] if bad else None
+            rec = {"workload": cfg["name"] + ("" if a.scale == 1.0 else " [SCALED x%g: not the named config]" % a.scale),
+                   "value": residues / elapsed, "elapsed_s": elapsed, "steps": steps, "ms_per_step": elapsed / max(steps, 1) * 1e3,
+                   "proteins_per_step": cfg["batch"], "distinct_mini_batches": nb, "aligned_residues": residues,
+                   "input_residues_per_s": sum(len(p) for k in range(steps) for p in wl.batches[k % nb].seqs) / elapsed,
+                   "md5_first_pass": hashlib.md5(one_pass).hexdigest() if len(texts) >= nb else None, "paf_identical": identical,
+                   "roofline": roofline_record(st, elapsed, world), "cpu_baseline": cpu,
+                   "dp_cells": {"ext": st["cells_ext"], "glob": st["cells_glob"]},
+                   "gcups_wall": (st["cells_ext"] + st["cells_glob"]) / elapsed / 1e9,
+                   "setup_s": {"generate": wl.t_generate, "index_build": wl.t_index, "total": wl.t_setup}, "host_threads_per_rank": n_threads}
+        ctx.close()
+        wl.idx.close()
+        barrier()
+        if rank == 0:
+            shutil.rmtree(share, ignore_errors=True)
+        return rec
 
-    # ---- roofline of the dominant kernel (k_ext: >80 % of all DP cells), from HIP events on the executor's stream
-    roofline = None
-    if ext_launches > 0 and dp_ms["ext"] > 0:
-        avg_ms = dp_ms["ext"] / ext_launches
-        achieved = ext_bytes / ext_launches / (avg_ms * 1e-3) / 1e9
-        gcups = ext_cells / (dp_ms["ext"] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+    main_rec = run_config(a.config, a.steps, a.warmup, with_cpu=(world == 1))
+    extra = {}
+    if world == 1 and a.config == 3 and not a.no_extra and a.scale == 1.0:
+        for cid, (k, w) in ((2, (40, 4)), (5, (8, 4))):
             try:
-                traffic = json.load(open(pmc)).get("k_ext_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"kernel": "k_ext_narrow + k_ext_wide<NW>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": ext_launches, "avg_launch_ms": avg_ms,
-                    "alg_bytes_per_launch": ext_bytes / ext_launches,
-                    "valu_int16": {"gcups": gcups, "ops_per_cell": OPS_PER_CELL_EXT, "achieved_ops_per_s": gcups * 1e9 * OPS_PER_CELL_EXT,
-                                   "peak_ops_per_s": VALU_I16_PEAK, "frac": gcups * 1e9 * OPS_PER_CELL_EXT / VALU_I16_PEAK},
-                    "note": "score-only DP is VALU/cross-lane bound, not HBM bound (SURVEY.md 8(d)); both fractions reported"}
-
-    # ---- CPU baseline: the reference itself (oracle/_ref/miniprot, built from /root/reference) on a bounded sample
-    cpu = None
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniprot")
-    if world == 1 and not a.no_cpu_baseline and a.cpu_sample > 0 and os.path.exists(ref_bin):   # (rank 0 at N=1 only)
-        tmp = "/tmp/mpa_bench_%d" % os.getpid()
-        os.makedirs(tmp, exist_ok=True)
-        mpi = os.path.join(tmp, "g.mpi")
-        idx.dump(mpi)
-        ns = min(a.cpu_sample, len(prots0))
-        gen_synth.write_fasta_aa(os.path.join(tmp, "p.fa"), prots0[:ns], names0[:ns])
-        # the timed sample: the whole protein set, replicated so that the run lasts seconds on a many-core host
-        reps = max(1, a.cpu_replicas)
-        gen_synth.write_fasta_aa(os.path.join(tmp, "rep.fa"), list(prots0) * reps, ["r%d_%s" % (k, n) for k in range(reps) for n in names0])
-        open(os.path.join(tmp, "empty.fa"), "w").close()
-        def timed(args, n_runs):
-            best, out = 1e30, b""
-            for _ in range(n_runs):
-                tl = time.time()
-                out = subprocess.run([ref_bin, "-t%d" % ncpu, "-u", mpi] + args, capture_output=True).stdout
-                best = min(best, time.time() - tl)
-            return best, out
-        t_load, _ = timed([os.path.join(tmp, "empty.fa")], 3)
-        _, out = timed([os.path.join(tmp, "p.fa")], 1)
-        t_run, out_rep = timed([os.path.join(tmp, "rep.fa")], 2)
-        ours = b"".join(l + b"\n" for l in all_paf[0].split(b"\n")[:-1] if l.split(b"\t", 1)[0].decode() in set(names0[:ns]))
-        cpu_res = aligned_residues(out_rep)
-        cpu = {"value": cpu_res / max(t_run - t_load, 1e-6), "unit": "aligned residues/s", "cores": ncpu, "kind": "reference",
-               "sample": "the %d proteins x %d replicas (%d residues aligned), miniprot -t%d -u on the same .mpi, best of 2; wall %.2fs minus index load %.2fs"
-                         % (len(prots0), reps, cpu_res, ncpu, t_run, t_load),
-               "paf_identical_on_sample": bool(ours == out), "identity_sample": "first %d proteins" % ns}
-        subprocess.run(["rm", "-rf", tmp])
-
-    rec = {"metric": "aligned protein residues/sec (whole node)", "value": value, "unit": "aligned residues/s", "n_gpus": world,
-           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-           "config": {"workload": "synthetic %.0f Mbp genome x %d proteins per GPU (~400 aa, 15%% diverged), index resident in HBM, flags -u" % (a.genome_mb, a.n_prot),
-                      "proteins_per_gpu": a.n_prot, "aligned_residues_per_step": residues, "host_threads_per_rank": n_threads, "parallelism": "proteins sharded x%d" % world, "batching": "blocking call per step" if a.no_stream else "stream of mini-batches (mpa_map_batches)"},
-           "roofline": roofline, "cpu_baseline": cpu,
-           "stage_ms_per_step": {k: v / a.steps for k, v in dp_ms.items()},
-           "dp_cells_per_step": {"ext": ext_cells // max(a.steps, 1), "glob": glob_cells // max(a.steps, 1)},
-           "setup_s": t_setup}
-    print(json.dumps(rec))
+                r = run_config(cid, k, w, with_cpu=True)
+                extra["config%d" % cid] = {x: r[x] for x in ("workload", "value", "elapsed_s", "steps", "ms_per_step", "paf_identical", "gcups_wall", "md5_first_pass")}
+                extra["config%d" % cid]["cpu_baseline"] = r["cpu_baseline"]
+                extra["config%d" % cid]["roofline_frac"] = r["roofline"]["frac"] if r["roofline"] else None
+            except Exception as e:                               # an extra must not cost the headline line
+                extra["config%d" % cid] = {"error": repr(e)[:300]}
+    if rank == 0:
+        shutil.rmtree(share_root, ignore_errors=True)
+        r = main_rec
+        out = {"metric": "aligned protein residues/sec (whole node), 3 Gbp genome x 20k proteins" if a.config == 3 and a.scale == 1.0 else "aligned protein residues/sec (whole node)",
+               "value": r["value"], "unit": "aligned residues/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+               "config": {"workload": r["workload"], "proteins_per_step": r["proteins_per_step"], "distinct_mini_batches": r["distinct_mini_batches"],
+                          "parallelism": "mini-batches dealt round-robin over %d GPU(s), index replicated, text gathered to rank 0" % world,
+                          "batching": "stream of mini-batches (mpa_map_batches)", "host_threads_per_rank": r["host_threads_per_rank"]},
+               "elapsed_s": r["elapsed_s"], "aligned_residues": r["aligned_residues"], "input_residues_per_s": r["input_residues_per_s"],
+               "paf_identical": r["paf_identical"], "md5_first_pass": r["md5_first_pass"],
+               "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
+        out.update(extra)
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -228,6 +228,11 @@ int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_q
 int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                           const mpa_result_t *r, int64_t *id_io, char **out);
 
+/* The number of hit records mpa_format_output() prints for this batch, i.e. by how much it advances *id_io.  A job whose batches
+ * are mapped by different processes (one per GPU) exchanges these counts, and every process formats its batches with the
+ * exclusive prefix sum as its starting id: the merged GFF3/GTF then carries the ids of a single-process run (map.c:306). */
+int64_t mpa_result_n_output(const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const mpa_result_t *r);
+
 /* A stream of mini-batches (the loop of mp_map_file()'s kt_pipeline, map.c:273-345, which overlaps only file I/O with
  * mapping): a three-stage software pipeline in which the host seeding/chaining of batch k+1 and the flattening +
  * formatting of batch k-1 overlap the GPU DP rounds of batch k.  results[k] is what mpa_map_batch() returns for
@@ -237,6 +242,15 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len);
 
 const char *mpa_version(void);
+
+/* ---- diagnostics (operator-level parity tests of the seeding kernels; not needed by a caller) ---------------------------- */
+/* the k-mer hits (hash << 32 | window position) of the refinement scan (map.c:97-111) for n_win windows [as, as+len) on vid of one
+ * query, from the device kernel (ctx != NULL) or the host stage (ctx == NULL): *out (mpa_free) holds them window by window,
+ * first[n_win + 1] the boundaries.  Returns the number of hits or a negative error code. */
+int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, const char *aa, int32_t l_aa, int32_t n_win, const int32_t *vid, const int64_t *as,
+                            const int32_t *len, int64_t *first, uint64_t **out);
+/* the anchors that survive the pre-chain (map.c:186-192), query by query, from the host stage (ctx == NULL) or the device's */
+int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out);
 
 #ifdef __cplusplus
 }

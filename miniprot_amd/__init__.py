@@ -129,6 +129,7 @@ def lib():
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
             ("mpa_format_output", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
                                               C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
+            ("mpa_result_n_output", C.c_int64, [C.POINTER(MapOpt), C.POINTER(QBatch), C.c_void_p]),
             ("mpa_format_paf", C.c_int64, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.POINTER(C.c_char_p),
                                            C.c_void_p, C.POINTER(C.c_void_p)]),
         ]:
@@ -293,24 +294,81 @@ def dpopt_from(mo):
     return dp
 
 
-def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False):
+class Result:
+    """Owner of an mpa_result_t (the structured hits of one batch)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def n_hit(self):
+        return lib().mpa_result_n_hit(self.h)
+
+    def n_output(self, mo, queries):
+        """ids the output of this batch consumes (mpa_result_n_output)"""
+        return lib().mpa_result_n_output(C.byref(mo), C.byref(queries.c), self.h)
+
+    def close(self):
+        if self.h:
+            lib().mpa_result_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_output(idx, mo, queries, result, id0=0):
+    """mpa_format_output(): the text of one batch whose first printed hit gets id0 + 1.  Returns (text, id after the batch)."""
+    names = (C.c_char_p * len(queries.names))(*[n.encode() for n in queries.names])
+    out = C.c_void_p()
+    idc = C.c_int64(id0)
+    n = lib().mpa_format_output(idx.h, C.byref(mo), C.byref(queries.c), names, result.h, C.byref(idc), C.byref(out))
+    if n < 0:
+        raise MpaError(last_error())
+    txt = C.string_at(out.value, n)
+    lib().mpa_free(out)
+    return txt, idc.value
+
+
+def map_batch(ctx, idx, mo, queries, n_threads=1):
+    """mpa_map_batch(): one blocking batch; returns its Result."""
+    res = C.c_void_p()
+    _check(lib().mpa_map_batch(ctx.h, idx.h, C.byref(mo), C.byref(queries.c), n_threads, C.byref(res)))
+    return Result(res.value)
+
+
+def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_text=True):
     """mpa_map_batches(): a stream of Queries batches through the pipelined mapper.  Returns the list of output texts
-    (bytes, one per batch; the hit-id counter runs across the batches as in one output file)."""
+    (bytes, one per batch; the hit-id counter runs across the batches as in one output file); with keep_results the pair
+    (texts, [Result]); with want_text=False no text is produced (texts are None)."""
     n = len(batches)
+    if n == 0:
+        return ([], []) if keep_results else []
     qb = (QBatch * n)(*[b.c for b in batches])
-    name_arrays = [(C.c_char_p * len(b.names))(*[x.encode() for x in b.names]) for b in batches]
-    names = (C.POINTER(C.c_char_p) * n)(*[C.cast(a, C.POINTER(C.c_char_p)) for a in name_arrays])
     res = (C.c_void_p * n)()
-    text = (C.c_void_p * n)()
-    tlen = (C.c_int64 * n)()
     idc = C.c_int64(0)
-    _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc), text, tlen))
-    out = []
+    if want_text:
+        name_arrays = [(C.c_char_p * len(b.names))(*[x.encode() for x in b.names]) for b in batches]
+        names = (C.POINTER(C.c_char_p) * n)(*[C.cast(a, C.POINTER(C.c_char_p)) for a in name_arrays])
+        text = (C.c_void_p * n)()
+        tlen = (C.c_int64 * n)()
+        _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc), text, tlen))
+    else:
+        _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, None, n_threads, res, None, None, None))
+    out, results = [], []
     for k in range(n):
-        out.append(C.string_at(text[k], tlen[k]))
-        lib().mpa_free(C.c_void_p(text[k]))
-        lib().mpa_result_destroy(C.c_void_p(res[k]))
-    return out
+        if want_text:
+            out.append(C.string_at(text[k], tlen[k]))
+            lib().mpa_free(C.c_void_p(text[k]))
+        else:
+            out.append(None)
+        if keep_results:
+            results.append(Result(res[k]))
+        else:
+            lib().mpa_result_destroy(C.c_void_p(res[k]))
+    return (out, results) if keep_results else out
 
 
 def dp_run(ctx, idx, dpopt, queries, tasks):

@@ -65,6 +65,7 @@ struct HostPinned {
 		cap = want;
 		return MPA_OK;
 	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr, cap = 0; }
 	template<typename T> T *as() { return (T*)p; }
 };
 
@@ -248,11 +249,16 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
 	mpa_ctx_s *ctx = new mpa_ctx_s();
 	ctx->device = device;
-	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return nullptr; }
-	for (auto &e : ctx->ev) (void)hipEventCreate(&e);
-	for (auto &st : ctx->side) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-	for (auto &e : ctx->lev) (void)hipEventCreate(&e);
-	(void)hipEventCreate(&ctx->fork_ev);
+	bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+	for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	ok = ok && hipEventCreate(&ctx->fork_ev) == hipSuccess;
+	if (!ok) {                                            // a null handle would silently alias the legacy default stream
+		set_error("creating the context's HIP streams/events failed");
+		mpa_ctx_destroy(ctx);
+		return nullptr;
+	}
 	if (const char *s = getenv("MPA_TB_BUDGET_MB")) ctx->tb_budget = (size_t)atoll(s) << 20;
 	return ctx;
 }
@@ -263,13 +269,19 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	for (mpa_ctx_s *sb : ctx->siblings) mpa_ctx_destroy(sb);
 	ctx->siblings.clear();
 	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	SeedBufs &B = ctx->seed;
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff }) b->release();
-	for (auto &e : ctx->ev) (void)hipEventDestroy(e);
-	for (auto &e : ctx->lev) (void)hipEventDestroy(e);
-	(void)hipEventDestroy(ctx->fork_ev);
-	for (auto &st : ctx->side) (void)hipStreamDestroy(st);
-	(void)hipStreamDestroy(ctx->stream);
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey,
+	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
+	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count }) b->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits }) h->release();
+	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
+	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+	for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
+	if (ctx->seed_stream && ctx->seed_stream != ctx->stream) (void)hipStreamDestroy(ctx->seed_stream);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
@@ -494,7 +506,7 @@ void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset)
 	if (reset) ctx->total = mpa_dp_stats_t();
 }
 
-int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
+static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
                int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
 {
 	if (cigar_pool) *cigar_pool = nullptr;
@@ -524,6 +536,12 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		DTask &t = T[k];
 		memset(&t, 0, sizeof(t));
 		if (x.nl < 0 || x.al <= 0 || x.qid < 0 || x.qid >= q->n_seq || x.io < 0 || x.io > 32000) { set_error("malformed DP task"); return MPA_ERR_ARG; }
+		// the kernels address the resident genome and the query buffer with these: a window or a protein slice that leaves its
+		// contig / its query would read foreign memory (or fault the context), so it is refused here
+		if (x.vid < 0 || x.vid >= 2 * (int32_t)mi->ctg.size() || x.nt_off < 0 || x.nt_off + (int64_t)x.nl > mi->ctg[x.vid >> 1].len ||
+		    x.aa_off < 0 || (int64_t)x.aa_off + x.al > q->q_off[x.qid + 1] - q->q_off[x.qid]) {
+			set_error("DP task " + std::to_string(k) + " reaches outside its contig or its query"); return MPA_ERR_ARG;
+		}
 		t.nt_off = x.nt_off, t.vid = x.vid, t.nl = x.nl, t.al = x.al, t.flag = x.flag, t.io = x.io;
 		t.q_off = q->q_off[x.qid] + x.aa_off - q->q_off[0];     // relative to the slice uploaded below
 		t.ncol = (x.al + 7) / 8 * 8;
@@ -904,6 +922,12 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 		t.launches_ext += st.launches_ext, t.launches_glob += st.launches_glob;
 	}
 	return MPA_OK;
+}
+
+int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
+               int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_dp_run_impl(ctx, mi, opt, q, n, in, rst, cigar_pool, n_pool); });
 }
 
 } // extern "C"

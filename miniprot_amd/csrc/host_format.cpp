@@ -359,6 +359,28 @@ static int64_t format_batch(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const 
 	return (int64_t)s.size();
 }
 
+// how many hit records mpa_format_output() prints for this batch = how far it advances the running hit id (map.c:298-306)
+extern "C" int64_t mpa_result_n_output(const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const mpa_result_t *r)
+{
+	const mpa_hit_t *hits = mpa_result_hits(r);
+	const int64_t *off = mpa_result_hit_off(r);
+	int64_t n = 0;
+	for (int32_t i = 0; i < q->n_seq; ++i) {
+		const int64_t n_reg = off[i + 1] - off[i];
+		if (n_reg == 0) continue;
+		const int32_t best_sc = hits[off[i]].has_aln ? hits[off[i]].dp_max : hits[off[i]].chn_sc;
+		const int32_t qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
+		for (int64_t j = 0; j < n_reg && j < opt->out_n; ++j) {
+			const mpa_hit_t &h = hits[off[i] + j];
+			const int32_t sc = h.has_aln ? h.dp_max : h.chn_sc;
+			if (sc <= 0 || sc < (double)best_sc * opt->out_sim) continue;
+			if (h.qe - h.qs < (double)qlen * opt->out_cov) continue;
+			++n;
+		}
+	}
+	return n;
+}
+
 extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                                   const mpa_result_t *r, char **out)
 {
@@ -367,8 +389,14 @@ extern "C" int64_t mpa_format_paf(const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 	return format_batch(mi, &o, q, names, r, nullptr, out);
 }
 
-extern "C" int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+static int64_t mpa_format_output_impl(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
                                      const mpa_result_t *r, int64_t *id_io, char **out)
 {
 	return format_batch(mi, opt, q, names, r, id_io, out);
+}
+
+extern "C" int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const char *const *names,
+                                     const mpa_result_t *r, int64_t *id_io, char **out)
+{
+	return mpa::guarded<int64_t>((int64_t)MPA_ERR_HIP, [&] { return mpa_format_output_impl(mi, opt, q, names, r, id_io, out); });
 }

@@ -1008,9 +1008,14 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
 	return n;
 }
 
-mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+static mpa_batch_t *mpa_batch_begin_impl(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
 {
 	return batch_begin_impl(nullptr, mi, opt, q, n_threads);
+}
+
+mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+{
+	return mpa::guarded<mpa_batch_t *>(nullptr, [&] { return mpa_batch_begin_impl(mi, opt, q, n_threads); });
 }
 
 int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpopt_t *opt)
@@ -1034,7 +1039,7 @@ int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpop
 	return (int64_t)b->tasks.size();
 }
 
-int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool)
+static int mpa_batch_dp_results_impl(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool)
 {
 	double t0 = now_ms();
 	if (b->round == 1) { take_round1_emit_round2(b, rst, cigar_pool); b->round = 2; timing_note("take 1 / emit 2", now_ms() - t0); }
@@ -1044,7 +1049,12 @@ int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t
 	return MPA_OK;
 }
 
-mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
+int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_batch_dp_results_impl(b, rst, cigar_pool); });
+}
+
+static mpa_result_t *mpa_batch_finish_impl(mpa_batch_t *b)
 {
 	double t_fin = now_ms();
 	mpa_result_s *res = new mpa_result_s();
@@ -1080,6 +1090,11 @@ mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
 	delete b;
 	timing_note("batch_finish (flatten)", now_ms() - t_fin);
 	return res;
+}
+
+mpa_result_t *mpa_batch_finish(mpa_batch_t *b)
+{
+	return mpa::guarded<mpa_result_t *>(nullptr, [&] { return mpa_batch_finish_impl(b); });
 }
 
 int64_t mpa_result_n_hit(const mpa_result_t *r) { return (int64_t)r->hits.size(); }
@@ -1124,7 +1139,7 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 
 // Several mini-batches as a three-stage software pipeline: [seed..plan of batch k+1] | [DP rounds of batch k on the GPU]
 // | [flatten + format batch k-1].  Each stage is one host thread driving its own worker-pool lane.
-int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
 {
 	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
@@ -1149,7 +1164,8 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	if (!seed_ctx[0] || !seed_ctx[1]) return MPA_ERR_HIP;
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
-	std::thread seeder([&] {
+	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
+	std::thread seeder([&] { try {
 		tl_pool_lane = 1, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{	// stay at most one batch ahead of the planner (its result lives in one of two seeding contexts)
@@ -1163,8 +1179,8 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 			slot[k].b = b, slot[k].seeded = true;
 			cv.notify_all();
 		}
-	});
-	std::thread planner([&] {
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("seeding stage: ") + e.what()); } });
+	std::thread planner([&] { try {
 		tl_pool_lane = 3;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{	// stay at most one batch ahead of the ones in their DP rounds
@@ -1177,8 +1193,8 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 			slot[k].begun = true, ++n_planned;
 			cv.notify_all();
 		}
-	});
-	std::thread finisher([&] {
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("planning stage: ") + e.what()); } });
+	std::thread finisher([&] { try {
 		tl_pool_lane = 2, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{
@@ -1190,11 +1206,11 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 			slot[k].b = nullptr;
 			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], id_io, &text[k]);
 		}
-	});
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("output stage: ") + e.what()); } });
 	// DP lanes: lane d drives the DP rounds of batches d, d + n_lanes, ... on its own device context (streams + buffers).
 	// The rounds of one batch are dominated by the tails of a few very long DP calls, during which the GPU is nearly
 	// idle; the next batch's rounds fill that space.
-	auto dp_lane = [&](int d, mpa_ctx_t *cd) {
+	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
 		tl_thread_div = 4;
 		for (int32_t k = d; k < n_batches; k += n_lanes) {
 			{
@@ -1208,7 +1224,7 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 			slot[k].dp_done = true, ++n_dp_done;
 			cv.notify_all();
 		}
-	};
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("DP lane: ") + e.what()); } };
 	std::vector<std::thread> lanes;
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
@@ -1227,7 +1243,13 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
 	return rc_all;
 }
 
-int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
+int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                    const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batches_impl(ctx, mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len); });
+}
+
+static int mpa_map_batch_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
 {
 	*out = nullptr;
 	if (!ctx) { set_error("mpa_map_batch needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
@@ -1257,9 +1279,10 @@ int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 	std::vector<int> rc(n_sub, MPA_OK);
 	std::vector<std::string> err(n_sub);
 	std::vector<std::thread> th;
+	std::vector<mpa_ctx_t*> sub_ctx(n_sub, nullptr);
+	for (int s = 0; s < n_sub; ++s) if (!(sub_ctx[s] = ctx_sibling(ctx, s))) return MPA_ERR_HIP;   // (before any thread exists)
 	for (int s = 0; s < n_sub; ++s) {
-		mpa_ctx_t *cs = ctx_sibling(ctx, s);
-		if (!cs) return MPA_ERR_HIP;
+		mpa_ctx_t *cs = sub_ctx[s];
 		th.emplace_back([&, s, cs]() {
 			mpa_qbatch_t sq{ cut[s + 1] - cut[s], q->seqs, q->q_off + cut[s] };
 			if (sq.n_seq > 0) rc[s] = run_batch_on(cs, mi, opt, &sq, n_threads, &part[s]);
@@ -1287,6 +1310,11 @@ int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 	res->hit_off[q->n_seq] = (int64_t)res->hits.size();
 	*out = res;
 	return MPA_OK;
+}
+
+int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batch_impl(ctx, mi, opt, q, n_threads, out); });
 }
 
 } // extern "C"

@@ -158,7 +158,7 @@ int mpa_idx_dump(const char *fn, const mpa_idx_t *mi)
 
 // Genome-only index built from nt4 codes in memory (no k-mer table): enough for the DP operator
 // (mpa_dp_run) and used by the operator-level parity tests.  Packing follows ntseq.c:56-70.
-mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4)
+static mpa_idx_t *mpa_idx_from_nt4_impl(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4)
 {
 	mpa_idx_s *mi = new mpa_idx_s();
 	mpa_idxopt_init(&mi->opt);
@@ -175,6 +175,11 @@ mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64
 	mi->ki.assign((size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit), 0);
 	compute_block_offsets(mi);
 	return mi;
+}
+
+mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64_t *lens, const uint8_t *nt4)
+{
+	return mpa::guarded<mpa_idx_t *>(nullptr, [&] { return mpa_idx_from_nt4_impl(n_ctg, names, lens, nt4); });
 }
 
 // mp_idx_build (index.c:97-136) = mp_ntseq_read (ntseq.c:29-75) + the k-mer table: FASTA (plain or gzip) -> index.
@@ -205,7 +210,7 @@ mpa_idx_t *mpa_idx_build(const char *fn, const mpa_idxopt_t *io, int n_threads)
 // Build the k-mer -> block table of an index whose genome is already loaded.  Same result as
 // build_worker + build_bidx (index.c:52-95): every (contig,strand) is sketched in all three frames with
 // the index parameters, then a counting sort lays the block ids out bucket by bucket, strands in order.
-int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads)
+static int mpa_idx_build_kmers_impl(mpa_idx_t *mi, int n_threads)
 {
 	const int32_t n_strand = (int32_t)mi->ctg.size() * 2;
 	std::vector<std::vector<uint64_t>> sk(n_strand);
@@ -235,6 +240,11 @@ int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads)
 	std::vector<int64_t> fill(mi->ki);
 	for (const auto &v : sk) for (uint64_t x : v) mi->kb[fill[x >> 32]++] = (uint32_t)x;
 	return MPA_OK;
+}
+
+int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_idx_build_kmers_impl(mi, n_threads); });
 }
 
 void mpa_idx_destroy(mpa_idx_t *mi)

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstddef>
 #include <string>
+#include <new>
+#include <exception>
 #include <vector>
 #include "../../include/mpamd.h"
 
@@ -22,6 +24,14 @@ int set_trans_code(int code);        // ns_make_tables (nasw-tab.c:85); returns 
 extern const char *const kAA;        // "ARNDCQEGHILKMFPSTWYV*X"
 
 void set_error(const std::string &msg);
+// no C++ exception may cross the C ABI: the extern "C" entry points run their bodies through this
+template<typename R, typename F> static inline R guarded(R on_error, F f)
+{
+	try { return f(); }
+	catch (const std::bad_alloc&) { set_error("out of host memory"); }
+	catch (const std::exception &e) { set_error(std::string("internal error: ") + e.what()); }
+	return on_error;
+}
 
 // MPA_TIMING=1 prints wall-clock stage timings to stderr
 double now_ms();

@@ -59,8 +59,8 @@ def gpu_executor(ctx):
     return run
 
 
-def map_batch(idx, mo, queries, executor, n_threads=1):
-    """Returns the PAF text (bytes) of the batch."""
+def map_batch_result(idx, mo, queries, executor, n_threads=1):
+    """The batch through the stage machine with `executor` for the DP rounds; returns the structured result (mpa.Result)."""
     L = mpa.lib()
     b = L.mpa_batch_begin(idx.h, C.byref(mo), C.byref(queries.c), n_threads)
     if not b:
@@ -76,26 +76,15 @@ def map_batch(idx, mo, queries, executor, n_threads=1):
         rst = np.ascontiguousarray(rst)
         pool = np.ascontiguousarray(pool, dtype=np.uint32)
         mpa._check(L.mpa_batch_dp_results(b, rst.ctypes.data, pool.ctypes.data))
-    res = L.mpa_batch_finish(b)
-    return format_paf(idx, mo, queries, res)
+    return mpa.Result(L.mpa_batch_finish(b))
 
 
-def format_paf(idx, mo, queries, res):
-    L = mpa.lib()
-    names = (C.c_char_p * len(queries.names))(*[n.encode() for n in queries.names])
-    out = C.c_void_p()
-    idc = C.c_int64(0)
-    n = L.mpa_format_output(idx.h, C.byref(mo), C.byref(queries.c), names, res, C.byref(idc), C.byref(out))
-    if n < 0:
-        raise mpa.MpaError(mpa.last_error())
-    txt = C.string_at(out.value, n)
-    L.mpa_free(out)
-    L.mpa_result_destroy(res)
-    return txt
+def map_batch(idx, mo, queries, executor, n_threads=1):
+    """Returns the output text (bytes) of the batch."""
+    res = map_batch_result(idx, mo, queries, executor, n_threads)
+    return mpa.format_output(idx, mo, queries, res)[0]
 
 
 def map_batch_gpu(ctx, idx, mo, queries, n_threads=1):
-    L = mpa.lib()
-    res = C.c_void_p()
-    mpa._check(L.mpa_map_batch(ctx.h, idx.h, C.byref(mo), C.byref(queries.c), n_threads, C.byref(res)))
-    return format_paf(idx, mo, queries, res)
+    res = mpa.map_batch(ctx, idx, mo, queries, n_threads)
+    return mpa.format_output(idx, mo, queries, res)[0]

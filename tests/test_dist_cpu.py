@@ -1,9 +1,11 @@
-"""The N>1 path on CPU: two gloo ranks map disjoint protein shards (host logic + oracle DP executor) and
-gather the PAF text to rank 0; the concatenation must equal the single-process output."""
+"""The N>1 path on CPU: two gloo ranks share the mini-batches of one job (host logic + oracle DP executor, the same
+miniprot_amd.dist.run_sharded() that bench.py --gpus N drives with the HIP mapper) and rank 0 must end up with the bytes of
+the single-process run -- for PAF, and for GFF3/GTF whose hit ids run across the whole output file (map.c:306)."""
 import os
 import subprocess
 import sys
 import numpy as np
+import pytest
 import miniprot_amd.dist as mdist
 import refbind
 
@@ -12,20 +14,27 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "tools"))
 import torch, torch.distributed as dist
 import miniprot_amd as mpa, miniprot_amd.dist as mdist, golden
-from hostpipe import map_batch, oracle_executor
+from hostpipe import map_batch_result, oracle_executor
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo")
 case = golden.SYNTH_CASES[0]
 contigs, prots, names = golden.synth_inputs(case)
-prots, names = prots[:10], names[:10]
 idx = mpa.Index.from_nt4(contigs, ["chr1"])
 mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 2))
-lo, hi = mdist.shard_range(len(prots), rank, world)
-paf = map_batch(idx, golden.mapopt_for(case), mpa.Queries(prots[lo:hi], names[lo:hi]), oracle_executor)
+cuts = [0, 3, 4, 9, 9, 14]                                  # five uneven mini-batches, one of them empty
+batches = [mpa.Queries(prots[a:b], names[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+for tag, flag in (("paf", 0x4), ("gff", 0x4 | 0x8), ("gtf", 0x4 | 0x20)):
+    mo = golden.mapopt_for(case)
+    mo.flag |= flag
+    needs_ids = bool(flag & (0x8 | 0x20))
+    def map_mine(ks):
+        rs = [map_batch_result(idx, mo, batches[k], oracle_executor) for k in ks]
+        return rs if needs_ids else [mpa.format_output(idx, mo, batches[k], r)[0] for k, r in zip(ks, rs)]
+    texts, n_ids = mdist.run_sharded(len(batches), rank, world, torch.device("cpu"), needs_ids, map_mine,
+                                     lambda k, r: r.n_output(mo, batches[k]), lambda k, r, id0: mpa.format_output(idx, mo, batches[k], r, id0)[0])
+    if rank == 0:
+        open(sys.argv[2] + "." + tag, "wb").write(b"".join(texts))
 dist.barrier()
-parts = mdist.gather_bytes(paf, rank, world, torch.device("cpu"))
-if rank == 0:
-    open(sys.argv[2], "wb").write(b"".join(parts))
 dist.destroy_process_group()
 '''
 
@@ -36,22 +45,31 @@ def test_shard_range_covers_everything():
             cuts = [mdist.shard_range(n, r, w) for r in range(w)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            assert sorted(k for r in range(w) for k in mdist.my_batches(n, r, w)) == list(range(n))
 
 
-def test_two_rank_gloo_gather_equals_single_process(tmp_path, oracle_built):
+def test_two_rank_gloo_job_equals_single_process(tmp_path, oracle_built):
     import miniprot_amd as mpa
     import golden
-    from hostpipe import map_batch, oracle_executor
+    from hostpipe import map_batch_result, oracle_executor
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    out = tmp_path / "gathered.paf"
+    out = str(tmp_path / "gathered")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29617", str(script), refbind.ROOT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", "29617", str(script), refbind.ROOT, out], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     case = golden.SYNTH_CASES[0]
     contigs, prots, names = golden.synth_inputs(case)
     idx = mpa.Index.from_nt4(contigs, ["chr1"])
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 2))
-    single = map_batch(idx, golden.mapopt_for(case), mpa.Queries(prots[:10], names[:10]), oracle_executor)
-    assert out.read_bytes() == single
+    q = mpa.Queries(prots[:14], names[:14])
+    for tag, flag in (("paf", 0x4), ("gff", 0x4 | 0x8), ("gtf", 0x4 | 0x20)):
+        mo = golden.mapopt_for(case)
+        mo.flag |= flag
+        single = mpa.format_output(idx, mo, q, map_batch_result(idx, mo, q, oracle_executor))[0]
+        got = open(out + "." + tag, "rb").read()
+        assert got == single, tag
+        if tag == "gff":                                        # the ids really do run across the ranks' batches
+            ids = [l.split(b"ID=MP")[1][:6] for l in got.split(b"\n") if b"\tmRNA\t" in l]
+            assert len(ids) > 5 and ids == [b"%06d" % (k + 1) for k in range(len(ids))]

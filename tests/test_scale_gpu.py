@@ -1,0 +1,101 @@
+"""Whole-path parity at SCALE on the GPU, against the reference binary run live on the same box (oracle/_ref/miniprot travels
+with the repo).  These are the regimes the small golden cases never reach: `-I` at hundreds of Mbp with N runs and tandem
+paralogs, mini-batches big enough that the library switches GPU seeding and the GPU refinement scan on BY ITSELF (thresholds of
+host_map.cpp left at their defaults), `-G 500000` with 250 000-row extension windows, and the widest extension classes
+(k_ext_wide<8>, k_ext_wide<16>).  About two minutes in total."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+import miniprot_amd as mpa
+import refbind
+import gen_synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(refbind.REF_BIN), reason="oracle/_ref/miniprot not present")]
+NCPU = os.cpu_count() or 4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mpa.Context(0)
+    yield c
+    c.close()
+
+
+def _reference(tmp_path, idx, prots, names, flags):
+    mpi, faa = str(tmp_path / "g.mpi"), str(tmp_path / "p.faa")
+    idx.dump(mpi)
+    gen_synth.write_fasta_aa(faa, prots, names)
+    out = subprocess.run([refbind.REF_BIN, "-t%d" % NCPU] + flags + [mpi, faa], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    os.remove(mpi)
+    return out
+
+
+def _first_difference(ours, ref):
+    for k, (x, y) in enumerate(zip(ours.split(b"\n"), ref.split(b"\n"))):
+        if x != y:
+            return "line %d\n ours %r\n ref  %r" % (k, x[:400], y[:400])
+    return "lengths differ: %d vs %d bytes" % (len(ours), len(ref))
+
+
+def test_genome_scale_batch_with_default_thresholds(ctx, tmp_path, monkeypatch, capfd):
+    """360 Mbp in 3 contigs (5 % N runs, 2 % tandem paralogs) x 2 400 proteins, -I -u, as TWO mini-batches of 1 200 through
+    mpa_map_batches: more than 8 M anchors and 100 M refinement-window bases per batch, so both device stages engage on their
+    own (checked from the library's timing notes), and every output byte equals the reference's."""
+    for v in ("MPA_GPU_SEED", "MPA_GPU_REFINE"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("MPA_TIMING", "1")
+    contigs, prots, names = gen_synth.generate(360_000_000, 3, 2400, 5, mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02)
+    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(3)])
+    del contigs
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, min(64, NCPU)))
+    idx.to_device(ctx)
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+    assert mo.max_intron > 60000
+    batches = [mpa.Queries(prots[i:i + 1200], names[i:i + 1200]) for i in (0, 1200)]
+    ours = b"".join(mpa.map_batches(ctx, idx, mo, batches, min(64, NCPU)))
+    notes = capfd.readouterr().err
+    assert "seeding on the GPU" in notes and "refinement scan on the GPU" in notes, "the device stages did not switch on by themselves"
+    ref = _reference(tmp_path, idx, prots, names, ["-I", "-u"])
+    assert ours == ref, _first_difference(ours, ref)
+    assert ours.count(b"\n") >= 2400
+    idx.close()
+
+
+def _chimeras(rng, planted, tails):
+    """proteins whose seeds cover one end only: a planted protein's first (or last) 140 residues + a random tail, so that the
+    extension call at the other end is `tail` columns wide"""
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    out = []
+    for k, tail in enumerate(tails):
+        p = bytes(planted[k % len(planted)])
+        junk = aa[rng.integers(0, 20, tail)].tobytes()
+        out.append(p[:140] + junk if k % 2 == 0 else junk + p[-140:])
+    return out
+
+
+def test_long_introns_and_the_widest_extension_classes(ctx, tmp_path):
+    """-G 500000 (max_intron = bw = 500 000: extension windows of 250 000 rows, align.c:260-261) on a 60 Mbp contig with
+    long-intron genes (>= 4 exons, introns to 450 kb), plus chimeric proteins whose unanchored ends are 300..1000 residues
+    wide: extension calls of every wide class (k_ext_wide<2> .. <16>) at full window length.  Bytes equal the reference's."""
+    contigs, prots, names, planted = gen_synth.generate(60_000_000, 1, 60, 9, mu=10.5, sigma=1.2, imin=1000, imax=450000, min_exons=4, return_planted=True)
+    rng = np.random.default_rng(99)
+    chim = _chimeras(rng, planted, [100, 100, 200, 230, 300, 400, 500, 520, 600, 800, 900, 1000])
+    prots = list(prots) + chim
+    names = list(names) + ["chim%02d" % k for k in range(len(chim))]
+    idx = mpa.Index.from_nt4(contigs, ["chr1"])
+    del contigs
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, min(32, NCPU)))
+    idx.to_device(ctx)
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    mo.max_intron = mo.bw = 500000
+    ours, results = mpa.map_batches(ctx, idx, mo, [mpa.Queries(prots, names)], min(64, NCPU), keep_results=True)
+    st = ctx.dp_stats(total=True)
+    assert st["n_ext"] > 100 and st["cells_ext"] > 1.5e9           # the long windows were really swept
+    ref = _reference(tmp_path, idx, prots, names, ["-G", "500000", "-u"])
+    assert ours[0] == ref, _first_difference(ours[0], ref)
+    idx.close()
