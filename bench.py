@@ -30,6 +30,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# The DP executor runs the kernel classes of a round on separate HIP streams; the runtime reads its number of hardware queues
+# when it initialises, and torch initialises it before libmpamd.so (which sets the same default when loaded) is even imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

@@ -26,8 +26,8 @@ struct DTask {
 };
 
 // Per-row record produced by the prep kernel, one uint32 per window row i:
-//   byte0 8*nas[i]      nas = amino acid (aa20 code) of the codon ending at row i, 21 when undefined; stored
-//                       times 8 because it is used directly as a byte offset into an LDS profile column
+//   byte0 2*nas[i]      nas = amino acid (aa20 code) of the codon ending at row i, 21 when undefined; stored
+//                       times 2 because it is used directly as a byte offset into an int16 LDS profile column
 //   byte1 donor[i+1]    (int8)  penalty of an intron whose first base is row i+2
 //   byte2 gei[i]        (uint8) gap-extension of D at this row: fs when nas[i] is a stop, else ge
 //   byte3 acceptor[i]   (int8)  penalty of an intron whose last base is row i
@@ -58,6 +58,18 @@ struct GlobWave {
 	int32_t max_nl;
 	int32_t pad_[3];
 };
+
+// One 256-thread workgroup of k_dp_round: which kind of DP unit(s) its four waves work on.
+enum DpUnitKind : int32_t {
+	U_EXT16 = 0, U_EXT32, U_EXT64,      // up to four independent extension waves (16 / 32 / 64 lanes per call), descriptors first .. first+count
+	U_EXT_W2,                           // up to two two-wave extension groups
+	U_EXT_W4,                           // one four-wave extension group
+	U_EXT_SPLIT,                        // a quarter (or half) of a 1024- (512-) column pair of calls: blk of n_blk
+	U_GLOB16, U_GLOB32, U_GLOB64,       // up to four independent traceback waves
+	U_GLOB_MB,                          // ... block-major ones (more than 1024 columns)
+	U_GLOB_W2, U_GLOB_W4                // two two-wave / one four-wave traceback group(s)
+};
+struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; };
 
 struct DpConst {         // scalar scoring parameters, passed by value
 	int32_t go, ge, fs, xdrop, end_bonus;

@@ -89,7 +89,7 @@ struct mpa_ctx_s {
 	hipEvent_t ev[6] = {};
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
-	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey;
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey, xg;
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -181,7 +181,7 @@ static int ext_class_of(int32_t ncol)
 static hipError_t launch_ext_narrow(const ExtArgs &a, const int *first, const int *cnt, hipStream_t s)
 {
 	// LDS of the largest instantiation (G = 16: 4 rings)
-	const size_t lds = (size_t)2 * 64 * PROF_COL_STRIDE + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4;
+	const size_t lds = (((size_t)2 * 64 * PROF_COL_STRIDE + 7) & ~(size_t)7) + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4;
 	NarrowMap m{};
 	for (int k = 0; k < 3; ++k) m.first[k] = first[k], m.cnt[k] = cnt[k];
 	hipLaunchKernelGGL(k_ext_narrow, dim3((unsigned)(cnt[0] + cnt[1] + cnt[2])), dim3(64), lds, s, a, m);
@@ -201,12 +201,16 @@ template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_g
 
 static hipError_t launch_ext_wide_class(int k, const ExtWideArgs &wa, int n_groups, hipStream_t s)
 {
-	switch (k) {
-	case 3: return launch_ext_wide<2>(wa, n_groups, s);
-	case 4: return launch_ext_wide<4>(wa, n_groups, s);
-	case 5: return launch_ext_wide<8>(wa, n_groups, s);
-	default: return launch_ext_wide<16>(wa, n_groups, s);
-	}
+	return k == 3 ? launch_ext_wide<2>(wa, n_groups, s) : launch_ext_wide<4>(wa, n_groups, s);
+}
+
+// classes 5 (257..512 columns) and 6 (513..1024): one launch of 256-thread workgroups, two / four per pair of calls
+static hipError_t launch_ext_wide_split(const ExtWideArgs &wa, int n8, int n16, hipStream_t s)
+{
+	const size_t lds = (size_t)4 * 2 * 22 * 64 * 2 + 12 * 4 * 4 + 64 * 8 + 128 * (2 * 4 + 1) * 4 + 96 * 8;
+	SplitMap m{ n16, n8, n8, 0 };                          // wa.waves: the class-5 groups, then the class-6 ones
+	hipLaunchKernelGGL(k_ext_wide_split, dim3((unsigned)(4 * n16 + 2 * n8)), dim3(256), lds, s, wa, m);
+	return hipGetLastError();
 }
 
 template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s)
@@ -272,7 +276,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	SeedBufs &B = ctx->seed;
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey,
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg,
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count }) b->release();
 	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits }) h->release();
@@ -665,6 +669,14 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
 	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));
+	// split classes: boundary granules (16 B per row and boundary: 3 boundaries per 1024-column group, 1 per 512-column group),
+	// then the per-group completion counters and the error flag; all zero before the launch (a granule's tag is row + 1)
+	const int64_t n_split = ewave_cnt[5] + ewave_cnt[6], n_bound = 3 * (int64_t)ewave_cnt[6] + ewave_cnt[5];
+	const size_t xg_bytes = (size_t)n_bound * key_stride * 16, xg_tail = ((size_t)n_split + 1) * 4;
+	if (n_split) {
+		if ((rc = ctx->xg.ensure(xg_bytes + xg_tail + 64))) return rc;
+		HIP_TRY(hipMemsetAsync(ctx->xg.p, 0, xg_bytes + xg_tail, s));
+	}
 	// extension calls wider than 1024 columns: keys (zeroed), then one GlobWave and one list entry per call
 	GlobWave *d_hw = nullptr;
 	int32_t *d_hlist = nullptr;
@@ -722,12 +734,24 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	ea.c = dc, ea.pen = pen;
 	ExtWideArgs wa;
 	wa.tasks = ea.tasks, wa.rec = ea.rec, wa.prof = ea.prof, wa.out = ea.out, wa.c = dc, wa.pen = pen, wa.key_stride = key_stride;
-	int64_t wide_groups_done = 0;
-	for (int cls = kNumExtClasses - 1; cls >= 3; --cls) {               // widest classes first
+	wa.xg = n_split ? ctx->xg.as<unsigned long long>() : nullptr;
+	wa.done = n_split ? (int32_t*)((char*)ctx->xg.p + xg_bytes) : nullptr;
+	wa.err = n_split ? wa.done + n_split : nullptr;
+	// rowkey slots follow the order of the wave descriptors (classes 3, 4, 5, 6)
+	int64_t rk_first[kNumExtClasses] = { 0 };
+	{ int64_t at = 0; for (int cls = 3; cls < kNumExtClasses; ++cls) rk_first[cls] = at, at += ewave_cnt[cls]; }
+	if (ewave_cnt[5] + ewave_cnt[6] > 0) {                              // the two widest classes first: four / two workgroups per pair of calls
+		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[5];
+		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[5] * 2 * key_stride;
+		hipStream_t st = begin_side(true);
+		HIP_TRY(launch_ext_wide_split(wa, ewave_cnt[5], ewave_cnt[6], st));
+		end_side();
+		ctx->stats.launches_ext++;
+	}
+	for (int cls = 4; cls >= 3; --cls) {
 		if (ewave_cnt[cls] == 0) continue;
 		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
-		wa.rowkey = ctx->rowkey.as<uint32_t>() + wide_groups_done * 2 * key_stride;
-		wide_groups_done += ewave_cnt[cls];
+		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[cls] * 2 * key_stride;
 		hipStream_t st = begin_side(true);
 		HIP_TRY(launch_ext_wide_class(cls, wa, ewave_cnt[cls], st));
 		end_side();
@@ -845,6 +869,11 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		if (l.is_ext) ms_ext_sum += ms;
 	}
 
+	if (n_split) {                                                        // a boundary hand-off that never arrived (bounded spin in the kernel)
+		int32_t kerr = 0;
+		HIP_TRY(hipMemcpy(&kerr, wa.err, 4, hipMemcpyDeviceToHost));
+		if (kerr) { set_error("k_ext_wide_split: a column-block hand-off between workgroups timed out"); return MPA_ERR_HIP; }
+	}
 	timing_note("  dp: upload+kernels (wall)", now_ms() - t_begin);
 	const double t_res = now_ms();
 	// ---- results

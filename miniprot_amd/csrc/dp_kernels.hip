@@ -36,6 +36,20 @@ namespace mpa {
 
 struct DevTables { uint8_t aa20[256]; uint8_t codon[64]; int8_t mat[484]; };
 
+// Where a wavefront sits: every DP body below is written for "a group of NW waves working on one unit" and is told its LDS
+// region, its lane, its wave index inside the group (scalar) and its thread index inside the group.  The stand-alone kernels
+// are one group per workgroup; k_dp_round packs several groups (e.g. four independent one-wave units) into a 256-thread
+// workgroup.
+struct WavePos { char *lds; int lane, w, tg; };
+__device__ __forceinline__ WavePos whole_block(char *lds)
+{
+	return WavePos{ lds, (int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)threadIdx.x };
+}
+// ordering of LDS writes and reads among the lanes of ONE wave: the LDS executes a wave's instructions in order, so only the
+// compiler has to be kept from moving them (a one-wave unit needs no s_barrier, and inside k_dp_round must not use one: the
+// other waves of the workgroup are on different units)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
@@ -164,7 +178,7 @@ __device__ __forceinline__ int32_t s_add(int32_t a, int32_t b) { return sat16(a 
 // K3: per-row records and query profiles
 // ------------------------------------------------------------------------------------------------
 struct PrepChunk { int32_t task; int32_t row0; };
-#define PROF_AA_STRIDE_REC 8   /* byte0 of a record = amino acid * 8 = byte offset into a profile column (k_ext) */
+#define PROF_AA_STRIDE_REC 2   /* byte0 of a record = amino acid * 2 = byte offset into an int16 profile column (k_ext) */
 
 // base of the strand-oriented contig at strand-local position x (ntseq.c:89-106 folded into addressing)
 __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off, int64_t len, int rev, int64_t x)
@@ -306,9 +320,12 @@ __global__ __launch_bounds__(256) void k_prep_prof(const DTask *tasks, const cha
 // written for a minimal instruction count:
 //   * row records come from a small LDS ring refilled 16 rows at a time (one coalesced global load per
 //     16 rows instead of two dependent loads per row);
-//   * the query profile sits in LDS with an 8-byte stride per amino acid, {score, score<<16}, so that the
-//     two halves of a lane fetch their score with `base + byte0(record)` (one SDWA add each) and combine
-//     with one OR;
+//   * the query profile sits in LDS as int16 [call][column][amino acid], 46 bytes per column (an odd number of
+//     16-bit words: the columns of a lane group fall into distinct banks); a row record carries 2 * amino acid
+//     in its low byte, so a lane's address is `base + byte0(record)` (one SDWA add per half) and the two halves
+//     of the packed register are filled by ds_read_u16_d16 / ds_read_u16_d16_hi -- no combining instruction.
+//     5.9 KB per wave instead of the 23.5 KB of a {score, score << 16} layout: LDS no longer caps a CU at six
+//     of these waves (it was the limiter of this kernel at batch sizes of a few thousand proteins);
 //   * donor/acceptor windows and the H/D rings are register rings indexed at compile time (rows are
 //     processed in groups of three), so no state is ever moved;
 //   * the best-row / x-drop bookkeeping is two saturating subtractions and one compare per row: a lane votes
@@ -325,20 +342,28 @@ struct ExtArgs {
 	PenTable pen;
 };
 
-#define PROF_AA_STRIDE 8                       /* bytes per amino acid inside one column of the LDS profile */
-#define PROF_COL_STRIDE 184                    /* bytes per column: 23 * 8, an odd number of 8-byte words    */
+#define PROF_AA_STRIDE 2                       /* bytes per amino acid inside one column of the LDS profile */
+#define PROF_COL_STRIDE 46                     /* bytes per column: 22 scores + 1 pad, an odd number of 16-bit words */
 
+// two int16 profile scores into the halves of one register (the compiler emits ds_read_u16_d16 + ds_read_u16_d16_hi)
+__device__ __forceinline__ uint32_t prof2(const char *lo, const char *hi)
+{
+	v2s r;
+	r.x = *(const int16_t*)lo, r.y = *(const int16_t*)hi;
+	return as_u(r);
+}
+
+#define EXT_NARROW_LDS ((((size_t)2 * 64 * PROF_COL_STRIDE + 7) & ~(size_t)7) + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4)   /* bytes per wave */
 template<int G>
-__device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
+__device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp, const WavePos wp)
 {
 	constexpr int NG = 64 / G;               // lane groups per wave
 	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
-	extern __shared__ uint32_t lds_raw[];
-	char *lds_prof = (char*)lds_raw;                                   // [NSLOT][G columns][23][2 x u32]
-	uint2 *lds_ring = (uint2*)(lds_prof + NSLOT * G * PROF_COL_STRIDE); // [NG][32 rows] {record of half 0, record of half 1}
+	char *lds_prof = wp.lds;                                           // [NSLOT][G columns][23] int16
+	uint2 *lds_ring = (uint2*)(lds_prof + ((NSLOT * G * PROF_COL_STRIDE + 7) & ~7)); // [NG][32 rows] {record of half 0, record of half 1}
 	int32_t *lds_pen = (int32_t*)(lds_ring + NG * 32);                 // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
 
-	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
+	const int lane = wp.lane, grp = lane / G, col = lane % G;
 	const DpConst c = a.c;
 	const uint32_t *recbase = a.rec + wvp->rec_base;
 	const int32_t max_nl = wvp->max_nl;
@@ -359,16 +384,15 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 	// ---- stage the profiles: global [22][pw] int16 -> LDS [col][aa]{lo, hi}
 	for (int s = 0; s < NSLOT; ++s) {
 		const int t = wvp->task[s];
-		if (t < 0) {   // the two halves of a lane are OR-ed together: an empty slot must read as zero
-			for (int k = lane; k < G * PROF_COL_STRIDE / 4; k += 64) ((uint32_t*)(lds_prof + s * G * PROF_COL_STRIDE))[k] = 0;
+		if (t < 0) {   // an empty slot scores zero everywhere (its half never reaches a result)
+			for (int k = lane; k < G * PROF_COL_STRIDE / 2; k += 64) ((uint16_t*)(lds_prof + s * G * PROF_COL_STRIDE))[k] = 0;
 			continue;
 		}
 		const DTask *tt = &a.tasks[t];
 		const int16_t *src = a.prof + tt->prof_off;
 		for (int k = lane; k < 22 * G; k += 64) {
 			const int aa = k / G, cc = k - aa * G;
-			const uint32_t v = (uint16_t)src[aa * tt->pw + cc];
-			*(uint2*)(lds_prof + (s * G + cc) * PROF_COL_STRIDE + aa * PROF_AA_STRIDE) = make_uint2(v, v << 16);
+			*(int16_t*)(lds_prof + (s * G + cc) * PROF_COL_STRIDE + aa * PROF_AA_STRIDE) = src[aa * tt->pw + cc];
 		}
 	}
 	for (int k = lane; k < MPA_PEN_MAX; k += 64) lds_pen[k] = a.pen.x[k], lds_pen[MPA_PEN_MAX + k] = a.pen.val[k];
@@ -380,7 +404,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 		lds_ring[grp * 32 + col] = make_uint2(recbase[roff[0] + col], recbase[roff[1] + col]);
 		pf = make_uint2(recbase[roff[0] + 16 + col], recbase[roff[1] + 16 + col]);
 	}
-	__syncthreads();
+	wave_sync();
 
 	// ---- per-lane constants
 	const uint32_t jge = splat16(col * c.ge), gojge = splat16(c.go + col * c.ge);
@@ -389,7 +413,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
 	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
 	const uint32_t pbase0 = (uint32_t)(((0 * NG + grp) * G + col) * PROF_COL_STRIDE);
-	const uint32_t pbase1 = (uint32_t)(((1 * NG + grp) * G + col) * PROF_COL_STRIDE) + 4;           // the <<16 copy
+	const uint32_t pbase1 = (uint32_t)(((1 * NG + grp) * G + col) * PROF_COL_STRIDE);
 	const uint2 *ring = lds_ring + grp * 32;
 
 	// ---- DP state: rings of three rows (compile-time indexed), A/B/C persist
@@ -447,9 +471,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 	uint2 rcur = ring[2], rnext = ring[3];                                 // records of rows i and i+1
 	uint32_t S;                                                            // profile scores of row i
 	{
-		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rcur.x & 0xff));
-		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rcur.y & 0xff));
-		S = s0 | s1;
+		S = prof2(lds_prof + pbase0 + (rcur.x & 0xff), lds_prof + pbase1 + (rcur.y & 0xff));
 	}
 
 	auto row = [&](auto kc) {
@@ -462,8 +484,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 			if (loader) lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
 		}
 		// next row's profile scores and the record of row i+2: issued first, consumed one row later
-		const uint32_t s0 = *(const uint32_t*)(lds_prof + pbase0 + (rnext.x & 0xff));
-		const uint32_t s1 = *(const uint32_t*)(lds_prof + pbase1 + (rnext.y & 0xff));
+		const uint32_t Snext = prof2(lds_prof + pbase0 + (rnext.x & 0xff), lds_prof + pbase1 + (rnext.y & 0xff));
 		const uint2 rnn = ring[(i + 2) & 31];
 		// unpack the record of row i: donor[i+1], acceptor[i], gap extension of this row
 		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);        // dn: R1 = donor[i-1], R2 = donor[i]... see below
@@ -514,7 +535,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp)
 			repack();
 		}
 		if (i == 2 && col == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;               // column -1 is -inf from row 3 on
-		S = s0 | s1;
+		S = Snext;
 		rcur = rnext, rnext = rnn;
 		++i;
 	};
@@ -560,11 +581,13 @@ struct NarrowMap { int32_t first[4], cnt[4]; };
 __global__ __launch_bounds__(64) void k_ext_narrow(ExtArgs a, NarrowMap m)
 {
 	int b = blockIdx.x;
-	if (b < m.cnt[0]) { ext_narrow<16>(a, a.waves + m.first[0] + b); return; }
+	extern __shared__ uint32_t lds_raw[];
+	const WavePos wp = whole_block((char*)lds_raw);
+	if (b < m.cnt[0]) { ext_narrow<16>(a, a.waves + m.first[0] + b, wp); return; }
 	b -= m.cnt[0];
-	if (b < m.cnt[1]) { ext_narrow<32>(a, a.waves + m.first[1] + b); return; }
+	if (b < m.cnt[1]) { ext_narrow<32>(a, a.waves + m.first[1] + b, wp); return; }
 	b -= m.cnt[1];
-	ext_narrow<64>(a, a.waves + m.first[2] + b);
+	ext_narrow<64>(a, a.waves + m.first[2] + b, wp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,29 +608,58 @@ struct ExtWideArgs {
 	const uint32_t *rec;
 	const int16_t *prof;
 	ExtOut *out;
-	uint32_t *rowkey;         // [2][max_nl] per workgroup, zero-initialised; offset = blockIdx.x * 2 * key_stride
+	uint32_t *rowkey;         // [2][max_nl] per group, zero-initialised; offset = group * 2 * key_stride
 	int64_t key_stride;
 	DpConst c;
 	PenTable pen;
+	// split classes only (k_ext_wide_split): column-block boundaries travel between workgroups through HBM
+	unsigned long long *xg;   // [boundary][key_stride rows][2] granules {payload, row + 1}, zero-initialised
+	int32_t *done;            // [group] workgroups of the group that have finished, zero-initialised
+	int32_t *err;             // set to 1 if a hand-off never arrived (bounded spin)
 };
 
-template<int NW>
-__global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
+// where a workgroup of the split kernel sits: group = pair of calls, blk = which quarter (or half) of its columns
+struct SplitPos { int32_t group, blk, n_blk, xg_first; };
+
+// One 8-byte granule {payload, tag} per value and row, written by ONE write-through store and polled with loads that bypass
+// the reader's L1 (MI355X_MICROARCH.md, hand-off by data-tagged granules): no fence, no separate flag.
+__device__ __forceinline__ void granule_put(unsigned long long *p, uint32_t payload, uint32_t tag)
 {
-	extern __shared__ uint32_t lds_raw[];
+	__hip_atomic_store(p, (unsigned long long)tag << 32 | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_get(const unsigned long long *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// NWB = waves of this workgroup.  SPLIT: the pair of calls spans pos.n_blk workgroups of NWB waves each; workgroup pos.blk
+// owns the columns [256 blk, 256 blk + 256) and receives the carry of the gap scan and the H of the column to its left, row
+// by row, from workgroup blk - 1 through HBM (it runs about fifty rows behind it), so that a 1024-column call occupies four
+// CUs with one wave per SIMD instead of one CU with four (782 -> ~370 ns per row: the tail of a DP round at genome scale).
+#define EXT_WIDE_LDS(NW) ((size_t)(NW) * 2 * 22 * 64 * 2 + 12 * (NW) * 4 + ((NW) <= 4 ? 64 : 128) * 8 + 128 * (2 * (NW) + 1) * 4 + 96 * 8)   /* bytes per group */
+template<int NWB, bool SPLIT>
+__device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int group_idx, const SplitPos pos, const WavePos wp)
+{
+	constexpr int NW = NWB;
 	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots and the record ring
-	int16_t *lds_prof = (int16_t*)lds_raw;
+	int16_t *lds_prof = (int16_t*)wp.lds;
 	constexpr int RING = NW <= 4 ? 64 : 128;                     // rows of records in LDS: the last wave runs 3 (NW - 1) rows behind the first
 	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 step parities][3 rows][NW] carry of the I scan
 	uint32_t *xH = xY + 6 * NW;                                  // [2 step parities][3 rows][NW] H of the block's last column
 	uint2 *ring = (uint2*)(xH + 6 * NW);                         // [RING rows] {record of half 0, record of half 1}
 	constexpr int KS = 2 * NW + 1;                               // dwords per row of the key ring (odd: the flush reads it row-parallel)
 	uint32_t *kring = (uint32_t*)(ring + RING);                  // [128 rows][NW][2 halves] per-row, per-block keys (see keys())
-	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
-	const ExtWave *wvp = &a.waves[blockIdx.x];
+	constexpr int XIN = 96;                                      // rows of incoming boundary values kept in LDS (two fetches of 48)
+	uint2 *xin = (uint2*)(kring + 128 * KS);                     // [XIN] {carry, H} from the workgroup to the left (SPLIT only; 128 KS is even)
+	const int lane = wp.lane, w = wp.w;                          // w: wave index inside the group, scalar
+	const int gw = SPLIT ? pos.blk * NWB + w : w;                // wave index inside the call: owns columns [64 gw, 64 gw + 64)
+	const bool has_left = SPLIT && pos.blk > 0, has_right = SPLIT && pos.blk + 1 < pos.n_blk;
+	const ExtWave *wvp = &a.waves[group_idx];
 	const DpConst c = a.c;
 	const uint32_t *recbase = a.rec + wvp->rec_base;
-	uint32_t *rowkey = a.rowkey + (int64_t)blockIdx.x * 2 * a.key_stride;
+	uint32_t *rowkey = a.rowkey + (int64_t)group_idx * 2 * a.key_stride;
+	unsigned long long *xg_out = SPLIT ? a.xg + ((int64_t)(pos.xg_first + pos.blk) * a.key_stride) * 2 : nullptr;
+	const unsigned long long *xg_in = SPLIT ? a.xg + ((int64_t)(pos.xg_first + pos.blk - 1) * a.key_stride) * 2 : nullptr;
 
 	int32_t tid[2], nl[2], al[2], ncol[2];
 	uint32_t roff[2];
@@ -625,11 +677,11 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		const DTask *t = &a.tasks[tid[h]];
 		const int16_t *src = a.prof + t->prof_off;
 		for (int k = lane; k < 22 * 64; k += 64) {
-			const int aidx = k >> 6, cc = k & 63, gcc = w * 64 + cc;
+			const int aidx = k >> 6, cc = k & 63, gcc = gw * 64 + cc;
 			lds_prof[(w * 2 + h) * 22 * 64 + k] = gcc < t->pw ? src[aidx * t->pw + gcc] : (int16_t)NEG16;
 		}
 	}
-	if (threadIdx.x < 12 * NW) xY[threadIdx.x] = NEGP;            // xY and xH are contiguous (NW * 64 threads >= 12 NW)
+	if (wp.tg < 12 * NW) xY[wp.tg] = NEGP;                       // xY and xH are contiguous (NW * 64 threads >= 12 NW)
 	// record ring, filled by the leading wave: rows [0,32) now, then 16 rows at a time (see k_ext)
 	const bool loader = w == 0 && lane < 16;
 	uint2 pf = make_uint2(0, 0);
@@ -637,7 +689,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	if (loader) pf = make_uint2(recbase[roff[0] + 32 + lane], recbase[roff[1] + 32 + lane]);
 	__syncthreads();
 
-	const int gc = w * 64 + lane;
+	const int gc = gw * 64 + lane;
 	const uint32_t jge = splat16(gc * c.ge), gojge = splat16(c.go + gc * c.ge);
 	const uint32_t ebv = pack16(gc == al[0] - 1 ? c.end_bonus : 0, gc == al[1] - 1 ? c.end_bonus : 0);
 	// live halves keep their value, dead halves read as -32768 in the row maximum
@@ -650,7 +702,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP;
 #pragma unroll
 	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
-	if (w == 0 && lane == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
+	if (gw == 0 && lane == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
 	{
 		const uint2 q0 = ring[0], q1 = ring[1];
 		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
@@ -659,7 +711,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	}
 	const int32_t max_nl = wvp->max_nl;
 	uint2 rpre = ring[2], rnxt = ring[3];
-	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
+	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 64), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 64));
 
 	uint32_t hxv[3];
 	// Per-row key of this block: the best (H + end bonus) and its column, ties to the smallest column, per half, as
@@ -686,6 +738,21 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 			}
 		}
 	};
+	// SPLIT, leading wave of a workgroup that has a left neighbour: the boundary values of rows [i0, i0 + 48) into the LDS
+	// ring, one row per lane, polling until the neighbour has written them (it is a few dozen rows ahead; the spin is bounded)
+	auto fetch_left = [&](int32_t i0) {
+		const int32_t r = i0 + lane;
+		const bool want = lane < 48 && r < max_nl;
+		unsigned long long gy = 0, gh = 0;
+		for (int spin = 0;; ++spin) {
+			if (want) gy = granule_get(xg_in + 2 * (int64_t)r), gh = granule_get(xg_in + 2 * (int64_t)r + 1);
+			const bool ok = !want || ((uint32_t)(gy >> 32) == (uint32_t)r + 1 && (uint32_t)(gh >> 32) == (uint32_t)r + 1);
+			if (__ballot(!ok) == 0) break;
+			if (spin > (1 << 22)) { if (lane == 0) *a.err = 1; break; }    // seconds: the producer is gone; give up loudly
+			__builtin_amdgcn_s_sleep(4);
+		}
+		if (want) xin[r % XIN] = make_uint2((uint32_t)gy, (uint32_t)gh);
+	};
 	auto row = [&](auto kc, int32_t i, int par) {                  // par: parity of the (three-row) step this row belongs to
 		constexpr int K = decltype(kc)::value;
 		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
@@ -703,10 +770,12 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
 		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
 		const uint32_t S = Spre;                                           // looked up during the previous row
-		Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 16), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 16));
-		// what the wave to the left produced for this same row in the previous step
-		const uint32_t carry_in = w > 0 ? xY[((par ^ 1) * 3 + K) * NW + w - 1] : NEGP;
-		const uint32_t left_h = w > 0 ? xH[((par ^ 1) * 3 + K) * NW + w - 1] : NEGP;
+		Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 64), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 64));
+		// what the wave to the left produced for this same row: in the previous step (same workgroup, through LDS) or some
+		// dozens of rows ago (the workgroup to the left, through HBM and the xin ring)
+		uint32_t carry_in = NEGP, left_h = NEGP;
+		if (w > 0) carry_in = xY[((par ^ 1) * 3 + K) * NW + w - 1], left_h = xH[((par ^ 1) * 3 + K) * NW + w - 1];
+		else if (has_left) { const uint2 v = xin[i % XIN]; carry_in = v.x, left_h = v.y; }
 		uint32_t h, t, u;
 		h = p_adds(Hs[R3], S);
 		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
@@ -725,10 +794,16 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 		h = p_max(h, p_subs(ex, gojge));
 		const uint32_t hs = shift1<64>(h, left_h, lane);
 		Hr[R3] = h, Hs[R3] = hs;
-		if (lane == 63) xY[(par * 3 + K) * NW + w] = p_max(carry_in, y), xH[(par * 3 + K) * NW + w] = h;
+		if (lane == 63) {
+			xY[(par * 3 + K) * NW + w] = p_max(carry_in, y), xH[(par * 3 + K) * NW + w] = h;
+			if (has_right && w == NW - 1) {                                  // the workgroup to the right reads these from HBM
+				granule_put(xg_out + 2 * (int64_t)i, p_max(carry_in, y), (uint32_t)i + 1);
+				granule_put(xg_out + 2 * (int64_t)i + 1, h, (uint32_t)i + 1);
+			}
+		}
 		// per-row key input: (H + end bonus), dead columns as -32768; reduced for the three rows of a step together (keys())
 		hxv[K] = (p_adds(h, ebv) & keepP) | deadP;
-		if (i == 2 && w == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
+		if (i == 2 && gw == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
 	};
 
 	// Wave w runs 3 w rows behind wave 0: one barrier per step of three rows (the exchange slots hold three rows), w
@@ -750,13 +825,19 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 						if ((v0 >> 6) > (b0 >> 6)) b0 = v0, w0 = ww;
 						if ((v1 >> 6) > (b1 >> 6)) b1 = v1, w1 = ww;
 					}
-					rowkey[r] = (b0 >> 6) << 16 | (0xffffu - (uint32_t)(w0 * 64 + 63 - (int32_t)(b0 & 63)));
-					rowkey[a.key_stride + r] = (b1 >> 6) << 16 | (0xffffu - (uint32_t)(w1 * 64 + 63 - (int32_t)(b1 & 63)));
+					const int32_t wb = SPLIT ? pos.blk * NWB : 0;
+					const uint32_t key0 = (b0 >> 6) << 16 | (0xffffu - (uint32_t)((wb + w0) * 64 + 63 - (int32_t)(b0 & 63)));
+					const uint32_t key1 = (b1 >> 6) << 16 | (0xffffu - (uint32_t)((wb + w1) * 64 + 63 - (int32_t)(b1 & 63)));
+					if (SPLIT) {                                               // best value, then smallest column, over the workgroups too
+						atomicMax(&rowkey[r], key0);
+						atomicMax(&rowkey[a.key_stride + r], key1);
+					} else rowkey[r] = key0, rowkey[a.key_stride + r] = key1;
 				}
 			}
 		};
 		hxv[0] = hxv[1] = hxv[2] = NEGP;
 		for (; i + 3 <= max_nl; i += 3, par ^= 1) {
+			if (has_left && w == 0 && (i - 2) % 48 == 0) fetch_left(i);
 			row(std::integral_constant<int, 0>(), i, par);
 			row(std::integral_constant<int, 1>(), i + 1, par);
 			row(std::integral_constant<int, 2>(), i + 2, par);
@@ -765,6 +846,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 			lds_barrier();
 		}
 		if (i < max_nl) {                                                  // one or two rows left
+			if (has_left && w == 0 && (i - 2) % 48 == 0) fetch_left(i);
 			row(std::integral_constant<int, 0>(), i, par);
 			if (i + 1 < max_nl) row(std::integral_constant<int, 1>(), i + 1, par);
 			keys(i, max_nl - i);
@@ -775,6 +857,14 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	for (int k = w; k < NW - 1; ++k) lds_barrier();
 	__threadfence();
 	__syncthreads();
+	if (SPLIT) {
+		// the replay needs the keys of every workgroup of the group: the last one to get here does it
+		int32_t *flag = (int32_t*)xin;
+		if (wp.tg == 0) *flag = atomicAdd(&a.done[pos.group], 1);
+		__syncthreads();
+		if (*flag != pos.n_blk - 1) return;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
 
 	// ---- replay of nasw-sse.c:423-443 over the per-row keys, one wave per half
 	if (w < 2 && tid[w] >= 0) {
@@ -828,6 +918,31 @@ __global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
 	}
 }
 
+template<int NW>
+__global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
+{
+	extern __shared__ uint32_t lds_raw[];
+	ext_wide_body<NW, false>(a, (int)blockIdx.x, SplitPos{ 0, 0, 1, 0 }, whole_block((char*)lds_raw));
+}
+
+// The two widest classes (513..1024 columns: four workgroups per pair of calls; 257..512: two) in one launch of 256-thread
+// workgroups.  Workgroups of a group are consecutive and in column order, so a workgroup's left neighbour is always
+// dispatched before it; a.waves = the 1024-column groups first (n16 of them), then the 512-column ones.
+struct SplitMap { int32_t n16, n8, first16, first8; };
+__global__ __launch_bounds__(256) void k_ext_wide_split(ExtWideArgs a, SplitMap m)
+{
+	const int bid = (int)blockIdx.x;
+	SplitPos pos;
+	int widx;
+	if (bid < 4 * m.n16) pos.group = bid >> 2, pos.blk = bid & 3, pos.n_blk = 4, pos.xg_first = 3 * pos.group, widx = m.first16 + pos.group;
+	else {
+		const int k = bid - 4 * m.n16;
+		pos.group = m.n16 + (k >> 1), pos.blk = k & 1, pos.n_blk = 2, pos.xg_first = 3 * m.n16 + (k >> 1), widx = m.first8 + (k >> 1);
+	}
+	extern __shared__ uint32_t lds_raw[];
+	ext_wide_body<4, true>(a, widx, pos, whole_block((char*)lds_raw));
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: global alignment with traceback.  int32 arithmetic, one column per lane, one call per group of
 // G lanes; matrices wider than 64 columns are swept in column blocks (block-major), each block leaving
@@ -857,13 +972,13 @@ __device__ __forceinline__ uint32_t push_neg(uint32_t acc, int32_t d) { return _
 // MB: the matrix may span several 64-column blocks (block-major sweep).  EXT: score-only extension call swept with this
 // kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
 // per-row key (best H + end bonus, first column) that k_ext_replay consumes.
+#define GLOB_NARROW_LDS ((size_t)22 * 64 * 2 + (size_t)4 * 32 * 4)   /* bytes per wave */
 template<int G, bool MB, bool EXT = false>
-__device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv)
+__device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv, const WavePos wp)
 {
 	constexpr int NG = 64 / G;
-	extern __shared__ uint32_t lds_raw[];
-	int16_t *lds_prof = (int16_t*)lds_raw;           // [NG][22][G] for the current column block
-	const int lane = threadIdx.x, grp = lane / G, col = lane % G;
+	int16_t *lds_prof = (int16_t*)wp.lds;            // [NG][22][G] for the current column block
+	const int lane = wp.lane, grp = lane / G, col = lane % G;
 	const DpConst c = a.c;
 	const int32_t tid = wv.task[grp];
 	DTask t;
@@ -883,7 +998,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		// the previous block's boundary records were written by this wave: make them visible (and drop L1)
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
 		// stage this block's profile columns
-		__syncthreads();
+		wave_sync();
 		for (int s = 0; s < NG; ++s) {
 			const int ts = wv.task[s];
 			if (ts < 0) continue;
@@ -894,13 +1009,13 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 				lds_prof[s * 22 * G + k] = gcc < tt->pw ? src[aidx * tt->pw + gcc] : (int16_t)NEG16;
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		// record ring (see k_ext): rows [0,16) now, rows [16,32) wait in pf, then 16 rows per refill
 		uint32_t *ring = (uint32_t*)(lds_prof + NG * 22 * G) + grp * 32;
 		const bool loader = col < 16;
 		uint32_t pf = 0;
 		if (loader) ring[col] = rec[col], pf = rec[16 + col];
-		__syncthreads();
+		wave_sync();
 		const int16_t *myprof = lds_prof + grp * 22 * G + col;
 		const int32_t seg = slen > 0 ? gc / slen : 0;
 		const bool seg_start = slen > 0 && gc % slen == 0;
@@ -922,7 +1037,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			if ((i & 15) == 0) { if (loader) pf = rec[i + 16 + col]; }
 			else if ((i & 15) == 12) { if (loader) ring[((i + 4) & 31) + col] = pf; }
 			const uint32_t rnn = ring[(i + 2) & 31];                      // two rows ahead: LDS latency is off the critical path
-			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
+			const int32_t nas = (rcur & 0xff) >> 1, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
 			const int32_t S = myprof[nas * G];
@@ -1000,20 +1115,23 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 {
 	int b = blockIdx.x;
-	if (b < m.cnt[0]) { glob_narrow<16, false>(a, a.waves[m.first[0] + b]); return; }
+	extern __shared__ uint32_t lds_raw[];
+	const WavePos wp = whole_block((char*)lds_raw);
+	if (b < m.cnt[0]) { glob_narrow<16, false>(a, a.waves[m.first[0] + b], wp); return; }
 	b -= m.cnt[0];
-	if (b < m.cnt[1]) { glob_narrow<32, false>(a, a.waves[m.first[1] + b]); return; }
+	if (b < m.cnt[1]) { glob_narrow<32, false>(a, a.waves[m.first[1] + b], wp); return; }
 	b -= m.cnt[1];
-	if (b < m.cnt[2]) { glob_narrow<64, false>(a, a.waves[m.first[2] + b]); return; }
+	if (b < m.cnt[2]) { glob_narrow<64, false>(a, a.waves[m.first[2] + b], wp); return; }
 	b -= m.cnt[2];
-	glob_narrow<64, true>(a, a.waves[m.first[3] + b]);
+	glob_narrow<64, true>(a, a.waves[m.first[3] + b], wp);
 }
 
 // Extension calls wider than 1024 columns: one wave per call, 64-column blocks swept one after the other (each all rows),
 // boundary records through HBM, per-row keys combined across blocks with 64-bit atomic maxima.
 __global__ __launch_bounds__(64) void k_ext_huge(GlobArgs a)
 {
-	glob_narrow<64, true, true>(a, a.waves[blockIdx.x]);
+	extern __shared__ uint32_t lds_raw[];
+	glob_narrow<64, true, true>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
 }
 
 // nasw-sse.c:423-443 replayed over per-row keys ((row max + 32768) << 32 | ~column): best row under the length penalty,
@@ -1076,15 +1194,14 @@ __global__ __launch_bounds__(64) void k_ext_replay(const DTask *tasks, const int
 // waves skewed by one row (see k_ext_wide); the boundary record travels through LDS instead of HBM and
 // the block-major passes of the narrow kernel collapse into one sweep of nl + NW steps.
 // ------------------------------------------------------------------------------------------------
+#define GLOB_WIDE_LDS(NW) ((size_t)(NW) * 22 * 64 * 2 + 2 * (NW) * 16 + 64 * 4)   /* bytes per group */
 template<int NW>
-__global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
+__device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave &wv, const WavePos wp)
 {
 	constexpr int G = 64;
-	extern __shared__ uint32_t lds_raw[];
-	int16_t *lds_prof = (int16_t*)lds_raw;                      // [NW][22][64]
+	int16_t *lds_prof = (int16_t*)wp.lds;                       // [NW][22][64]
 	int4 *xB = (int4*)(lds_prof + NW * 22 * 64);               // [2 parities][NW] boundary records
-	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, scalar
-	const GlobWave wv = a.waves[blockIdx.x];
+	const int lane = wp.lane, w = wp.w;                         // w: wave index inside the group, scalar
 	const DpConst c = a.c;
 	const int32_t tid = wv.task[0];
 	const DTask t = a.tasks[tid];
@@ -1100,7 +1217,7 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 			const int aidx = k >> 6, cc = k & 63, gcc = w * 64 + cc;
 			lds_prof[w * 22 * 64 + k] = gcc < t.pw ? src[aidx * t.pw + gcc] : (int16_t)NEG16;
 		}
-		if (threadIdx.x < 2 * NW) xB[threadIdx.x] = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
+		if (wp.tg < 2 * NW) xB[wp.tg] = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
 	}
 	// record ring of 64 rows shared by the waves, maintained by wave 0 (see k_ext_wide)
 	uint32_t *ring = (uint32_t*)(xB + 2 * NW);
@@ -1132,7 +1249,7 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 				else if ((i & 15) == 12) { if (loader) ring[((i + 20) & 63) + lane] = pf; }
 			}
 			const uint32_t rnext = ring[(i + 1) & 63];
-			const int32_t nas = (rcur & 0xff) >> 3, gei = (rcur >> 16) & 0xff;
+			const int32_t nas = (rcur & 0xff) >> 1, gei = (rcur >> 16) & 0xff;
 			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
 			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
 			const int32_t S = myprof[nas * G];
@@ -1188,7 +1305,56 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 		lds_barrier();
 	}
 	for (int k = w; k < NW - 1; ++k) lds_barrier();
-	if (nl < 3 && threadIdx.x == 0) a.score[tid] = NEG16;
+	if (nl < 3 && wp.tg == 0) a.score[tid] = NEG16;
+}
+
+template<int NW>
+__global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
+{
+	extern __shared__ uint32_t lds_raw[];
+	glob_wide_body<NW>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dp_round: ALL DP units of a round -- extension calls of every width class and the traceback calls of the first traceback
+// chunk -- in ONE launch of 256-thread workgroups.  A workgroup reads its DpUnit and its four waves become four independent
+// one-wave units, two two-wave groups, one four-wave group or a quarter of a split 1024-column group.  Units are ordered by
+// expected duration, longest first, so the hardware's in-order workgroup dispatcher is the task queue: a workgroup slot that
+// frees up takes the longest unit not yet started.  One launch instead of eight to ten concurrent ones means one hardware
+// queue per batch in flight, which is what lets a stream of batches keep more than two batches in their DP rounds (each
+// concurrently running kernel occupies a queue, and more queues than the hardware schedules at once are time-sliced).
+// ------------------------------------------------------------------------------------------------
+#define DP_ROUND_LDS_MAX4(a, b, c, d) ((a) > (b) ? ((a) > (c) ? ((a) > (d) ? (a) : (d)) : ((c) > (d) ? (c) : (d))) : ((b) > (c) ? ((b) > (d) ? (b) : (d)) : ((c) > (d) ? (c) : (d))))
+#define DP_ROUND_LDS DP_ROUND_LDS_MAX4(4 * EXT_NARROW_LDS, 2 * EXT_WIDE_LDS(2), EXT_WIDE_LDS(4), 4 * GLOB_NARROW_LDS + 2 * GLOB_WIDE_LDS(2) + GLOB_WIDE_LDS(4))
+__global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
+{
+	extern __shared__ uint32_t lds_raw[];
+	char *lds = (char*)lds_raw;
+	const DpUnit u = units[blockIdx.x];
+	const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const WavePos one{ lds, lane, 0, lane };                      // a one-wave unit: its LDS region is set per case
+	switch (u.kind) {
+	case U_EXT16: if (wv < u.count) ext_narrow<16>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT32: if (wv < u.count) ext_narrow<32>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT64: if (wv < u.count) ext_narrow<64>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT_W2: {
+		const int g = wv >> 1, w = wv & 1;
+		if (g < u.count) ext_wide_body<2, false>(wa, u.first + g, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds + g * EXT_WIDE_LDS(2), lane, w, w * 64 + lane });
+	} break;
+	case U_EXT_W4: ext_wide_body<4, false>(wa, u.first, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
+	case U_EXT_SPLIT: ext_wide_body<4, true>(wa, u.first, SplitPos{ u.sgroup, u.blk, u.n_blk, u.xg_first }, WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
+	case U_GLOB16: if (wv < u.count) glob_narrow<16, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB32: if (wv < u.count) glob_narrow<32, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB64: if (wv < u.count) glob_narrow<64, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB_MB: if (wv < u.count) glob_narrow<64, true>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB_W2: {
+		const int g = wv >> 1, w = wv & 1;
+		if (g < u.count) glob_wide_body<2>(ga, ga.waves[u.first + g], WavePos{ lds + g * GLOB_WIDE_LDS(2), lane, w, w * 64 + lane });
+	} break;
+	case U_GLOB_W4: glob_wide_body<4>(ga, ga.waves[u.first], WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
+	default: break;
+	}
+	(void)one;
 }
 
 // ------------------------------------------------------------------------------------------------

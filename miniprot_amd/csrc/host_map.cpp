@@ -150,6 +150,15 @@ private:
 	uint64_t epoch_ = 0;
 };
 
+// MPA_TRACE=1: one line per pipeline event of mpa_map_batches() with a time stamp (ms since the call began) -- tools/gantt.py
+// turns them into a per-stage timeline
+static double g_trace_t0 = 0;
+static bool trace_on() { static int on = -1; if (on < 0) { const char *e = getenv("MPA_TRACE"); on = e && *e && *e != '0'; } return on != 0; }
+static void trace(const char *stage, int32_t batch, const char *what)
+{
+	if (trace_on()) fprintf(stderr, "[mpa-trace] %10.3f %-8s batch %3d %s\n", now_ms() - g_trace_t0, stage, batch, what);
+}
+
 static thread_local int tl_pool_lane = 0;
 static thread_local int tl_thread_div = 1;          // pipeline stages with light host work take a fraction of the threads
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
@@ -842,7 +851,10 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	const double t1 = now_ms();
 	timing_note("  A1: seed jobs", t1 - t0);
 	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse);
-	if (rc == MPA_ERR_UNSUPPORTED) return b;            // e.g. the batch does not fit the device: seed on the host
+	if (rc == MPA_ERR_UNSUPPORTED) {                    // e.g. the batch does not fit the device: seed on the host
+		if (timing_on()) fprintf(stderr, "[mpa-timing]   device seeding declined (%s): seeding on the host\n", mpa_last_error());
+		return b;
+	}
 	if (rc != MPA_OK) { delete b; return nullptr; }
 	b->seeded_on_device = true;
 	timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
@@ -1145,6 +1157,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
+	g_trace_t0 = now_ms();
 	struct Slot { mpa_batch_t *b = nullptr; bool seeded = false, begun = false, dp_done = false; };
 	std::vector<Slot> slot((size_t)n_batches);
 	std::mutex mu;
@@ -1173,7 +1186,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_planned + 1; });
 				if (rc_all != MPA_OK) return;
 			}
+			trace("seed", k, "begin");
 			mpa_batch_t *b = batch_seed_phase(seed_ctx[k & 1], mi, opt, &batches[k], n_threads);
+			trace("seed", k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].b = b, slot[k].seeded = true;
@@ -1188,7 +1203,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes); });
 				if (rc_all != MPA_OK) return;
 			}
+			trace("plan", k, "begin");
 			batch_plan_phase(slot[k].b, seed_ctx[k & 1]);
+			trace("plan", k, "end");
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].begun = true, ++n_planned;
 			cv.notify_all();
@@ -1202,9 +1219,11 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].dp_done; });
 				if (!slot[k].dp_done) return;
 			}
+			trace("finish", k, "begin");
 			results[k] = mpa_batch_finish(slot[k].b);
 			slot[k].b = nullptr;
 			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], id_io, &text[k]);
+			trace("finish", k, "end");
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("output stage: ") + e.what()); } });
 	// DP lanes: lane d drives the DP rounds of batches d, d + n_lanes, ... on its own device context (streams + buffers).
@@ -1218,7 +1237,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
 				if (rc_all != MPA_OK) return;
 			}
+			trace(d == 0 ? "dp0" : d == 1 ? "dp1" : d == 2 ? "dp2" : "dp3", k, "begin");
 			const int rc = run_dp_rounds(cd, mi, &batches[k], slot[k].b);
+			trace(d == 0 ? "dp0" : d == 1 ? "dp1" : d == 2 ? "dp2" : "dp3", k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].dp_done = true, ++n_dp_done;

@@ -143,7 +143,7 @@ namespace mpa {
 const int8_t *blosum62() { return ns_mat_blosum62; }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-bool timing_on() { static int on = -1; if (on < 0) { const char *e = getenv("MPA_TIMING"); on = e && *e && *e != '0'; } return on != 0; }
+bool timing_on() { const char *e = getenv("MPA_TIMING"); return e && *e && *e != '0'; }   // (read per call: the tests flip it)
 void timing_note(const char *what, double ms) { if (timing_on()) fprintf(stderr, "[mpa-timing] %-28s %9.3f ms\n", what, ms); }
 
 static thread_local std::string g_err;

@@ -40,13 +40,14 @@ def _first_difference(ours, ref):
 
 
 def test_genome_scale_batch_with_default_thresholds(ctx, tmp_path, monkeypatch, capfd):
-    """360 Mbp in 3 contigs (5 % N runs, 2 % tandem paralogs) x 2 400 proteins, -I -u, as TWO mini-batches of 1 200 through
-    mpa_map_batches: more than 8 M anchors and 100 M refinement-window bases per batch, so both device stages engage on their
-    own (checked from the library's timing notes), and every output byte equals the reference's."""
+    """360 Mbp in 3 contigs (5 % N runs, 2 % tandem paralogs) x 3 300 proteins, -I -u, as mini-batches of 3 000 and 300 through
+    mpa_map_batches: the big one has more than 8 M anchors and 100 M refinement-window bases, so both device stages engage on
+    their own (checked from the library's timing notes), the small one stays on the host paths, and every output byte equals
+    the reference's."""
     for v in ("MPA_GPU_SEED", "MPA_GPU_REFINE"):
         monkeypatch.delenv(v, raising=False)
     monkeypatch.setenv("MPA_TIMING", "1")
-    contigs, prots, names = gen_synth.generate(360_000_000, 3, 2400, 5, mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02)
+    contigs, prots, names = gen_synth.generate(360_000_000, 3, 3300, 5, mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02)
     idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(3)])
     del contigs
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, min(64, NCPU)))
@@ -55,13 +56,13 @@ def test_genome_scale_batch_with_default_thresholds(ctx, tmp_path, monkeypatch, 
     mo.flag |= 4
     mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
     assert mo.max_intron > 60000
-    batches = [mpa.Queries(prots[i:i + 1200], names[i:i + 1200]) for i in (0, 1200)]
+    batches = [mpa.Queries(prots[a:b], names[a:b]) for a, b in ((0, 3000), (3000, 3300))]
     ours = b"".join(mpa.map_batches(ctx, idx, mo, batches, min(64, NCPU)))
     notes = capfd.readouterr().err
     assert "seeding on the GPU" in notes and "refinement scan on the GPU" in notes, "the device stages did not switch on by themselves"
     ref = _reference(tmp_path, idx, prots, names, ["-I", "-u"])
     assert ours == ref, _first_difference(ours, ref)
-    assert ours.count(b"\n") >= 2400
+    assert ours.count(b"\n") >= 3300
     idx.close()
 
 
