@@ -89,7 +89,7 @@ struct mpa_ctx_s {
 	hipEvent_t ev[6] = {};
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
-	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey, xg;
+	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey, xg, units;
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -276,7 +276,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	SeedBufs &B = ctx->seed;
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg,
+	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count }) b->release();
 	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits }) h->release();
@@ -324,7 +324,7 @@ namespace mpa {
 // GPU seeding for one mini-batch: anchors -> sort -> forward pass of the pre-chain -> the anchors that have a neighbour.
 // jobs: the kept seeds of all queries (qid ascending, within a query ascending query position, dst = running anchor
 // offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
-// (pred = position inside the query, -1 for none).
+// (pred = index into the query's part of the view, -1 for none).
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
                          const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out)
 {
@@ -740,7 +740,70 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	// rowkey slots follow the order of the wave descriptors (classes 3, 4, 5, 6)
 	int64_t rk_first[kNumExtClasses] = { 0 };
 	{ int64_t at = 0; for (int cls = 3; cls < kNumExtClasses; ++cls) rk_first[cls] = at, at += ewave_cnt[cls]; }
-	if (ewave_cnt[5] + ewave_cnt[6] > 0) {                              // the two widest classes first: four / two workgroups per pair of calls
+	// MPA_ONE_LAUNCH (default 1): every DP unit of the round in ONE k_dp_round launch on the context's main stream; 0 = one
+	// launch per kernel class on side streams (the round-1 executor, kept for comparison)
+	static const bool one_launch = [] { const char *e = getenv("MPA_ONE_LAUNCH"); return e ? atoi(e) != 0 : true; }();
+	GlobArgs ga;
+	ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
+	ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc, ga.rowkey64 = nullptr, ga.waves = nullptr;
+	hipEvent_t ev_round0 = ctx->lev[2 * (mpa_ctx_s::kSide - 1)], ev_round1 = ctx->lev[2 * (mpa_ctx_s::kSide - 1) + 1];
+	bool round_launched = false;
+	// units of the round: the extension waves/groups of every class, plus (gw_first/gw_cnt != nullptr) the traceback waves of
+	// the first traceback chunk; longest first
+	auto launch_round = [&](const int *gw_first, const int *gw_cnt, const std::vector<GlobWave> *gwv, GlobWave *d_gw) -> int {
+		struct Cost { int64_t cost; DpUnit u; };
+		std::vector<Cost> cu;
+		auto add = [&](int kind, int first, int count, int64_t cost, int blk = 0, int n_blk = 1, int sgroup = 0, int xg_first = 0) {
+			cu.push_back(Cost{ cost, DpUnit{ kind, first, count, blk, n_blk, sgroup, xg_first, 0 } });
+		};
+		for (int cls = 0; cls < 3; ++cls)
+			for (int k = 0; k < ewave_cnt[cls]; k += 4)
+				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(4, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
+		for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
+		for (int k = 0; k < ewave_cnt[4]; ++k) add(U_EXT_W4, ewave_first[4] + k, 1, (int64_t)ewaves[ewave_first[4] + k].max_nl * 370);
+		for (int k = 0; k < ewave_cnt[6]; ++k)
+			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
+		for (int k = 0; k < ewave_cnt[5]; ++k)
+			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 425, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
+		if (gw_first) {
+			static const int kind_of[8] = { U_GLOB16, U_GLOB32, U_GLOB64, U_GLOB_W2, U_GLOB_W4, -1, -1, U_GLOB_MB };
+			for (int cls = 0; cls < 8; ++cls) {
+				if (kind_of[cls] < 0) continue;
+				const int per = cls == 3 ? 2 : cls == 4 ? 1 : 4;
+				for (int k = 0; k < gw_cnt[cls]; k += per) {
+					const GlobWave &g = (*gwv)[gw_first[cls] + k];
+					int64_t cost = (int64_t)g.max_nl * (cls >= 3 && cls <= 4 ? 510 : 430);
+					if (cls == 7) cost *= (T[g.task[0]].ncol + 63) / 64;
+					add(kind_of[cls], gw_first[cls] + k, std::min(per, gw_cnt[cls] - k), cost);
+				}
+			}
+		}
+		if (cu.empty()) return MPA_OK;
+		std::stable_sort(cu.begin(), cu.end(), [](const Cost &x, const Cost &y) { return x.cost > y.cost; });   // (stable: the workgroups of a split group stay adjacent, in column order)
+		std::vector<DpUnit> units(cu.size());
+		for (size_t k = 0; k < cu.size(); ++k) units[k] = cu[k].u;
+		int rc2;
+		if ((rc2 = ctx->units.ensure(units.size() * sizeof(DpUnit)))) return rc2;
+		HIP_TRY(hipMemcpyAsync(ctx->units.p, units.data(), units.size() * sizeof(DpUnit), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));                  // (units is a local)
+		ea.waves = ctx->waves.as<ExtWave>();
+		wa.waves = ctx->waves.as<ExtWave>();                // absolute descriptor indices: the rowkey slot of group g is g - first wide group
+		wa.rowkey = ctx->rowkey.as<uint32_t>() - (int64_t)ewave_first[3] * 2 * key_stride;
+		ga.waves = d_gw;
+		static bool attr_set = false;
+		if (!attr_set && DP_ROUND_LDS > 48 * 1024) {
+			HIP_TRY(hipFuncSetAttribute((const void*)k_dp_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_ROUND_LDS));
+			attr_set = true;
+		}
+		HIP_TRY(hipEventRecord(ev_round0, s));
+		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)units.size()), dim3(256), DP_ROUND_LDS, s, ea, wa, ga, ctx->units.as<DpUnit>());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(ev_round1, s));
+		round_launched = true;
+		ctx->stats.launches_ext++;
+		return MPA_OK;
+	};
+	if (!one_launch && ewave_cnt[5] + ewave_cnt[6] > 0) {                              // the two widest classes first: four / two workgroups per pair of calls
 		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[5];
 		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[5] * 2 * key_stride;
 		hipStream_t st = begin_side(true);
@@ -748,7 +811,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		end_side();
 		ctx->stats.launches_ext++;
 	}
-	for (int cls = 4; cls >= 3; --cls) {
+	for (int cls = 4; cls >= 3 && !one_launch; --cls) {
 		if (ewave_cnt[cls] == 0) continue;
 		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
 		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[cls] * 2 * key_stride;
@@ -770,7 +833,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		end_side();
 		ctx->stats.launches_ext++;
 	}
-	if (ewave_cnt[0] + ewave_cnt[1] + ewave_cnt[2] > 0) {               // the narrow classes share one launch
+	if (!one_launch && ewave_cnt[0] + ewave_cnt[1] + ewave_cnt[2] > 0) { // the narrow classes share one launch
 		ea.waves = ctx->waves.as<ExtWave>();
 		hipStream_t st = begin_side(true);
 		HIP_TRY(launch_ext_narrow(ea, ewave_first.data(), ewave_cnt.data(), st));
@@ -815,9 +878,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		HIP_TRY(hipMemcpyAsync(d_list, glist.data(), glist.size() * 4, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(d_gw, gwaves.data(), gwaves.size() * sizeof(GlobWave), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));                                 // gwaves/glist are reused by the next round
-		GlobArgs ga;
-		ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
-		ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc, ga.rowkey64 = nullptr;
+		ga.tb = ctx->tb.as<uint16_t>();
 		// classes 0,1,2,7 share one launch ("narrow"); every wide class has its own
 		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
 			if (cls < 0) { ga.waves = d_gw; return launch_glob_narrow(ga, first, cnt, st); }
@@ -833,11 +894,17 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		// every launch on its own stream (next to the extension classes in the first round); the walk needs them all
 		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
 		const size_t first_glob_launch = launches.size();
+		const bool in_round = one_launch && ri == 0;                       // the first chunk's calls ride in the round's one launch
+		if (in_round) {
+			if ((rc = launch_round(first, cnt, &gwaves, d_gw)) != MPA_OK) return rc;
+			ctx->stats.launches_glob++;
+		}
 		const int order[5] = { 6, 5, 4, 3, -1 };
 		for (int oi = 0; oi < 5; ++oi) {
 			const int cls = order[oi];
+			if (in_round && cls < 5) continue;                               // (only the 512/1024-thread traceback classes keep their own launch)
 			if (cls >= 0 ? !cnt[cls] : !(cnt[0] + cnt[1] + cnt[2] + cnt[7])) continue;
-			if (n_side >= mpa_ctx_s::kSide) {                                // out of side streams: run on the main stream
+			if (n_side >= mpa_ctx_s::kSide - 1) {                            // out of side streams (the last event pair times the round's launch): main stream
 				HIP_TRY(launch_glob_class(cls, s));
 			} else {
 				hipStream_t st = begin_side(false);
@@ -858,11 +925,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
 		ms_glob += a, ms_bt += b;
 	}
+	if (one_launch && !round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
 	// ---- join
 	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
 	HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	HIP_TRY(hipStreamSynchronize(s));
 	float ms_ext_sum = 0;                                                 // sum of the per-launch durations of the extension kernels
+	if (round_launched) (void)hipEventElapsedTime(&ms_ext_sum, ev_round0, ev_round1);
 	for (auto &l : launches) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ctx->lev[2 * l.side], ctx->lev[2 * l.side + 1]);

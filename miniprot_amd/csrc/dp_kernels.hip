@@ -1324,8 +1324,9 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 // queue per batch in flight, which is what lets a stream of batches keep more than two batches in their DP rounds (each
 // concurrently running kernel occupies a queue, and more queues than the hardware schedules at once are time-sliced).
 // ------------------------------------------------------------------------------------------------
-#define DP_ROUND_LDS_MAX4(a, b, c, d) ((a) > (b) ? ((a) > (c) ? ((a) > (d) ? (a) : (d)) : ((c) > (d) ? (c) : (d))) : ((b) > (c) ? ((b) > (d) ? (b) : (d)) : ((c) > (d) ? (c) : (d))))
-#define DP_ROUND_LDS DP_ROUND_LDS_MAX4(4 * EXT_NARROW_LDS, 2 * EXT_WIDE_LDS(2), EXT_WIDE_LDS(4), 4 * GLOB_NARROW_LDS + 2 * GLOB_WIDE_LDS(2) + GLOB_WIDE_LDS(4))
+constexpr size_t dp_round_max(size_t a, size_t b) { return a > b ? a : b; }
+constexpr size_t DP_ROUND_LDS = dp_round_max(dp_round_max(dp_round_max(4 * EXT_NARROW_LDS, 2 * EXT_WIDE_LDS(2)), dp_round_max(EXT_WIDE_LDS(4), 4 * GLOB_NARROW_LDS)),
+                                             dp_round_max(2 * GLOB_WIDE_LDS(2), GLOB_WIDE_LDS(4)));   // 30 400 bytes: five workgroups per CU
 __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
 {
 	extern __shared__ uint32_t lds_raw[];

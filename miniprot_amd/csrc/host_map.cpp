@@ -524,16 +524,13 @@ static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint6
 static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const PrechainSparse &ps, std::vector<uint64_t> &a)
 {
 	AccTimer tm(2);
-	static thread_local std::vector<int32_t> vpred;
 	static thread_local std::vector<uint64_t> u;
 	const int64_t c0 = ps.cfirst[qs.qid], m = ps.cfirst[qs.qid + 1] - c0;
 	a.clear();
 	g_acc[14] += qs.n_anchor * 1000;
 	if (m == 0) return;
-	vpred.resize((size_t)m);
-	const int32_t *pos = ps.pos + c0, *pp = ps.pred + c0;
-	for (int64_t c = 0; c < m; ++c) vpred[c] = pp[c] < 0 ? -1 : (int32_t)(c - (pos[c] - pp[c]));   // runs are contiguous in both numberings
-	const ChainView v{ qs.n_anchor, m, pos, ps.f + c0, vpred.data(), ps.a + c0 };
+	// (the device hands the predecessors over as indices into the query's part of the view)
+	const ChainView v{ qs.n_anchor, m, ps.pos + c0, ps.f + c0, ps.pred + c0, ps.a + c0 };
 	chain_extract(prechain_params(b->mi, b->opt), v, a, u);
 	sort_u64(a.data(), a.data() + a.size());
 	g_acc[15] += (int64_t)a.size() * 1000;
@@ -897,6 +894,8 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 		stage_chain_to_windows(b, b->qs[i], a);
 	});
 	b->sparse = PrechainSparse();
+	timing_note("  plan: anchors..windows (wall)", now_ms() - t0);
+	const double t_a = now_ms();
 	// the refinement scan of all windows on the device, if the batch is worth the round trip
 	RefineHits rh;
 	bool on_device = false;
@@ -933,11 +932,14 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 		}
 	}
 	const RefineHits *rhp = on_device ? &rh : nullptr;
+	timing_note("  plan: windows + scan (wall)", now_ms() - t_a);
+	const double t_b = now_ms();
 	parallel_for(b->n_threads, n_q, [&, rhp](int64_t i) {
 		stage_refine_to_plan(b, b->qs[i], rhp);
 		AccTimer tm(7);
 		plan_round1(b, b->qs[i]);
 	});
+	timing_note("  plan: refine..plans (wall)", now_ms() - t_b);
 	timing_note("stage A (seed..plan)", now_ms() - t0);
 	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
 	if (b->opt.flag & MPA_MF_NO_ALIGN) { b->round = 4; return; }

@@ -77,10 +77,10 @@ void ctx_set_side_offset(mpa_ctx_t *ctx, int off);   // which of its side stream
 
 // ---- GPU seeding (seed_exec.hip + the driver in dp_exec.hip) --------------------------------------
 struct SeedJob { int64_t kb_off, dst; int32_t cnt, qpos, qid; };   // one kept seed: its occurrence list and where its anchors go
-struct PrechainSparse {              // result for a mini-batch: the anchors that have a neighbour, query by query
+struct PrechainSparse {              // result for a mini-batch: the chained anchors (with a predecessor, or being one), query by query
 	std::vector<int64_t> cfirst;     // [n_query + 1] offsets into the arrays below
 	int64_t m = 0;
-	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call
+	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call; pred = index into the query's part of the view, -1 for none
 	const uint64_t *a = nullptr;
 };
 struct RefineWindow { int64_t as; int32_t qid, vid, len; };    // strand-local window [as, as + len) on vid, refined for query qid

@@ -4,10 +4,11 @@
 //   k_seed_gather   anchors of every kept seed: (query, block) key + query position      map.c:163-177
 //   rocPRIM         one stable LSD radix sort over (query, block)                          map.c:178 (radix_sort_mp64)
 //   k_prechain_fwd  forward pass of the block-resolution pre-chain                         chain.c:112-151,181-209
-//   scan + k_seed_compact   only anchors that have a neighbour travel back to the host
+//   scan + k_seed_compact   only anchors that are chained -- have a predecessor or are one -- travel back to the host
 // The pre-chain only links anchors at most one 256-bp block apart, so the sorted anchors of a query fall into
 // independent "runs" (maximal stretches in which consecutive blocks differ by at most max_dblock); ~97 % of the anchors
-// at genome scale are runs of one, which the extraction (host, chain_extract on a sparse ChainView) never needs to see.
+// at genome scale are runs of one, and of the rest about half link to nothing (wrong order or distance on the query): the
+// extraction (host, chain_extract on a sparse ChainView) never needs to see an anchor that is neither chained nor chained onto.
 // One thread walks one run with exactly the reference's loop; the arithmetic of comput_sc() includes two float
 // operations, compiled without FMA contraction like the host code.
 #include <rocprim/device/device_radix_sort.hpp>
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const
 			if (pj >= 0) mark[q0 + pj] = me;
 		}
 		f[i] = best, pred[i] = best_j < 0 ? -1 : (int32_t)(best_j - q0);
-		flag[i] = 1;
+		if (best_j >= 0) flag[i] = 1, flag[best_j] = 1;                 // (this thread owns the whole run: no race)
 		if (hot_f < best) hot_f = best, hot = i;
 	}
 }
@@ -127,8 +128,11 @@ __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const
 	if (i >= n || !flag[i]) return;
 	const uint64_t k = key[i];
 	const uint32_t d = idx[i];
-	o_pos[d] = (int32_t)(i - qfirst[k >> nb]);
-	o_f[d] = f[i], o_pred[d] = pred[i];
+	const int64_t q0 = qfirst[k >> nb];
+	o_pos[d] = (int32_t)(i - q0);
+	// the predecessor as an index into the query's part of the compacted view (a chained-onto anchor is always in the view)
+	const int32_t pr = pred[i];
+	o_f[d] = f[i], o_pred[d] = pr < 0 ? -1 : (int32_t)(idx[q0 + pr] - idx[q0]);
 	o_a[d] = (k & ((1ULL << nb) - 1)) << 32 | val[i];
 }
 
