@@ -11,7 +11,7 @@ PAF text) over ONE mini-batch.  The K timed steps are the mini-batches k mod 10,
 (what miniprot's own batch loop, map.c:273-345, would call): pipeline fill and drain are inside the timed region.  Every
 output line of every timed step is compared with the reference's output for the same proteins (`paf_identical`).
 
-    python bench.py                                    # N=1, config 3, 40 steps (4 passes over the 20 000 proteins)
+    python bench.py                                    # N=1, config 3, 60 steps (6 passes over the 20 000 proteins, ~6 s timed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
 N>1 (BASELINE.json configs[3]): the SAME job -- the same K mini-batches of the same proteins -- dealt round-robin over the ranks
@@ -164,41 +164,54 @@ def measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, 
 
 
 def roofline_record(st, elapsed, world):
-    if st["launches_ext"] <= 0 or st["ms_ext"] <= 0:
+    """Roofline of the dominant kernel.  With one launch per DP round (k_dp_round, the default) that kernel does every
+    extension call and the traceback calls of the round's first chunk; its duration is measured with HIP events on the stream
+    it is launched on.  (With MPA_ONE_LAUNCH=0 the figures are those of the per-class extension kernels, whose durations
+    overlap.)"""
+    if st["launches_round"] > 0 and st["ms_round"] > 0:
+        kernel = "k_dp_round (one launch per DP round: all extension classes + first traceback chunk)"
+        n, ms = st["launches_round"], st["ms_round"]
+        ops = OPS_PER_CELL_EXT * st["cells_ext_round"] + OPS_PER_CELL_GLOB * st["cells_glob_round"]
+        cells = st["cells_ext_round"] + st["cells_glob_round"]
+        note = "launch durations from HIP events on the launch stream; rounds of different batches in flight (MPA_DP_LANES) overlap on the GPU, so the sum of launch durations exceeds the wall time"
+    elif st["launches_ext"] > 0 and st["ms_ext"] > 0:
+        kernel = "k_ext_narrow + k_ext_wide<NW> + k_ext_wide_split (score-only extension sweep, > 80 % of all DP cells)"
+        n, ms = st["launches_ext"], st["ms_ext"]
+        ops, cells = OPS_PER_CELL_EXT * st["cells_ext"], st["cells_ext"]
+        note = "per-launch durations are HIP-event times of kernels that run CONCURRENTLY on several streams (sum over launches > wall time)"
+    else:
         return None
-    n, ms = st["launches_ext"], st["ms_ext"]
-    ops_ext = OPS_PER_CELL_EXT * st["cells_ext"]
-    ach = ops_ext / (ms * 1e-3)                               # int16 ops/s while an extension kernel is running (per launch)
+    ach = ops / (ms * 1e-3)                                   # int16 ops/s while the kernel is running
     hbm = st["alg_bytes_ext"] / (ms * 1e-3) / 1e9
-    wall_ops = (ops_ext + OPS_PER_CELL_GLOB * st["cells_glob"]) / elapsed
+    wall_ops = (OPS_PER_CELL_EXT * st["cells_ext"] + OPS_PER_CELL_GLOB * st["cells_glob"]) / elapsed
     traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if os.path.exists(pmc):
         try:
             d = json.load(open(pmc))
-            traffic, src = d.get("k_ext_hbm_bytes_per_launch"), "profiles/pmc_latest.json: separate rocprofv3 --pmc passes (tools/pmc_round.sh), NOT measured in this run; workload %s" % d.get("workload", "config 2")
+            traffic = d["kernels"]["k_dp_round"]["hbm_bytes_per_launch"]
+            src = "profiles/r02_pmc_summary.json: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over config 3 scaled x0.1 -- NOT measured in this run and not this run's launch size"
         except Exception:
             pass
-    return {"kernel": "k_ext_narrow + k_ext_wide<NW> (score-only extension sweep, > 80 % of all DP cells)", "bound": "valu-int16",
-            "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
+    return {"kernel": kernel, "bound": "valu-int16", "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
             "traffic": traffic, "traffic_source": src,
-            "launches": n, "avg_launch_ms": ms / n, "cells_per_launch": st["cells_ext"] / n, "ops_per_cell": OPS_PER_CELL_EXT,
-            "gcups_per_launch": st["cells_ext"] / (ms * 1e-3) / 1e9,
+            "launches": n, "avg_launch_ms": ms / n, "cells_per_launch": cells / n, "ops_per_cell": {"score_only": OPS_PER_CELL_EXT, "traceback": OPS_PER_CELL_GLOB},
+            "gcups_per_launch": cells / (ms * 1e-3) / 1e9,
             "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": st["alg_bytes_ext"] / n,
-                    "note": "algorithmic bytes (packed window + protein + result, SURVEY.md 8(d)) / launch time: the score-only DP is not HBM-bound"},
+                    "note": "algorithmic bytes of the extension calls (packed window + protein + result, SURVEY.md 8(d)) / launch time: the score-only DP is not HBM-bound"},
             "wall": {"achieved": wall_ops / 1e12, "frac": wall_ops / VALU_I16_PEAK / max(world, 1), "unit": "Tops/s",
                      "note": "all DP ops of the timed steps (32/cell score-only + 65/cell traceback) / elapsed wall time / GPUs: includes every host stage and idle gap"},
-            "note": "per-launch durations are HIP-event times of kernels that run CONCURRENTLY on several streams (sum over launches > wall time)"}
+            "note": note}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--scale", type=float, default=1.0, help="(debug) shrink genome and protein set by this factor; the line is then NOT the named config")
-    ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = all cores / ranks, at most 128)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = cores / ranks, at most 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N=1, config 3: skip the config-2 and config-5 records")
     a = ap.parse_args()
@@ -221,7 +234,9 @@ def main():
     from miniprot_amd import dist as mdist
 
     ncpu = os.cpu_count() or 1
-    n_threads = a.threads if a.threads > 0 else max(1, min(128, ncpu // max(world, 1)))
+    # host threads of the planning stage (the other pipeline stages take a quarter each): the host stages are memory-bound and
+    # more than 64 threads lose (measured at config 3 on the 256-thread host: 32 -> 0.98 s, 64 -> 1.00 s, 96 -> 1.10 s, 128 -> 1.22 s)
+    n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
 
     def barrier():
         if dist is not None:
@@ -248,9 +263,10 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-            tot = torch.tensor([st[k] for k in ("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext")] + [st["ms_ext"]], dtype=torch.float64, device=device)
+            keys = ("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext", "ms_ext", "cells_ext_round", "cells_glob_round", "launches_round", "ms_round")
+            tot = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device=device)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            for k, v in zip(("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext", "ms_ext"), tot.tolist()):
+            for k, v in zip(keys, tot.tolist()):
                 st[k] = v
         rec = None
         if rank == 0:

@@ -167,6 +167,10 @@ typedef struct {
 	int64_t alg_bytes_ext, alg_bytes_glob; /* algorithmic HBM bytes, SURVEY.md 8(d) */
 	double ms_prep, ms_ext, ms_glob, ms_backtrack, ms_total; /* HIP-event timings on the context's stream */
 	int32_t launches_ext, launches_glob;
+	/* k_dp_round (one launch per DP round: every extension call + the traceback calls of the first traceback chunk) */
+	int64_t cells_ext_round, cells_glob_round;   /* padded DP cells those launches swept */
+	double ms_round;                             /* sum of their HIP-event durations */
+	int32_t launches_round, pad_;
 } mpa_dp_stats_t;
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
 /* sums over every mpa_dp_run() of this context since the last reset */
@@ -249,6 +253,10 @@ const char *mpa_version(void);
  * first[n_win + 1] the boundaries.  Returns the number of hits or a negative error code. */
 int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, const char *aa, int32_t l_aa, int32_t n_win, const int32_t *vid, const int64_t *as,
                             const int32_t *len, int64_t *first, uint64_t **out);
+/* forward pass of mp_chain (chain.c:181-209) of n_prob problems (sorted anchors back to back in a[], first[n_prob + 1]): f and
+ * pred (index inside the problem, -1 = none) of every anchor, from the device kernel (ctx != NULL) or the host pass (ctx == NULL) */
+int mpa_dbg_chain_forward(mpa_ctx_t *ctx, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t max_skip, int32_t max_iter, float coef_log,
+                          int32_t is_spliced, int32_t kmer, int32_t bbit, int32_t n_prob, const int64_t *first, const uint64_t *a, int32_t *f, int32_t *pred);
 /* the anchors that survive the pre-chain (map.c:186-192), query by query, from the host stage (ctx == NULL) or the device's */
 int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out);
 

@@ -74,6 +74,8 @@ struct SeedBufs {
 	HostPinned h_jobs, h_pos, h_f, h_pred, h_a;
 	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
 	HostPinned h_rhits;
+	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first;                // chain forward pass (k_chain_fwd)
+	HostPinned hc_a, hc_f, hc_pred;
 };
 
 
@@ -278,8 +280,9 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
 	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
-	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count }) b->release();
-	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits }) h->release();
+	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
+	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first }) b->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -315,6 +318,7 @@ void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 		t.alg_bytes_ext += u.alg_bytes_ext, t.alg_bytes_glob += u.alg_bytes_glob;
 		t.ms_prep += u.ms_prep, t.ms_ext += u.ms_ext, t.ms_glob += u.ms_glob, t.ms_backtrack += u.ms_backtrack, t.ms_total += u.ms_total;
 		t.launches_ext += u.launches_ext, t.launches_glob += u.launches_glob;
+		t.cells_ext_round += u.cells_ext_round, t.cells_glob_round += u.cells_glob_round, t.ms_round += u.ms_round, t.launches_round += u.launches_round;
 		u = mpa_dp_stats_t();
 	}
 }
@@ -425,6 +429,56 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
 	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
 	timing_note("    seed: compact + download", now_ms() - t_kernels);
+	return MPA_OK;
+}
+} // namespace mpa
+
+namespace mpa {
+// Forward pass of mp_chain for a batch of chaining problems on the device (k_chain_fwd): the main chain of every query of a
+// mini-batch, or the refinement chains of its regions.  The caller writes the sorted anchors of all problems, back to back,
+// into io.a (pinned memory of the context) and finds f / pred (index inside the problem) in io.f / io.pred afterwards.
+int dev_chain_buffers(mpa_ctx_t *ctx, int64_t n, ChainIO &io)
+{
+	SeedBufs &B = ctx->seed;
+	int rc;
+	if ((rc = B.hc_a.ensure((size_t)n * 8 + 64)) || (rc = B.hc_f.ensure((size_t)n * 4 + 64)) || (rc = B.hc_pred.ensure((size_t)n * 4 + 64))) return rc;
+	io.a = B.hc_a.as<uint64_t>(), io.f = B.hc_f.as<int32_t>(), io.pred = B.hc_pred.as<int32_t>();
+	return MPA_OK;
+}
+
+int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &cp, int32_t n_prob, const int64_t *first, const ChainIO &io)
+{
+	const int64_t n = first[n_prob];
+	if (n == 0 || n_prob == 0) return MPA_OK;
+	if (n_prob > (1 << 30) || cp.kmer < 0) { set_error("chain forward pass: parameters outside the device kernel's range"); return MPA_ERR_UNSUPPORTED; }
+	for (int32_t q = 0; q < n_prob; ++q)
+		if (first[q + 1] - first[q] > INT32_MAX - 2) { set_error("chain forward pass: a problem has too many anchors"); return MPA_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeedBufs &B = ctx->seed;
+	if (!ctx->seed_stream) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
+	}
+	hipStream_t s = ctx->seed_stream;
+	PreParams pp;
+	pp.max_dist_x = std::max(cp.max_dist_x, cp.bw), pp.max_dist_y = cp.max_dist_y;
+	if (pp.max_dist_y < cp.bw && !cp.is_spliced) pp.max_dist_y = cp.bw;
+	pp.bw = cp.bw, pp.max_skip = cp.max_skip, pp.max_iter = cp.max_iter, pp.kmer = cp.kmer, pp.bbit = cp.bbit;
+	pp.is_spliced = cp.is_spliced, pp.coef_log = cp.coef_log, pp.max_dblock = pp.max_dist_x >> cp.bbit;
+	int rc;
+	if ((rc = B.c_a.ensure((size_t)n * 8)) || (rc = B.c_f.ensure((size_t)n * 4)) || (rc = B.c_pred.ensure((size_t)n * 4)) || (rc = B.c_mark.ensure((size_t)n * 4)) ||
+	    (rc = B.c_flag.ensure((size_t)n * 4)) || (rc = B.c_first.ensure(((size_t)n_prob + 1) * 8))) return rc;
+	HIP_TRY(hipMemcpyAsync(B.c_a.p, io.a, (size_t)n * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(B.c_first.p, first, ((size_t)n_prob + 1) * 8, hipMemcpyHostToDevice, s));
+	const unsigned nblk = (unsigned)((n + 255) / 256);
+	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(), B.c_mark.as<int32_t>(), B.c_flag.as<uint32_t>());
+	hipLaunchKernelGGL(k_chain_fwd, dim3(nblk), dim3(256), 0, s, B.c_a.as<uint64_t>(), n, B.c_first.as<int64_t>(), n_prob, pp, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(),
+	                   B.c_mark.as<int32_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(io.f, B.c_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(io.pred, B.c_pred.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));                       // (first[] may be pageable memory of the caller: it is consumed by now)
 	return MPA_OK;
 }
 } // namespace mpa
@@ -931,7 +985,10 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	HIP_TRY(hipStreamSynchronize(s));
 	float ms_ext_sum = 0;                                                 // sum of the per-launch durations of the extension kernels
-	if (round_launched) (void)hipEventElapsedTime(&ms_ext_sum, ev_round0, ev_round1);
+	if (round_launched) {
+		(void)hipEventElapsedTime(&ms_ext_sum, ev_round0, ev_round1);
+		ctx->stats.ms_round = ms_ext_sum, ctx->stats.launches_round = 1;
+	}
 	for (auto &l : launches) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ctx->lev[2 * l.side], ctx->lev[2 * l.side + 1]);
@@ -997,12 +1054,16 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	mpa_dp_stats_t &st = ctx->stats;
 	for (int32_t id : ext_ids) {
 		const DTask &t = T[id];
+		if (round_launched && t.pad_ != 7) st.cells_ext_round += (int64_t)std::max(0, t.nl - 2) * t.ncol;
 		st.n_ext++, st.cells_ext += (int64_t)std::max(0, t.nl - 2) * t.ncol;
 		st.alg_bytes_ext += (t.nl + 1) / 2 + t.al + 12;
 	}
-	for (int32_t id : glob_ids) {
+	for (size_t gi = 0; gi < glob_ids.size(); ++gi) {
+		const int32_t id = glob_ids[gi];
 		const DTask &t = T[id];
 		const int64_t cells = (int64_t)std::max(0, t.nl - 2) * t.ncol;
+		// (the first traceback chunk rides in the round's launch, except the 512/1024-thread classes)
+		if (round_launched && !rounds.empty() && gi < rounds[0].last && t.pad_ != 5 && t.pad_ != 6) st.cells_glob_round += cells;
 		st.n_glob++, st.cells_glob += cells;
 		st.alg_bytes_glob += (t.nl + 1) / 2 + t.al + 12 + 2 * cells + 2 * ((int64_t)t.nl + t.al) + 4 * (int64_t)nc[id];
 	}
@@ -1018,6 +1079,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.alg_bytes_ext += st.alg_bytes_ext, t.alg_bytes_glob += st.alg_bytes_glob;
 		t.ms_prep += st.ms_prep, t.ms_ext += st.ms_ext, t.ms_glob += st.ms_glob, t.ms_backtrack += st.ms_backtrack, t.ms_total += st.ms_total;
 		t.launches_ext += st.launches_ext, t.launches_glob += st.launches_glob;
+		t.cells_ext_round += st.cells_ext_round, t.cells_glob_round += st.cells_glob_round, t.ms_round += st.ms_round, t.launches_round += st.launches_round;
 	}
 	return MPA_OK;
 }

@@ -590,7 +590,24 @@ void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_
 	u.assign(u_sorted.begin(), u_sorted.end());
 }
 
-void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
+void chain_anchors_after_forward(const ChainParams &p, const int32_t *f, const int32_t *pred, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
+{
+	u.clear();
+	const int64_t n = (int64_t)a.size();
+	if (n == 0) return;
+	static thread_local std::vector<uint64_t> a_in;
+	a_in.assign(a.begin(), a.end());
+	const ChainView v{ n, n, nullptr, f, pred, a_in.data() };
+	chain_extract(p, v, a, u);
+}
+
+void chain_forward(const ChainParams &p, const uint64_t *a_ptr, int64_t n, int32_t *f_out, int32_t *pred_out)
+{
+	std::vector<uint64_t> a(a_ptr, a_ptr + n), u;
+	chain_anchors(p, a, u, f_out, pred_out);
+}
+
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy, int32_t *pred_copy)
 {
 	u.clear();
 	const int64_t n = (int64_t)a.size();
@@ -631,6 +648,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 		f[i] = best, pred[i] = (int32_t)best_j;
 		if (hot_f < best) hot_f = best, hot = i;
 	}
+	if (f_copy) memcpy(f_copy, f.data(), (size_t)n * 4), memcpy(pred_copy, pred.data(), (size_t)n * 4);
 	a_in.assign(a.begin(), a.end());
 	const ChainView v{ n, n, nullptr, f.data(), pred.data(), a_in.data() };
 	chain_extract(p, v, a, u);

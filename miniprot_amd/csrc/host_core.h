@@ -38,7 +38,7 @@ struct ChainParams {
 };
 // a: sorted anchors, rewritten with the anchors of the kept chains (chain by chain, ascending);
 // u: one entry per chain, score<<32 | n_anchors
-void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u);
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy = nullptr, int32_t *pred_copy = nullptr);
 // The state after the forward pass (chain.c:181-209) of a chaining problem with n_total anchors.  A dense view holds all of
 // them (pos == nullptr, m == n_total).  A sparse view (only valid when min_cnt > 1) may leave out anchors that have no
 // predecessor and are nobody's predecessor; pos[] are then the ascending positions of the m anchors it does hold.
@@ -50,6 +50,10 @@ struct ChainView {
 	const uint64_t *a;       // [m] the anchors
 };
 void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u);
+// chain_anchors() when the forward pass was done elsewhere (the device, dev_chain_forward): extraction only
+void chain_anchors_after_forward(const ChainParams &p, const int32_t *f, const int32_t *pred, std::vector<uint64_t> &a, std::vector<uint64_t> &u);
+// the forward pass alone (reference values for the operator test of k_chain_fwd)
+void chain_forward(const ChainParams &p, const uint64_t *a, int64_t n, int32_t *f, int32_t *pred);
 
 // ---- regions (miniprot.h:119-145, hit.c) --------------------------------------------------------------
 struct Feat {

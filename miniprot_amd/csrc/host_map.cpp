@@ -58,6 +58,8 @@ struct QueryState {
 	std::vector<uint64_t> seeds;         // kept seeds (query position << 32 | index bucket), ascending; only between the seeding sub-stages
 	std::vector<uint64_t> ext_refine;    // per region: window extension limits of the refinement (between the planning sub-stages)
 	int64_t win0 = 0;                    // first refinement window of this query in the batch's list (device refinement)
+	std::vector<uint64_t> pre;           // the pre-chain's survivors, between the two halves of planning when the main chain's forward pass runs on the device
+	std::vector<std::vector<uint64_t>> ref_pairs;   // per region: the refinement's anchor pairs, likewise for the refinement chains
 	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
@@ -225,27 +227,27 @@ struct RefineQuery {
 	~RefineQuery() { if (filter) for (uint32_t w : words) (*filter)[w >> 6] = 0; }
 };
 
-// dev_hits != nullptr: the window was scanned on the device (dev_refine_scan); its k-mer hits are (hash << 32 | position)
-static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, Region &r, int32_t extl, int32_t extr,
-                          const uint64_t *dev_hits = nullptr, int64_t n_dev_hits = 0)
+// The anchors of a region's refinement (map.c:36-79): every (window position, query position) pair of equal k = kmer2 k-mers,
+// sorted.  dev_hits != nullptr: the window was scanned on the device (dev_refine_scan); its k-mer hits are (hash << 32 | position).
+static void refine_region_pairs(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, const Region &r, int32_t extl, int32_t extr,
+                                const uint64_t *dev_hits, int64_t n_dev_hits, std::vector<uint64_t> &a)
 {
-	const int32_t kmer = opt.kmer2, is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
+	const int32_t kmer = opt.kmer2;
 	const int64_t ctg_len = mi->ctg[r.vid >> 1].len;
 	const int64_t as = r.vs > extl ? r.vs - extl : 0;
 	const int64_t ae = r.ve + extr < ctg_len ? r.ve + extr : ctg_len;
 	static thread_local std::vector<uint8_t> nt;
-	static thread_local std::vector<uint64_t> sd, a;
+	static thread_local std::vector<uint64_t> sd;
 	g_acc[13] += 1000000LL * 1;                                // (count of refined regions, printed /1e6/threads)
 	if (dev_hits) {                                            // the window was scanned on the device
 		AccTimer tm(11);
 		sd.assign(dev_hits, dev_hits + n_dev_hits);
 		refine_pairs_from_hits(sd, rq.qk, opt.max_ava, a);
-	} else {
-		nt.resize((size_t)(ae - as));
-		{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
+		return;
 	}
-	if (dev_hits) {
-	} else if (rq.filter) {
+	nt.resize((size_t)(ae - as));
+	{ AccTimer tm(8); fetch_nt(mi, (int32_t)r.vid, as, ae, nt.data()); }
+	if (rq.filter) {
 		AccTimer tm(9);
 		refine_seed_pairs(nt.data(), ae - as, mi->opt.min_aa_len, kmer, rq.qk, rq.filter->data(), opt.max_ava, sd, a);
 	} else {
@@ -271,10 +273,24 @@ static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Re
 		}
 		sort_u64(a.data(), a.data() + a.size());
 	}
-	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
-	                opt.chn_coef_log, is_splice, kmer, 0 };
+}
+
+static inline ChainParams refine_chain_params(const mpa_mapopt_t &opt)
+{
+	return ChainParams{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
+	                    opt.chn_coef_log, !(opt.flag & MPA_MF_NO_SPLICE), opt.kmer2, 0 };
+}
+
+// The refinement chain of a region over those anchors and what mp_refine_reg() makes of it (map.c:81-111).  f/pred != nullptr:
+// the forward pass of the chain ran on the device (dev_chain_forward).
+static void refine_region_chain(const mpa_idx_s *mi, const mpa_mapopt_t &opt, Region &r, int32_t extl, std::vector<uint64_t> &a,
+                                const int32_t *f = nullptr, const int32_t *pred = nullptr)
+{
+	const int32_t kmer = opt.kmer2;
+	const int64_t as = r.vs > extl ? r.vs - extl : 0;
+	const ChainParams cp = refine_chain_params(opt);
 	std::vector<uint64_t> u;
-	{ AccTimer tm(12); chain_anchors(cp, a, u); }
+	{ AccTimer tm(12); if (f) chain_anchors_after_forward(cp, f, pred, a, u); else chain_anchors(cp, a, u); }
 	if (u.empty()) { r.cnt = 0, r.off = -1, r.a.clear(); return; }
 	// the first chain with the highest score
 	size_t best = 0, skip = 0;
@@ -290,6 +306,14 @@ static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const Re
 	r.ve = as + (int64_t)(r.a[n_a - 1] >> 32) + 1;
 	for (uint64_t &x : r.a) x = (uint64_t)((int64_t)(x >> 32) + as - r.vs) << 32 | (x << 32 >> 32);
 	r.chn_sc_ungap = chain_score_ungapped(r.a.data(), r.cnt, kmer);
+}
+
+static void refine_region(const mpa_idx_s *mi, const mpa_mapopt_t &opt, const RefineQuery &rq, Region &r, int32_t extl, int32_t extr,
+                          const uint64_t *dev_hits = nullptr, int64_t n_dev_hits = 0)
+{
+	static thread_local std::vector<uint64_t> a;
+	refine_region_pairs(mi, opt, rq, r, extl, extr, dev_hits, n_dev_hits, a);
+	refine_region_chain(mi, opt, r, extl, a);
 }
 
 // mp_filter_seed (align.c:6-31): mark (bit 31) anchors inside tight, in-frame runs, trimmed at both ends
@@ -537,16 +561,23 @@ static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const Prec
 }
 
 // (3) everything else up to and including the alignment plans (map.c:185-226)
-static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
+static inline ChainParams main_chain_params(const mpa_idx_s *mi, const mpa_mapopt_t &opt)
+{
+	return ChainParams{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
+	                    opt.chn_coef_log, !(opt.flag & MPA_MF_NO_SPLICE), mi->opt.kmer, mi->opt.bbit };
+}
+
+// f/pred != nullptr: the forward pass of the main chain ran on the device (dev_chain_forward)
+static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a, const int32_t *f = nullptr, const int32_t *pred = nullptr)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
 	const int32_t is_splice = !(opt.flag & MPA_MF_NO_SPLICE);
 	static thread_local std::vector<uint64_t> u;
 	u.clear();
-	ChainParams cp{ opt.max_intron, opt.max_gap, opt.bw, opt.max_chn_max_skip, opt.max_chn_iter, opt.min_chn_cnt, opt.min_chn_sc,
-	                opt.chn_coef_log, is_splice, mi->opt.kmer, mi->opt.bbit };
-	{ AccTimer tm(3); chain_anchors(cp, a, u); }
+	const ChainParams cp = main_chain_params(mi, opt);
+	(void)is_splice;
+	{ AccTimer tm(3); if (f) chain_anchors_after_forward(cp, f, pred, a, u); else chain_anchors(cp, a, u); }
 	std::vector<Region> &regs = qs.regs;
 	AccTimer tm(4);
 	regions_from_chains(mi, u, a, regs);
@@ -567,7 +598,24 @@ static inline void refine_window(const mpa_idx_s *mi, const Region &r, uint64_t 
 }
 
 // (4) refinement of every region (with the device's scan results if there are any), then the alignment plans
-static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh)
+// (4a) only the anchor pairs of every region's refinement (the chains follow once their forward pass has run on the device)
+static void stage_refine_pairs(mpa_batch_s *b, QueryState &qs, const RefineHits *rh)
+{
+	AccTimer tm(5);
+	const mpa_mapopt_t &opt = b->opt;
+	RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
+	qs.ref_pairs.resize(qs.regs.size());
+	for (size_t i = 0; i < qs.regs.size(); ++i) {
+		const int64_t w = qs.win0 + (int64_t)i;
+		refine_region_pairs(b->mi, opt, rq, qs.regs[i], (int32_t)(qs.ext_refine[i] >> 32), (int32_t)qs.ext_refine[i],
+		                    rh ? rh->hits.data() + rh->first[w] : nullptr, rh ? rh->first[w + 1] - rh->first[w] : 0, qs.ref_pairs[i]);
+	}
+}
+
+// pairs_ready: stage_refine_pairs() has run; fwd != nullptr: the forward passes of the refinement chains come from the device,
+// fwd_first[w] = offset of refinement window w (= qs.win0 + region) in fwd->f / fwd->pred
+static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh, bool pairs_ready = false, const ChainIO *fwd = nullptr,
+                                 const int64_t *fwd_first = nullptr)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
@@ -576,13 +624,23 @@ static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHit
 	{
 		AccTimer tm(5);
 		std::vector<Region> kept;
-		RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
-		for (size_t i = 0; i < regs.size(); ++i) {
-			if (rh) {
+		if (pairs_ready) {
+			for (size_t i = 0; i < regs.size(); ++i) {
 				const int64_t w = qs.win0 + (int64_t)i;
-				refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i], rh->hits.data() + rh->first[w], rh->first[w + 1] - rh->first[w]);
-			} else refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
-			if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
+				if (fwd) refine_region_chain(mi, opt, regs[i], (int32_t)(ext[i] >> 32), qs.ref_pairs[i], fwd->f + fwd_first[w], fwd->pred + fwd_first[w]);
+				else refine_region_chain(mi, opt, regs[i], (int32_t)(ext[i] >> 32), qs.ref_pairs[i]);   // (the device declined: host pass over the pairs)
+				if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
+			}
+			std::vector<std::vector<uint64_t>>().swap(qs.ref_pairs);
+		} else {
+			RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
+			for (size_t i = 0; i < regs.size(); ++i) {
+				if (rh) {
+					const int64_t w = qs.win0 + (int64_t)i;
+					refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i], rh->hits.data() + rh->first[w], rh->first[w + 1] - rh->first[w]);
+				} else refine_region(mi, opt, rq, regs[i], (int32_t)(ext[i] >> 32), (int32_t)ext[i]);
+				if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
+			}
 		}
 		regs.swap(kept);
 	}
@@ -883,16 +941,63 @@ static void query_words(const char *aa, int32_t l_aa, int32_t k, std::vector<uin
 	}
 }
 
+// MPA_GPU_CHAIN: 0 = the forward passes of the main chain and of the refinement chains on the host, 1 = on the device
+// (k_chain_fwd), unset = by the size of the batch
+static int gpu_chain_mode()
+{
+	const char *e = getenv("MPA_GPU_CHAIN");
+	return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}
+static const int64_t kDeviceChainMinAnchors = 4000000;      // anchors entering the main chains of a mini-batch
+
 static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 {
 	const double t0 = now_ms();
 	const int64_t n_q = (int64_t)b->qs.size();
-	parallel_for(b->n_threads, n_q, [&](int64_t i) {
-		static thread_local std::vector<uint64_t> a;
-		if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, a);
-		else stage_anchors_host(b, b->qs[i], a);
-		stage_chain_to_windows(b, b->qs[i], a);
-	});
+	const int chain_mode = gpu_chain_mode();
+	bool dev_chain = rctx && chain_mode != 0;
+	if (!dev_chain) {
+		parallel_for(b->n_threads, n_q, [&](int64_t i) {
+			static thread_local std::vector<uint64_t> a;
+			if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, a);
+			else stage_anchors_host(b, b->qs[i], a);
+			stage_chain_to_windows(b, b->qs[i], a);
+		});
+	} else {
+		// the pre-chain's survivors of every query first; then the forward pass of all main chains in one k_chain_fwd launch
+		// (chain.c:181-209; one thread per independent run of anchors), then extraction and the rest per query
+		parallel_for(b->n_threads, n_q, [&](int64_t i) {
+			if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, b->qs[i].pre);
+			else stage_anchors_host(b, b->qs[i], b->qs[i].pre);
+		});
+		static thread_local std::vector<int64_t> first;
+		first.assign((size_t)n_q + 1, 0);
+		for (int64_t i = 0; i < n_q; ++i) first[i + 1] = first[i] + (int64_t)b->qs[i].pre.size();
+		ChainIO io;
+		int rc = MPA_ERR_UNSUPPORTED;
+		if (chain_mode == 1 || first[n_q] >= kDeviceChainMinAnchors) {
+			const double t1 = now_ms();
+			if ((rc = dev_chain_buffers(rctx, first[n_q], io)) == MPA_OK) {
+				const int64_t *fp = first.data();
+				uint64_t *dst = io.a;
+				parallel_for(b->n_threads, n_q, [&, fp, dst](int64_t i) {
+					const std::vector<uint64_t> &v = b->qs[i].pre;
+					if (!v.empty()) memcpy(dst + fp[i], v.data(), v.size() * 8);
+				});
+				rc = dev_chain_forward(rctx, main_chain_params(b->mi, b->opt), (int32_t)n_q, first.data(), io);
+			}
+			timing_note("  main chains: forward pass on the GPU", now_ms() - t1);
+		}
+		if (rc != MPA_OK) dev_chain = false;                  // too small to be worth it, or declined: everything on the host
+		const bool fwd = rc == MPA_OK;
+		const int64_t *fp = first.data();
+		parallel_for(b->n_threads, n_q, [&, fp, fwd](int64_t i) {
+			QueryState &qs = b->qs[i];
+			if (fwd) stage_chain_to_windows(b, qs, qs.pre, io.f + fp[i], io.pred + fp[i]);
+			else stage_chain_to_windows(b, qs, qs.pre);
+			std::vector<uint64_t>().swap(qs.pre);
+		});
+	}
 	b->sparse = PrechainSparse();
 	timing_note("  plan: anchors..windows (wall)", now_ms() - t0);
 	const double t_a = now_ms();
@@ -934,8 +1039,34 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	const RefineHits *rhp = on_device ? &rh : nullptr;
 	timing_note("  plan: windows + scan (wall)", now_ms() - t_a);
 	const double t_b = now_ms();
-	parallel_for(b->n_threads, n_q, [&, rhp](int64_t i) {
-		stage_refine_to_plan(b, b->qs[i], rhp);
+	// the refinement chains (base resolution, chain.c:123-139): with the device, their forward passes in one launch too
+	ChainIO rio;
+	static thread_local std::vector<int64_t> rfirst;
+	bool ref_fwd = false;
+	if (dev_chain) {
+		int64_t n_win = 0;
+		for (int64_t i = 0; i < n_q; ++i) b->qs[i].win0 = n_win, n_win += (int64_t)b->qs[i].regs.size();   // (the same numbering as the device scan's)
+		parallel_for(b->n_threads, n_q, [&, rhp](int64_t i) { stage_refine_pairs(b, b->qs[i], rhp); });
+		rfirst.assign((size_t)n_win + 1, 0);
+		for (int64_t i = 0; i < n_q; ++i)
+			for (size_t r = 0; r < b->qs[i].regs.size(); ++r) rfirst[(size_t)b->qs[i].win0 + r + 1] = (int64_t)b->qs[i].ref_pairs[r].size();
+		for (int64_t w = 0; w < n_win; ++w) rfirst[(size_t)w + 1] += rfirst[(size_t)w];
+		if (n_win > 0 && rfirst[(size_t)n_win] > 0 && dev_chain_buffers(rctx, rfirst[(size_t)n_win], rio) == MPA_OK) {
+			const int64_t *fp = rfirst.data();
+			uint64_t *dst = rio.a;
+			parallel_for(b->n_threads, n_q, [&, fp, dst](int64_t i) {
+				const QueryState &qs = b->qs[i];
+				for (size_t r = 0; r < qs.regs.size(); ++r)
+					if (!qs.ref_pairs[r].empty()) memcpy(dst + fp[qs.win0 + (int64_t)r], qs.ref_pairs[r].data(), qs.ref_pairs[r].size() * 8);
+			});
+			ref_fwd = dev_chain_forward(rctx, refine_chain_params(b->opt), (int32_t)n_win, rfirst.data(), rio) == MPA_OK;
+		}
+	}
+	const ChainIO *riop = ref_fwd ? &rio : nullptr;
+	const int64_t *rfp = rfirst.data();
+	const bool pairs_ready = dev_chain;
+	parallel_for(b->n_threads, n_q, [&, rhp, riop, rfp, pairs_ready](int64_t i) {
+		stage_refine_to_plan(b, b->qs[i], rhp, pairs_ready, riop, rfp);
 		AccTimer tm(7);
 		plan_round1(b, b->qs[i]);
 	});
@@ -1020,6 +1151,27 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
 	const int64_t n = off[q->n_seq];
 	delete b;
 	return n;
+}
+
+// Test hook: the forward pass of mp_chain (chain.c:181-209) for n_prob chaining problems whose sorted anchors lie back to back
+// in a[] (first[n_prob + 1] = boundaries): f / pred (index inside the problem, -1 = none) of every anchor, from the device
+// kernel k_chain_fwd (ctx != NULL) or from the host pass that chain_anchors() runs (ctx == NULL).
+int mpa_dbg_chain_forward(mpa_ctx_t *ctx, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t max_skip, int32_t max_iter, float coef_log,
+                          int32_t is_spliced, int32_t kmer, int32_t bbit, int32_t n_prob, const int64_t *first, const uint64_t *a, int32_t *f, int32_t *pred)
+{
+	const ChainParams p{ max_dist_x, max_dist_y, bw, max_skip, max_iter, 1, 0, coef_log, is_spliced, kmer, bbit };
+	const int64_t n = first[n_prob];
+	if (!ctx) {
+		for (int32_t q = 0; q < n_prob; ++q) chain_forward(p, a + first[q], first[q + 1] - first[q], f + first[q], pred + first[q]);
+		return MPA_OK;
+	}
+	ChainIO io;
+	int rc = dev_chain_buffers(ctx, n, io);
+	if (rc != MPA_OK) return rc;
+	if (n > 0) memcpy(io.a, a, (size_t)n * 8);
+	if ((rc = dev_chain_forward(ctx, p, n_prob, first, io)) != MPA_OK) return rc;
+	if (n > 0) memcpy(f, io.f, (size_t)n * 4), memcpy(pred, io.pred, (size_t)n * 4);
+	return MPA_OK;
 }
 
 static mpa_batch_t *mpa_batch_begin_impl(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
@@ -1166,7 +1318,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK;
 	std::string err;
-	int n_lanes = 2;
+	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so three
+	// lanes fit next to the two seeding streams; measured at config 3: 2 lanes 1.09 s, 3 lanes 1.00 s, 4 lanes 1.07 s (the host
+	// stages, not the GPU, bound the stream from three lanes on)
+	int n_lanes = 3;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
 	n_lanes = std::max(1, std::min(n_lanes, 4));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);

@@ -88,6 +88,10 @@ struct RefineHits { std::vector<int64_t> first; std::vector<uint64_t> hits; };
 int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t n_query, const int64_t *qw_first, const uint32_t *qwords,
                     int64_t n_win, const RefineWindow *wins, RefineHits &out);
 struct ChainParams;
+// forward pass of mp_chain (chain.c:181-209) for a batch of problems on the device; see dp_exec.hip
+struct ChainIO { uint64_t *a = nullptr; int32_t *f = nullptr, *pred = nullptr; };   // pinned buffers of the context, valid until its next chain call
+int dev_chain_buffers(mpa_ctx_t *ctx, int64_t n, ChainIO &io);
+int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &p, int32_t n_prob, const int64_t *first, const ChainIO &io);
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
                          const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out);
 

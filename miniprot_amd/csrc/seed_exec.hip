@@ -115,6 +115,101 @@ __global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_chain_fwd: the forward pass of mp_chain (chain.c:181-209) for ANY chaining problem of the path -- the main chain over the
+// pre-chain's survivors (block anchors, bbit > 0) and the refinement chain of a region (base resolution, bbit = 0, the exact-gap
+// branch of comput_sc, chain.c:123-139).  Input: the sorted anchors x << 32 | y of many problems back to back (first[] = problem
+// boundaries).  Two anchors further apart than max_dist_x on the target can never be linked, so a problem falls into
+// independent runs; one thread per anchor, the thread of a run's first anchor walks the run with exactly the reference's loop
+// (distance window, best-so-far rescue, max_iter, the max_skip counter over the marks).  Output: f[] and pred[] (index
+// inside the problem, -1 for none) of every anchor; the extraction stays on the host (chain_extract), because it consumes
+// the tie order of the reference's in-place radix sort.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t d_link_score_a(uint64_t cur, uint64_t prev, const PreParams &p)
+{
+	const int32_t dq = (int32_t)(uint32_t)cur - (int32_t)(uint32_t)prev, dq3 = dq * 3;
+	if (dq <= 0 || dq3 > p.max_dist_x || dq > p.max_dist_y) return D_INCOMPAT;
+	int32_t dr3, gap, gap_signed, sc;
+	if (p.bbit > 0) {
+		const int32_t bs = 1 << p.bbit;
+		dr3 = (int32_t)(((cur >> 32) - (prev >> 32)) << p.bbit);
+		if (dq3 < dr3 - bs) gap = dr3 - bs - dq3, gap_signed = -gap;
+		else if (dq3 > dr3 + bs) gap = dq3 - dr3 - bs, gap_signed = gap;
+		else gap = gap_signed = 0;
+	} else {
+		dr3 = (int32_t)((cur >> 32) - (prev >> 32));
+		if (dr3 == 0) return D_INCOMPAT;
+		gap_signed = dq3 - dr3;
+		gap = gap_signed < 0 ? -gap_signed : gap_signed;
+	}
+	if (gap > p.bw) return D_INCOMPAT;
+	if (p.bbit > 0) sc = p.kmer < dq ? p.kmer : dq;
+	else if (p.kmer <= dq && p.kmer * 3 <= dr3) sc = p.kmer;
+	else {
+		const int32_t dr = dr3 / 3;
+		sc = dr < dq ? dr : dq;
+		if (p.kmer < sc) sc = p.kmer;
+		if (dr3 != dr * 3) --sc;                                    // the two anchors are in different frames
+	}
+	if (gap > 0) {
+		const float lin = (float)gap * .33334f;
+		const float lg = gap >= 2 ? p.coef_log * (d_log2_poly((float)(gap + 1)) - 1.0f) + 1.0f : (float)gap;
+		if (p.is_spliced && gap_signed < 0) sc -= (int)(lin < lg ? lin : lg);
+		else sc -= (int)(lin + lg);
+	}
+	if (p.bbit > 0 && cur >> 32 == prev >> 32 && gap == 0) sc += 2;   // MP_BLOCK_BONUS
+	return sc;
+}
+
+__global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n, const int64_t *first, int32_t n_prob, PreParams p,
+                                                   int32_t *f, int32_t *pred, int32_t *mark)
+{
+	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (s >= n) return;
+	// the problem this anchor belongs to: largest q with first[q] <= s
+	int32_t lo = 0, hi = n_prob - 1;
+	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (first[mid] <= s) lo = mid; else hi = mid - 1; }
+	const int64_t q0 = first[lo], q1 = first[lo + 1];
+	const uint64_t xs = a[s] >> 32;
+	const uint64_t max_dx = (uint64_t)(p.max_dist_x >> p.bbit);          // (x_i - x_j) << bbit > max_dist_x  <=>  x_i - x_j > max_dist_x >> bbit
+	if (s > q0 && xs - (a[s - 1] >> 32) <= max_dx) return;               // not the head of its run
+	int64_t e = s + 1;
+	{
+		uint64_t prev = xs;
+		while (e < q1) { const uint64_t x = a[e] >> 32; if (x - prev > max_dx) break; prev = x, ++e; }
+	}
+	int64_t win = s, hot = -1;
+	int32_t hot_f = 0;
+	for (int64_t i = s; i < e; ++i) {
+		const uint64_t ai = a[i];
+		const int32_t me = (int32_t)(i - q0);
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (ai >> 32) - (a[win] >> 32) > max_dx) ++win;
+		if (hot >= 0 && hot >= win) {
+			const int32_t l = d_link_score_a(ai, a[hot], p);
+			const int32_t sc = l == D_INCOMPAT ? D_INCOMPAT : hot_f + l;
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		for (int64_t j = i - 1; j >= win; --j) {
+			int32_t sc = d_link_score_a(ai, a[j], p);
+			if (sc == D_INCOMPAT) continue;
+			sc += f[j];
+			if (sc > best) {
+				best = sc, best_j = j;
+				if (skipped > 0) --skipped;
+			} else if (mark[j] == me) {
+				if (++skipped > p.max_skip) break;
+			}
+			const int32_t pj = pred[j];
+			if (pj >= 0) mark[q0 + pj] = me;
+		}
+		f[i] = best, pred[i] = best_j < 0 ? -1 : (int32_t)(best_j - q0);
+		if (hot_f < best) hot_f = best, hot = i;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
 {
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

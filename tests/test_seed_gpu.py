@@ -111,3 +111,77 @@ def test_device_refinement_scan_equals_host_scan():
     assert fh[-1] > 500                                                   # the windows over the ORF stretch do hit
     idx.close()
     ctx.close()
+
+
+def test_device_chain_forward_equals_host_forward():
+    """k_chain_fwd (the forward pass of mp_chain for any chaining problem, one thread per independent run of anchors) against
+    the host pass that tests/test_host_core.py pins to the oracle: block anchors (main chain: long windows, planted chains,
+    dense repeats that exercise max_skip and max_iter) and base-resolution anchors (refinement chains, the exact-gap branch
+    of comput_sc), many problems per launch, empty and one-anchor problems in between"""
+    from test_host_core import _anchors, _long_chains
+    L = mpa.lib()
+    L.mpa_dbg_chain_forward.argtypes = [C.c_void_p] + [C.c_int32] * 5 + [C.c_float] + [C.c_int32] * 4 + [C.c_void_p] * 4
+    rng = np.random.default_rng(17)
+    ctx = mpa.Context(0)
+
+    def both(args, probs):
+        first = np.zeros(len(probs) + 1, np.int64)
+        np.cumsum([len(p) for p in probs], out=first[1:])
+        a = np.ascontiguousarray(np.concatenate(probs + [np.zeros(0, np.uint64)]), dtype=np.uint64)
+        res = []
+        for c in (None, ctx.h):
+            f, pr = np.full(len(a) + 1, -7, np.int32), np.full(len(a) + 1, -7, np.int32)
+            rc = L.mpa_dbg_chain_forward(c, *args, len(probs), first.ctypes.data, a.ctypes.data, f.ctypes.data, pr.ctypes.data)
+            assert rc == 0, mpa.last_error()
+            res.append((f[:len(a)], pr[:len(a)]))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (args, [len(p) for p in probs][:8])
+        return int((res[0][1] >= 0).sum())
+
+    linked = 0
+    for it in range(12):                                        # main-chain shape: max_dist_x = max_intron, bbit 8
+        probs = []
+        for k in range(int(rng.choice([1, 7, 60]))):
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                probs.append(_anchors(rng, int(rng.choice([70, 500, 9000])), 3000000, 400, int(rng.choice([0, 3, 40]))))
+            elif kind == 1:
+                probs.append(_anchors(rng, int(rng.choice([65, 300, 3000])), int(rng.choice([50, 400, 3000])), 300, 20))       # dense: max_skip matters
+            elif kind == 2:
+                probs.append(np.unique(np.concatenate([_anchors(rng, 2000, 3000000, 900, 10), _long_chains(rng, 3000000, 3, "any")])))
+            elif kind == 3:
+                probs.append(np.zeros(0, np.uint64))
+            else:
+                probs.append(_anchors(rng, 1, 1000, 100, 0)[:1])
+        args = [int(rng.choice([200000, 20000])), 1000, int(rng.choice([200000, 20000])), int(rng.choice([25, 2])), int(rng.choice([1000000, 50])), 0.75, int(rng.integers(0, 2)), 6, 8]
+        linked += both(args, probs)
+    for it in range(8):                                         # refinement shape: base resolution, kmer 5
+        probs = []
+        for k in range(int(rng.choice([1, 30]))):
+            n = int(rng.choice([0, 1, 5, 80, 600]))
+            dq = np.cumsum(rng.integers(1, 9, n))
+            x = 1000 + dq * 3 + (rng.choice([0, 0, 1, -1, 300, 5000], n) * (rng.random(n) < 0.1)).cumsum()
+            probs.append(np.unique((x.astype(np.uint64) << np.uint64(32)) | (20 + dq).astype(np.uint64)))
+        args = [200000, 1000, 200000, int(rng.choice([25, 2])), 1000000, 0.75, int(rng.integers(0, 2)), 5, 0]
+        linked += both(args, probs)
+    assert linked > 5000
+    ctx.close()
+
+
+def test_whole_path_with_device_chains(monkeypatch):
+    """MPA_GPU_CHAIN=1: main chain and refinement chains take their forward passes from k_chain_fwd -- same output bytes as with
+    the host passes (and as the reference: the golden case is one of tests/test_map_gpu.py's)"""
+    from hostpipe import map_batch_gpu
+    case = golden.SYNTH_CASES[1]
+    contigs, prots, names = golden.synth_inputs(case)
+    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
+    ctx = mpa.Context(0)
+    idx.to_device(ctx)
+    mo = golden.mapopt_for(case)
+    ref = open(golden.path(case["name"] + ".ref.paf"), "rb").read()
+    for chain, seed, refine in (("1", "0", "0"), ("1", "1", "1"), ("0", "1", "1")):
+        monkeypatch.setenv("MPA_GPU_CHAIN", chain), monkeypatch.setenv("MPA_GPU_SEED", seed), monkeypatch.setenv("MPA_GPU_REFINE", refine)
+        out = golden.file_header(case) + b"".join(mpa.map_batches(ctx, idx, mo, [mpa.Queries(prots, names)], 4))
+        assert out == ref, (chain, seed, refine)
+    idx.close()
+    ctx.close()

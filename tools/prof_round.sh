@@ -1,8 +1,17 @@
-set -x
-cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py > gpurun_out/bench_r01.json 2> gpurun_out/bench_r01.err; tail -1 gpurun_out/bench_r01.json | cut -c1-400
-python bench.py --no-stream --steps 6 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_r01_blocking.json; cut -c1-220 gpurun_out/bench_r01_blocking.json
+#!/bin/bash
+# Round-end evidence on the GPU box (through gpurun): tests, smoke, the bench line, kernel trace of the bench command, PMC passes.
+#   bash tools/prof_round.sh [outdir]
+cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-rm -rf gpurun_out/trace_final; rocprofv3 --kernel-trace --stats -d gpurun_out/trace_final -o t -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/trace_final.json 2> gpurun_out/trace_final.err
-ls gpurun_out/trace_final | head
+OUT=${1:-gpurun_out/round}
+mkdir -p $OUT
+(time python -m pytest tests -m gpu -q) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | cut -c1-200
+(time python bench.py) > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
+rm -rf $OUT/trace; rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 10 > $OUT/trace_bench.json 2> $OUT/trace.err
+DB=$(find $OUT/trace -name "t_results.db" | head -1)
+python tools/rocpd_stats.py $DB > $OUT/kernel_trace_stats.txt 2>&1; head -12 $OUT/kernel_trace_stats.txt
+python tools/timeline.py $DB 2500 60 > $OUT/dispatch_timeline.txt 2>&1
+find $OUT/trace -name "*.db" -size +30M -delete
+bash tools/pmc_round.sh $OUT/pmc
+find $OUT/pmc -name "*.db" -size +30M -delete
