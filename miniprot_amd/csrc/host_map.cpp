@@ -941,14 +941,16 @@ static void query_words(const char *aa, int32_t l_aa, int32_t k, std::vector<uin
 	}
 }
 
-// MPA_GPU_CHAIN: 0 = the forward passes of the main chain and of the refinement chains on the host, 1 = on the device
-// (k_chain_fwd), unset = by the size of the batch
+// MPA_GPU_CHAIN=1: the forward passes of the main chain and of the refinement chains on the device (k_chain_fwd); default: on
+// the host.  Measured at config 3 (3 Gbp x 20 000 proteins, three DP lanes, 64 host threads): 0.96-1.01 s with the host passes,
+// 1.09-1.11 s with the device passes -- the pass itself is 24-28 ms per 2 000-protein batch next to three DP rounds in flight
+// (19 M anchors up, f/pred down) and it cuts the planning stage's one parallel region in two; the host pass it replaces is
+// about a third of the main-chain work, the extraction (which has to stay on the host) the rest.
 static int gpu_chain_mode()
 {
 	const char *e = getenv("MPA_GPU_CHAIN");
-	return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+	return e ? (atoi(e) != 0 ? 1 : 0) : 0;
 }
-static const int64_t kDeviceChainMinAnchors = 4000000;      // anchors entering the main chains of a mini-batch
 
 static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 {
@@ -975,7 +977,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 		for (int64_t i = 0; i < n_q; ++i) first[i + 1] = first[i] + (int64_t)b->qs[i].pre.size();
 		ChainIO io;
 		int rc = MPA_ERR_UNSUPPORTED;
-		if (chain_mode == 1 || first[n_q] >= kDeviceChainMinAnchors) {
+		{
 			const double t1 = now_ms();
 			if ((rc = dev_chain_buffers(rctx, first[n_q], io)) == MPA_OK) {
 				const int64_t *fp = first.data();
