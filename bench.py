@@ -82,7 +82,7 @@ class Workload:
     """Genome index + protein mini-batches of one config.  Rank 0 generates and indexes; with several ranks the index and the
     proteins travel through a directory in /dev/shm (mpa_idx_dump / mpa_idx_restore), so the host work is done once."""
 
-    def __init__(self, mpa, cfg, rank, world, barrier, share_dir, n_threads, scale=1.0):
+    def __init__(self, mpa, cfg, rank, world, barrier, share_dir, n_threads, scale=1.0, ctx=None):
         from miniprot_amd import synth
         self.cfg, self.mpa = cfg, mpa
         t0 = time.time()
@@ -95,7 +95,8 @@ class Workload:
             t1 = time.time()
             self.idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
             del contigs
-            mpa._check(mpa.lib().mpa_idx_build_kmers(self.idx.h, max(2, n_threads)))
+            # the k-mer table: scan + one radix sort on the GPU (mpa_idx_build_kmers_device), on the host cores if that declines
+            self.index_built_on = self.idx.build_kmers(max(2, n_threads), ctx)
             self.t_index = time.time() - t1
             synth.write_fasta_aa(faa, prots, names)
             self.idx.dump(mpi)                                # for the other ranks and for the reference binary
@@ -106,6 +107,7 @@ class Workload:
             for line in open(faa, "rb"):
                 (names if line.startswith(b">") else prots).append(line[1:].strip().decode() if line.startswith(b">") else line.strip())
             self.t_generate = self.t_index = 0.0
+            self.index_built_on = "rank 0"
         self.prots, self.names = prots, names
         b = cfg["batch"]
         self.batches = [mpa.Queries(prots[i:i + b], names[i:i + b]) for i in range(0, len(prots), b)]
@@ -255,8 +257,8 @@ def main():
         if rank == 0:
             os.makedirs(share, exist_ok=True)
         barrier()
-        wl = Workload(mpa, cfg, rank, world, barrier, share, n_threads, a.scale)
         ctx = mpa.Context(local_rank)
+        wl = Workload(mpa, cfg, rank, world, barrier, share, n_threads, a.scale, ctx)
         wl.idx.to_device(ctx)
         elapsed, texts, st = measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, sync)
         if dist is not None:
@@ -295,7 +297,8 @@ def main():
                    "roofline": roofline_record(st, elapsed, world), "cpu_baseline": cpu,
                    "dp_cells": {"ext": st["cells_ext"], "glob": st["cells_glob"]},
                    "gcups_wall": (st["cells_ext"] + st["cells_glob"]) / elapsed / 1e9,
-                   "setup_s": {"generate": wl.t_generate, "index_build": wl.t_index, "total": wl.t_setup}, "host_threads_per_rank": n_threads}
+                   "setup_s": {"generate": wl.t_generate, "index_build": wl.t_index, "index_built_on": wl.index_built_on, "total": wl.t_setup},
+                   "host_threads_per_rank": n_threads}
         ctx.close()
         wl.idx.close()
         barrier()

@@ -98,6 +98,11 @@ mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64
 mpa_idx_t *mpa_idx_build(const char *fasta_fn, const mpa_idxopt_t *io, int n_threads);
 /* k-mer table of a genome-only index: build_worker + build_bidx (index.c:52-95) */
 int mpa_idx_build_kmers(mpa_idx_t *mi, int n_threads);
+/* the same table built on the GPU (scan kernel + one radix sort of all k-mer keys): same ki/kb, and kb stays resident for the
+ * seeding kernels.  MPA_ERR_UNSUPPORTED when the parameters or the genome do not fit the device path (build on the host then). */
+int mpa_idx_build_kmers_device(mpa_ctx_t *ctx, mpa_idx_t *mi);
+/* genome-only index of a FASTA file with the given parameters (mp_ntseq_read, ntseq.c:29-75); build the table with either of the above */
+mpa_idx_t *mpa_idx_read_fasta(const char *fasta_fn, const mpa_idxopt_t *io);
 int mpa_idx_dump(const char *fn, const mpa_idx_t *mi);          /* mp_idx_dump, index.c:189: byte-identical file */
 void mpa_idx_destroy(mpa_idx_t *mi);
 int32_t mpa_idx_n_ctg(const mpa_idx_t *mi);

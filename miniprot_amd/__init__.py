@@ -91,6 +91,9 @@ def lib():
         L.mpa_idx_from_nt4.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p]
         L.mpa_idx_dump.argtypes = [C.c_char_p, C.c_void_p]
         L.mpa_idx_build_kmers.argtypes = [C.c_void_p, C.c_int]
+        L.mpa_idx_build_kmers_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.mpa_idx_read_fasta.restype = C.c_void_p
+        L.mpa_idx_read_fasta.argtypes = [C.c_char_p, C.c_void_p]
         L.mpa_idx_destroy.argtypes = [C.c_void_p]
         L.mpa_idx_n_ctg.argtypes = [C.c_void_p]
         L.mpa_idx_ctg_len.restype = C.c_int64
@@ -225,6 +228,28 @@ class Index:
         idx = cls.from_nt4(parts, names)
         _check(lib().mpa_idx_build_kmers(idx.h, n_threads))
         return idx
+
+    @classmethod
+    def read_fasta(cls, path, idxopt=None):
+        """Genome-only index of a FASTA file (mpa_idx_read_fasta); idxopt: (bbit, min_aa_len, kmer, mod_bit, trans_code) or None"""
+        io = (C.c_int32 * 5)()
+        lib().mpa_idxopt_init(io)
+        if idxopt is not None:
+            for k, v in enumerate(idxopt):
+                io[k] = v
+        return cls(lib().mpa_idx_read_fasta(os.fsencode(path), io))
+
+    def build_kmers(self, n_threads=4, ctx=None):
+        """The k-mer table (mp_idx_build): on the GPU when a context is given and the device path takes the job, else on the host.
+        Returns "gpu" or "host"."""
+        if ctx is not None:
+            rc = lib().mpa_idx_build_kmers_device(ctx.h, self.h)
+            if rc == 0:
+                return "gpu"
+            if rc != -3:                                      # MPA_ERR_UNSUPPORTED: parameters / memory -> host
+                _check(rc)
+        _check(lib().mpa_idx_build_kmers(self.h, n_threads))
+        return "host"
 
     def to_device(self, ctx):
         _check(lib().mpa_idx_to_device(ctx.h, self.h))

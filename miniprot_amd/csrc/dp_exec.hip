@@ -12,6 +12,7 @@
 // here too.  There is no CPU fallback here by design.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <cstring>
 #include <cstdlib>
@@ -294,6 +295,12 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 
 int mpa_idx_to_device(mpa_ctx_t *ctx, mpa_idx_t *mi) { return dev_upload_index(ctx, mi); }
 
+int mpa_idx_build_kmers_device(mpa_ctx_t *ctx, mpa_idx_t *mi)
+{
+	if (!ctx) { set_error("no device context"); return MPA_ERR_NO_DEVICE; }
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return dev_index_build(ctx, mi); });
+}
+
 } // extern "C"
 
 namespace mpa {
@@ -429,6 +436,116 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
 	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
 	timing_note("    seed: compact + download", now_ms() - t_kernels);
+	return MPA_OK;
+}
+} // namespace mpa
+
+namespace mpa {
+// mp_idx_build's k-mer table on the device (index.c:52-136): scan (count, then emit), one radix sort of all keys, unique,
+// bucket histogram + scan.  Leaves kb[] resident for the seeding kernels.  MPA_ERR_UNSUPPORTED (the caller builds on the host):
+// parameters outside the kernel's range, or not enough device memory for the keys of this genome.
+int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
+{
+	const int32_t n_strand = (int32_t)mi->ctg.size() * 2;
+	const mpa_idxopt_t &io = mi->opt;
+	const int bucket_bits = io.kmer * 4 - io.mod_bit;
+	if (n_strand == 0 || io.kmer < 1 || io.kmer > 7 || io.mod_bit < 0 || bucket_bits < 1 || bucket_bits > 28 || io.bbit < 0 || io.bbit > 20 || io.min_aa_len < io.kmer ||
+	    io.min_aa_len > 1000) { set_error("index build: parameters outside the device kernel's range"); return MPA_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
+	DeviceIndex *d = mi->dev;
+	hipStream_t s = ctx->stream;
+	std::vector<int64_t> chunk_first((size_t)n_strand + 1, 0);
+	for (int32_t j = 0; j < n_strand; ++j) chunk_first[j + 1] = chunk_first[j] + (mi->ctg[j >> 1].len + REFINE_CHUNK - 1) / REFINE_CHUNK;
+	const int64_t n_chunk = chunk_first[n_strand];
+	if (n_chunk == 0 || n_chunk > 0x7fffffff) { set_error("index build: genome too small or too large for one launch"); return MPA_ERR_UNSUPPORTED; }
+	const size_t n_bucket = (size_t)1 << bucket_bits;
+	DevBuf b_first, b_bo, b_count, b_off, b_keys, b_keys2, b_flag, b_idx, b_tmp, b_cnt, b_ki;
+	auto release_all = [&]() { for (DevBuf *b : { &b_first, &b_bo, &b_count, &b_off, &b_keys, &b_keys2, &b_flag, &b_idx, &b_tmp, &b_cnt, &b_ki }) b->release(); };
+	struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{ release_all };
+	int rc;
+	if ((rc = b_first.ensure(((size_t)n_strand + 1) * 8)) || (rc = b_bo.ensure((size_t)n_strand * 4 + 4)) || (rc = b_count.ensure((size_t)n_chunk * 4 + 4)) ||
+	    (rc = b_off.ensure(((size_t)n_chunk + 1) * 8))) return rc;
+	HIP_TRY(hipMemcpyAsync(b_first.p, chunk_first.data(), ((size_t)n_strand + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(b_bo.p, mi->bo.data(), (size_t)n_strand * 4, hipMemcpyHostToDevice, s));
+	IndexScanArgs a;
+	a.g = DevGenome{ d->seq, d->ctg_off, d->ctg_len, nullptr, mi->l_seq };
+	a.chunk_first = b_first.as<int64_t>(), a.bo = b_bo.as<uint32_t>();
+	a.n_strand = n_strand, a.kmer = io.kmer, a.mod_bit = io.mod_bit, a.bbit = io.bbit, a.min_aa_len = io.min_aa_len, a.halo = (3 * io.min_aa_len + 2 + 15) & ~15;
+	for (int c = 0; c < 64; ++c) a.rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
+	const size_t lds = (size_t)REFINE_CHUNK + 2 * (size_t)a.halo;
+	const double t0 = now_ms();
+	hipLaunchKernelGGL(k_index_scan<false>, dim3((unsigned)n_chunk), dim3(256), lds, s, a, b_count.as<uint32_t>(), (const uint64_t*)nullptr, (uint64_t*)nullptr);
+	HIP_TRY(hipGetLastError());
+	// exclusive scan of the per-chunk counts (as 64-bit offsets)
+	{
+		size_t tmp_bytes = 0;
+		auto in = rocprim::make_transform_iterator(b_count.as<uint32_t>(), U32ToU64());
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, in, b_off.as<uint64_t>(), (uint64_t)0, (size_t)n_chunk, rocprim::plus<uint64_t>(), s));
+		if ((rc = b_tmp.ensure(tmp_bytes + 256))) return rc;
+		HIP_TRY(rocprim::exclusive_scan(b_tmp.p, tmp_bytes, in, b_off.as<uint64_t>(), (uint64_t)0, (size_t)n_chunk, rocprim::plus<uint64_t>(), s));
+	}
+	uint64_t last_off = 0;
+	uint32_t last_cnt = 0;
+	HIP_TRY(hipMemcpyAsync(&last_off, b_off.as<uint64_t>() + (n_chunk - 1), 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&last_cnt, b_count.as<uint32_t>() + (n_chunk - 1), 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const int64_t n_keys = (int64_t)(last_off + last_cnt);
+	if (n_keys == 0) { mi->ki.assign(n_bucket, 0), mi->kb.clear(), mi->n_kb = 0; return MPA_OK; }
+	{	// two key buffers, flags, scan, kb: ~40 bytes per key
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)n_keys * 44 + n_bucket * 16 > free_b - (free_b >> 3)) {
+			set_error("index build: not enough device memory for the k-mer keys of this genome"); return MPA_ERR_UNSUPPORTED;
+		}
+	}
+	if ((rc = b_keys.ensure((size_t)n_keys * 8)) || (rc = b_keys2.ensure((size_t)n_keys * 8))) return rc;
+	hipLaunchKernelGGL(k_index_scan<true>, dim3((unsigned)n_chunk), dim3(256), lds, s, a, (uint32_t*)nullptr, b_off.as<uint64_t>(), b_keys.as<uint64_t>());
+	HIP_TRY(hipGetLastError());
+	int nb = 1;
+	while ((1ULL << nb) < (uint64_t)mi->n_block + 1) ++nb;
+	{
+		size_t tmp_bytes = 0;
+		HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, b_keys.as<uint64_t>(), b_keys2.as<uint64_t>(), (size_t)n_keys, 0u, 32u + (unsigned)bucket_bits, s));
+		if ((rc = b_tmp.ensure(tmp_bytes + 256))) return rc;
+		HIP_TRY(rocprim::radix_sort_keys(b_tmp.p, tmp_bytes, b_keys.as<uint64_t>(), b_keys2.as<uint64_t>(), (size_t)n_keys, 0u, 32u + (unsigned)bucket_bits, s));
+	}
+	(void)nb;
+	b_keys.release();
+	const uint64_t *sorted = b_keys2.as<uint64_t>();
+	if ((rc = b_flag.ensure((size_t)n_keys * 4)) || (rc = b_idx.ensure((size_t)n_keys * 8)) || (rc = b_cnt.ensure(n_bucket * 8)) || (rc = b_ki.ensure(n_bucket * 8))) return rc;
+	const unsigned nblk = (unsigned)((n_keys + 255) / 256);
+	hipLaunchKernelGGL(k_index_flag, dim3(nblk), dim3(256), 0, s, sorted, n_keys, b_flag.as<uint32_t>());
+	{
+		size_t tmp_bytes = 0;
+		auto in = rocprim::make_transform_iterator(b_flag.as<uint32_t>(), U32ToU64());
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, in, b_idx.as<uint64_t>(), (uint64_t)0, (size_t)n_keys, rocprim::plus<uint64_t>(), s));
+		if ((rc = b_tmp.ensure(tmp_bytes + 256))) return rc;
+		HIP_TRY(rocprim::exclusive_scan(b_tmp.p, tmp_bytes, in, b_idx.as<uint64_t>(), (uint64_t)0, (size_t)n_keys, rocprim::plus<uint64_t>(), s));
+	}
+	uint64_t last_idx = 0;
+	uint32_t last_flag = 0;
+	HIP_TRY(hipMemcpyAsync(&last_idx, b_idx.as<uint64_t>() + (n_keys - 1), 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&last_flag, b_flag.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const int64_t n_kb = (int64_t)(last_idx + last_flag);
+	uint32_t *d_kb = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_kb, (size_t)n_kb * 4 + 16));
+	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, n_bucket * 8, s));
+	hipLaunchKernelGGL(k_index_compact, dim3(nblk), dim3(256), 0, s, sorted, n_keys, b_flag.as<uint32_t>(), b_idx.as<uint64_t>(), d_kb, b_cnt.as<unsigned long long>());
+	{
+		size_t tmp_bytes = 0;
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, b_cnt.as<uint64_t>(), b_ki.as<uint64_t>(), (uint64_t)0, n_bucket, rocprim::plus<uint64_t>(), s));
+		if ((rc = b_tmp.ensure(tmp_bytes + 256))) { (void)hipFree(d_kb); return rc; }
+		HIP_TRY(rocprim::exclusive_scan(b_tmp.p, tmp_bytes, b_cnt.as<uint64_t>(), b_ki.as<uint64_t>(), (uint64_t)0, n_bucket, rocprim::plus<uint64_t>(), s));
+	}
+	HIP_TRY(hipGetLastError());
+	mi->ki.resize(n_bucket), mi->kb.resize((size_t)n_kb), mi->n_kb = n_kb;
+	HIP_TRY(hipMemcpyAsync(mi->ki.data(), b_ki.p, n_bucket * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(mi->kb.data(), d_kb, (size_t)n_kb * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (d->kb) (void)hipFree(d->kb);
+	d->kb = d_kb;                                          // stays resident for the seeding kernels
+	timing_note("index build on the GPU", now_ms() - t0);
 	return MPA_OK;
 }
 } // namespace mpa

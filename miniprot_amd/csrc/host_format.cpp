@@ -1,7 +1,8 @@
-// host_format.cpp -- PAF text of a mapped batch, byte-identical to the reference's.
+// host_format.cpp -- output text of a mapped batch, byte-identical to the reference's.
 //
-// Follows mp_write_paf (format.c:333-358), mp_write_cs (format.c:102-187) and the per-query output
-// filters of worker_pipeline step 2 (map.c:298-311).  GFF3/GTF/--aln/--trans are not part of this round.
+// Follows mp_write_output (format.c:453-473): mp_write_paf (format.c:333-358) with mp_write_cs (format.c:102-187), mp_write_gff
+// (format.c:360-412), mp_write_gtf (format.c:414-451), the residue rows of --aln / --trans (format.c:189-331), and the per-query
+// output filters and running hit id of worker_pipeline step 2 (map.c:298-311).
 #include <cctype>
 #include <cstdio>
 #include <cstring>

@@ -185,6 +185,13 @@ mpa_idx_t *mpa_idx_from_nt4(int32_t n_ctg, const char *const *names, const int64
 // mp_idx_build (index.c:97-136) = mp_ntseq_read (ntseq.c:29-75) + the k-mer table: FASTA (plain or gzip) -> index.
 mpa_idx_t *mpa_idx_build(const char *fn, const mpa_idxopt_t *io, int n_threads)
 {
+	mpa_idx_t *mi = mpa_idx_read_fasta(fn, io);
+	if (mi) mpa_idx_build_kmers(mi, n_threads > 1 ? n_threads : 1);
+	return mi;
+}
+
+mpa_idx_t *mpa_idx_read_fasta(const char *fn, const mpa_idxopt_t *io)
+{
 	FastaReader rd(fn);
 	if (!rd.ok()) { set_error(std::string("cannot open ") + fn); return nullptr; }
 	if (set_trans_code((int)io->trans_code) < 0) return nullptr;
@@ -203,7 +210,7 @@ mpa_idx_t *mpa_idx_build(const char *fn, const mpa_idxopt_t *io, int n_threads)
 	}
 	mi->l_seq = off;
 	compute_block_offsets(mi);
-	mpa_idx_build_kmers(mi, n_threads > 1 ? n_threads : 1);
+	mi->ki.assign((size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit), 0);
 	return mi;
 }
 

@@ -70,6 +70,7 @@ int64_t idx_read_spsc(mpa_idx_s *mi, const char *fn, int32_t max_sc);   // mp_nt
 
 // ---- device executor (mpa_dp.hip) ----------------------------------------------------------------
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi);
+int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi);           // k-mer table of a genome-only index on the device (index.c:52-136)
 void dev_free_index(mpa_idx_s *mi);
 mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);

@@ -13,8 +13,11 @@
 // operations, compiled without FMA contraction like the host code.
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace mpa {
+
+struct U32ToU64 { __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; } };   // scan inputs of 32-bit counts as 64-bit sums
 
 struct SeedJobDev { int64_t kb_off, dst; int32_t cnt, qpos, qid, pad; };
 
@@ -327,6 +330,94 @@ __global__ __launch_bounds__(256) void k_refine_scan(DevGenome g, const RefineWi
 		const unsigned long long at = atomicAdd(n_hits, 1ULL);
 		if (at < cap) hits[at] = make_uint4((uint32_t)ch.win, (uint32_t)pos, d_hash32_mask(word, mask), 0u);
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Index build on the device (mp_idx_build: build_worker + build_bidx, index.c:52-136; mp_sketch_nt4 + mp_sketch_clean_orf,
+// sketch.c:40-100): every selected k-mer of every reading frame of both strands of every contig as (bucket << 32 | global
+// block id); sorted and de-duplicated these keys ARE the index -- kb[] is their low words (inside a bucket ascending global
+// block id = contig/strand order, then position, which is the reference's layout) and ki[] the bucket boundaries.
+// k_index_scan: one workgroup per 2 048 positions of a strand (bases + halo in LDS); a thread forms the k-mer that ends at
+// its position from `kmer` codons, hashes it, applies the modimizer test, and checks that the open reading frame around it
+// has at least min_aa_len codons by walking its frame both ways (an ORF ends at a stop codon, an ambiguous base or the
+// contig end).  Two passes over the genome: count per chunk, exclusive scan, then emit at exact offsets.
+// ------------------------------------------------------------------------------------------------
+struct IndexScanArgs {
+	DevGenome g;
+	const int64_t *chunk_first;     // [2 n_ctg + 1] first chunk of every strand
+	const uint32_t *bo;             // [2 n_ctg] block offset of every strand
+	int32_t n_strand, kmer, mod_bit, bbit, min_aa_len, halo;
+	RefineTab rt;
+};
+
+template<bool EMIT>
+__global__ __launch_bounds__(256) void k_index_scan(IndexScanArgs a, uint32_t *count, const uint64_t *offset, uint64_t *keys)
+{
+	extern __shared__ uint32_t lds_index[];
+	uint8_t *base = (uint8_t*)lds_index;                            // [REFINE_CHUNK + 2 halo] nt4 codes, 15 = outside the contig
+	__shared__ uint8_t tab[64];
+	__shared__ uint32_t n_here;
+	const int64_t chunk = blockIdx.x;
+	int32_t lo = 0, hi = a.n_strand - 1;
+	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (a.chunk_first[mid] <= chunk) lo = mid; else hi = mid - 1; }
+	const int32_t strand = lo, cid = strand >> 1, rev = strand & 1;
+	const int64_t off = a.g.ctg_off[cid], clen = a.g.ctg_len[cid];
+	const int64_t start = (chunk - a.chunk_first[strand]) * REFINE_CHUNK;
+	const int32_t halo = a.halo, span = REFINE_CHUNK + 2 * halo;
+	if (threadIdx.x < 64) tab[threadIdx.x] = a.rt.t[threadIdx.x];
+	if (threadIdx.x == 0) n_here = 0;
+	for (int k = threadIdx.x; k < span; k += 256) {
+		const int64_t p = start - halo + k;
+		base[k] = (p < 0 || p >= clen) ? 15 : (uint8_t)strand_base(a.g.seq, off, clen, rev, p);
+	}
+	__syncthreads();
+	const uint32_t mask = (1u << (4 * a.kmer)) - 1, mask_mod = (1u << a.mod_bit) - 1;
+	auto codon_at = [&](int e) -> uint32_t {                          // reduced residue of the codon whose last base is LDS index e; 0xff if none
+		const uint32_t b0 = base[e - 2], b1 = base[e - 1], b2 = base[e];
+		if ((b0 | b1 | b2) > 3) return 0xffu;
+		return tab[b0 << 4 | b1 << 2 | b2];
+	};
+	const uint64_t out0 = EMIT ? offset[chunk] : 0;
+	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
+		const int64_t pos = start + t * 256 + (int64_t)threadIdx.x;     // strand-local position of the k-mer's last base
+		if (pos >= clen) continue;
+		const int e = (int)(pos - start) + halo;
+		uint32_t word = 0;
+		bool ok = true;
+		for (int c = a.kmer - 1; c >= 0; --c) {
+			const uint32_t r = codon_at(e - 3 * c);
+			if (r == 0xffu) { ok = false; break; }
+			word = word << 4 | r;
+		}
+		if (!ok) continue;
+		const uint32_t h = d_hash32_mask(word & mask, mask);
+		if (h & mask_mod) continue;
+		int32_t n = a.kmer;
+		for (int q = e - 3 * a.kmer; n < a.min_aa_len && q >= 2 && codon_at(q) != 0xffu; q -= 3) ++n;
+		for (int q = e + 3; n < a.min_aa_len && q < span && codon_at(q) != 0xffu; q += 3) ++n;
+		if (n < a.min_aa_len) continue;
+		const uint32_t slot = atomicAdd(&n_here, 1u);
+		if (EMIT) keys[out0 + slot] = (uint64_t)(h >> a.mod_bit) << 32 | (uint64_t)((uint32_t)(pos >> a.bbit) + a.bo[strand]);
+	}
+	if (!EMIT) {
+		__syncthreads();
+		if (threadIdx.x == 0) count[chunk] = n_here;
+	}
+}
+
+// flag[i] = 1 where sorted key i differs from key i - 1
+__global__ __launch_bounds__(256) void k_index_flag(const uint64_t *keys, int64_t n, uint32_t *flag)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// the distinct keys: kb[] = their block ids, cnt[bucket] = how many per bucket
+__global__ __launch_bounds__(256) void k_index_compact(const uint64_t *keys, int64_t n, const uint32_t *flag, const uint64_t *idx, uint32_t *kb, unsigned long long *cnt)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n || !flag[i]) return;
+	kb[idx[i]] = (uint32_t)keys[i];
+	atomicAdd(&cnt[keys[i] >> 32], 1ULL);
 }
 
 } // namespace mpa

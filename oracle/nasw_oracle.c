@@ -1,7 +1,7 @@
 /* nasw_oracle.c -- scalar, column-sequential restatement of miniprot's spliced protein-to-genome DP.
  *
  * TEST INFRASTRUCTURE ONLY (see mporacle.h).  Parity PINNED against oracle/_ref (the compiled
- * reference) by tests/test_oracle_vs_ref.py.
+ * reference) by tests/test_oracle.py (and tests/golden/dp_vectors.npz, made by tools/make_golden.py).
  *
  * What is restated: ns_global_gs16b (nasw-sse.c:340-551) in its three modes, the input preparation
  * ns_prep_seq / ns_prep_seq_left / ns_prep_nas / ns_gen_prof (nasw-sse.c:91-224), and the traceback

@@ -196,3 +196,38 @@ def test_ns_global_gs16b_on_a_host_buffer():
         assert res[0] == res[1], "call %d (flag %d, nl %d, al %d)" % (it, flag, len(nt), len(aa))
         n_checked += 1
     assert n_checked == 60
+
+
+@pytest.mark.gpu
+def test_index_built_on_the_gpu_is_the_reference_file(tmp_path):
+    """mpa_idx_build_kmers_device (scan kernel + one radix sort of all k-mer keys + unique) against the host build, which the
+    CPU tests pin to `miniprot -d`: the .mpi of the awkward multi-contig genome (tiny, empty, N-rich, soft-masked contigs), with
+    default and non-default -k/-M/-b/-L, and of a 30 Mbp synthetic genome; mapping with the GPU-built index gives the same bytes"""
+    fa = str(tmp_path / "g.fa")
+    prots, names = _multi_contig_genome(fa)
+    ctx = mpa.Context(0)
+    for k, io in enumerate((None, (6, 20, 5, 0, 1), (8, 30, 6, 2, 1))):
+        a = mpa.Index.read_fasta(fa, io)
+        b = mpa.Index.read_fasta(fa, io)
+        assert a.build_kmers(4, ctx) == "gpu" and b.build_kmers(4) == "host"
+        a.dump(str(tmp_path / "a.mpi")), b.dump(str(tmp_path / "b.mpi"))
+        assert open(str(tmp_path / "a.mpi"), "rb").read() == open(str(tmp_path / "b.mpi"), "rb").read(), io
+        if io is None and os.path.exists(refbind.REF_BIN):
+            subprocess.run([refbind.REF_BIN, "-t4", "-d", str(tmp_path / "r.mpi"), fa], check=True, capture_output=True)
+            assert open(str(tmp_path / "a.mpi"), "rb").read() == open(str(tmp_path / "r.mpi"), "rb").read()
+        a.close(), b.close()
+    contigs, prots, names = gen_synth.generate(30_000_000, 3, 60, 21, n_frac=0.05, paralog_frac=0.02)
+    a = mpa.Index.from_nt4(contigs, ["c1", "c2", "c3"])
+    b = mpa.Index.from_nt4(contigs, ["c1", "c2", "c3"])
+    assert a.build_kmers(8, ctx) == "gpu" and b.build_kmers(8) == "host"
+    a.dump(str(tmp_path / "a.mpi")), b.dump(str(tmp_path / "b.mpi"))
+    assert open(str(tmp_path / "a.mpi"), "rb").read() == open(str(tmp_path / "b.mpi"), "rb").read()
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    a.to_device(ctx)
+    ours = b"".join(mpa.map_batches(ctx, a, mo, [mpa.Queries(prots, names)], 8))
+    if os.path.exists(refbind.REF_BIN):
+        faa = str(tmp_path / "p.faa")
+        gen_synth.write_fasta_aa(faa, prots, names)
+        assert ours == subprocess.run([refbind.REF_BIN, "-t8", "-u", str(tmp_path / "b.mpi"), faa], capture_output=True).stdout
+    a.close(), b.close(), ctx.close()
