@@ -202,7 +202,19 @@ mp_idx_t *mp_idx_load(const char *fn, const mp_idxopt_t *io, int32_t n_threads)
 		close(fd);
 	}
 	if (is_idx) return mp_idx_restore(fn);
-	CompatIndex *c = wrap_index(mpa_idx_build(fn, reinterpret_cast<const mpa_idxopt_t*>(io), n_threads));
+	// mp_idx_build (index.c:97-136): the genome from the FASTA, then the k-mer table -- on the GPU when there is one (scan kernel
+	// + one radix sort, seconds for a human-sized genome), on n_threads host threads otherwise; the same table either way
+	mpa_idx_t *impl = mpa_idx_read_fasta(fn, reinterpret_cast<const mpa_idxopt_t*>(io));
+	if (impl) {
+		bool built = false;
+		if (mpa_device_count() > 0) {
+			std::lock_guard<std::mutex> g(g_mu);
+			if (!g_ctx) g_ctx = mpa_ctx_create(default_device());
+			built = g_ctx && mpa_idx_build_kmers_device(g_ctx, impl) == MPA_OK;
+		}
+		if (!built) mpa_idx_build_kmers(impl, n_threads > 1 ? n_threads : 1);
+	}
+	CompatIndex *c = wrap_index(impl);
 	if (c && mp_verbose >= 3)
 		fprintf(stderr, "[M::%s@%.3f*%.2f] %ld kmer-block pairs\n", "mp_idx_build", mp_realtime(), mp_percent_cpu(), (long)c->pub.n_kb);
 	return c ? &c->pub : nullptr;

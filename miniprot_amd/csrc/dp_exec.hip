@@ -961,13 +961,23 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		wa.waves = ctx->waves.as<ExtWave>();                // absolute descriptor indices: the rowkey slot of group g is g - first wide group
 		wa.rowkey = ctx->rowkey.as<uint32_t>() - (int64_t)ewave_first[3] * 2 * key_stride;
 		ga.waves = d_gw;
+		// MPA_ROUND_WG_PER_CU (default 4): workgroups of the round kernel per CU, enforced through the LDS it asks for.  Five fit
+		// (30.4 KB, 94 VGPRs), but then the 20 DP waves of a CU hold 480 of each SIMD's 512 registers and the seeding kernels of the
+		// next batches (radix sort passes, pre-chain) cannot be co-resident: they wait for whole workgroups to retire.
+		static const size_t round_lds = [] {
+			const char *e = getenv("MPA_ROUND_WG_PER_CU");
+			int w = e ? atoi(e) : 4;
+			w = w < 1 ? 1 : w > 5 ? 5 : w;
+			const size_t pad = ((size_t)160 * 1024 / w) & ~(size_t)255;
+			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
+		}();
 		static bool attr_set = false;
-		if (!attr_set && DP_ROUND_LDS > 48 * 1024) {
-			HIP_TRY(hipFuncSetAttribute((const void*)k_dp_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_ROUND_LDS));
+		if (!attr_set && round_lds > 48 * 1024) {
+			HIP_TRY(hipFuncSetAttribute((const void*)k_dp_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)round_lds));
 			attr_set = true;
 		}
 		HIP_TRY(hipEventRecord(ev_round0, s));
-		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)units.size()), dim3(256), DP_ROUND_LDS, s, ea, wa, ga, ctx->units.as<DpUnit>());
+		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)units.size()), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(ev_round1, s));
 		round_launched = true;

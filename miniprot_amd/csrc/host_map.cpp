@@ -106,7 +106,7 @@ public:
 	// never destroyed: workers outlive main().  One pool per lane, so that the pipeline stages of mpa_map_batches()
 	// (seeding of the next batch / DP-round bookkeeping / flattening + formatting of the previous one) can each run
 	// their own parallel region at the same time.
-	static WorkerPool &get(int lane) { static WorkerPool *p[4] = { new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
+	static WorkerPool &get(int lane) { static WorkerPool *p[8] = { new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
 	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
 		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
 		std::unique_lock<std::mutex> run_lock(run_mu_);              // one parallel region at a time
@@ -1320,10 +1320,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK;
 	std::string err;
-	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so three
-	// lanes fit next to the two seeding streams; measured at config 3: 2 lanes 1.09 s, 3 lanes 1.00 s, 4 lanes 1.07 s (the host
-	// stages, not the GPU, bound the stream from three lanes on)
-	int n_lanes = 3;
+	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so four
+	// lanes fit next to the seeding streams; measured at config 3 (20 000 proteins in 10 batches, two planners, two seeders):
+	// 3 lanes 0.91 s, 4 lanes 0.865 s; with one planner and one seeder the host stages bound the stream (1.00 s, any lane count)
+	int n_lanes = 4;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
 	n_lanes = std::max(1, std::min(n_lanes, 4));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
@@ -1331,45 +1331,61 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
 	// third context land on the queues of the second one's (measured, rocprofv3 queue ids), three further on they do not
 	{ const char *e = getenv("MPA_LANE2_SIDE_OFF"); if (n_lanes > 2) ctx_set_side_offset(lane_ctx[2], e ? atoi(e) : 3); }
-	// the seeder's own streams and buffers, two sets: the result of batch k is consumed while batch k+1 is on the device
-	mpa_ctx_t *seed_ctx[2] = { ctx_sibling(ctx, n_lanes), ctx_sibling(ctx, n_lanes + 1) };
-	if (!seed_ctx[0] || !seed_ctx[1]) return MPA_ERR_HIP;
+	// Planners: the planning stage (pre-chain extraction, chaining, refinement, plans) is memory-bound host work that gains
+	// nothing from more than ~32 threads, so two batches are planned side by side with half the threads each
+	// (MPA_PLANNERS, default 2).  The seeder's own streams and buffers, one set per batch that can be between seeding and
+	// the end of planning: the result of batch k is consumed while batches k+1 .. are on the device.
+	int n_plan = 2;
+	if (const char *e = getenv("MPA_PLANNERS")) n_plan = atoi(e);
+	n_plan = std::max(1, std::min(n_plan, 3));
+	// Seeders: the device-seeding stage of a batch is mostly waiting for its kernels, which share the GPU with the DP rounds in
+	// flight; two batches are seeded side by side (MPA_SEEDERS, default 2)
+	int n_seed = 2;
+	if (const char *e = getenv("MPA_SEEDERS")) n_seed = atoi(e);
+	n_seed = std::max(1, std::min(n_seed, 3));
+	const int n_seed_ctx = n_plan + n_seed;
+	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
+	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
-	std::thread seeder([&] { try {
-		tl_pool_lane = 1, tl_thread_div = 4;
-		for (int32_t k = 0; k < n_batches; ++k) {
-			{	// stay at most one batch ahead of the planner (its result lives in one of two seeding contexts)
+	auto seeder_body = [&](int sd) { try {
+		tl_pool_lane = sd == 0 ? 1 : 5 + sd, tl_thread_div = 4;
+		for (int32_t k = sd; k < n_batches; k += n_seed) {
+			{	// its result lives in a seeding context until the batch is planned: wait for the batch that had this context before
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || k <= n_planned + 1; });
+				cv.wait(g, [&] { return rc_all != MPA_OK || k < n_seed_ctx || slot[k - n_seed_ctx].begun; });
 				if (rc_all != MPA_OK) return;
 			}
-			trace("seed", k, "begin");
-			mpa_batch_t *b = batch_seed_phase(seed_ctx[k & 1], mi, opt, &batches[k], n_threads);
-			trace("seed", k, "end");
+			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "begin");
+			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &batches[k], n_threads);
+			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].b = b, slot[k].seeded = true;
 			cv.notify_all();
 		}
-	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("seeding stage: ") + e.what()); } });
-	std::thread planner([&] { try {
-		tl_pool_lane = 3;
-		for (int32_t k = 0; k < n_batches; ++k) {
-			{	// stay at most one batch ahead of the ones in their DP rounds
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("seeding stage: ") + e.what()); } };
+	std::vector<std::thread> seeders;
+	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
+	auto planner_body = [&](int pl) { try {
+		tl_pool_lane = pl == 0 ? 3 : 3 + pl, tl_thread_div = n_plan;
+		for (int32_t k = pl; k < n_batches; k += n_plan) {
+			{	// stay at most a planner's worth of batches ahead of the ones in their DP rounds
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes); });
+				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1); });
 				if (rc_all != MPA_OK) return;
 			}
-			trace("plan", k, "begin");
-			batch_plan_phase(slot[k].b, seed_ctx[k & 1]);
-			trace("plan", k, "end");
+			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "begin");
+			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
+			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "end");
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].begun = true, ++n_planned;
 			cv.notify_all();
 		}
-	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("planning stage: ") + e.what()); } });
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("planning stage: ") + e.what()); } };
+	std::vector<std::thread> planners;
+	for (int pl = 0; pl < n_plan; ++pl) planners.emplace_back(planner_body, pl);
 	std::thread finisher([&] { try {
 		tl_pool_lane = 2, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
@@ -1388,11 +1404,16 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// DP lanes: lane d drives the DP rounds of batches d, d + n_lanes, ... on its own device context (streams + buffers).
 	// The rounds of one batch are dominated by the tails of a few very long DP calls, during which the GPU is nearly
 	// idle; the next batch's rounds fill that space.
+	// a lane that is free takes the next batch in input order (a static deal would leave lanes idle behind a slow batch)
+	int32_t next_dp = 0;
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
 		tl_thread_div = 4;
-		for (int32_t k = d; k < n_batches; k += n_lanes) {
+		for (;;) {
+			int32_t k;
 			{
 				std::unique_lock<std::mutex> g(mu);
+				if (next_dp >= n_batches) return;
+				k = next_dp++;
 				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
 				if (rc_all != MPA_OK) return;
 			}
@@ -1410,7 +1431,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
 	tl_thread_div = 1;
-	seeder.join(), planner.join(), finisher.join();
+	finisher.join();
+	for (auto &t : seeders) t.join();
+	for (auto &t : planners) t.join();
 	ctx_absorb_sibling_stats(ctx);
 	if (rc_all != MPA_OK) {
 		for (Slot &sl : slot) delete sl.b;
