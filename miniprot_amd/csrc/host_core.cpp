@@ -509,7 +509,10 @@ static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, s
 
 // chain.c:8-110 on the result of the forward pass: extraction (best chain end first), then the kept chains laid out in
 // ascending anchor order and sorted by their first target position.
-void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u)
+// set_only: the caller wants the anchors of the kept chains as a SET, ascending (the pre-chain, map.c:186-192, whose chains
+// are dissolved again by the sort that follows it): no chain list, no layout, and no sort either -- the view is in ascending
+// anchor order, so marking the kept anchors and reading the view through gives them sorted.
+static void chain_extract_impl(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u, bool set_only)
 {
 	u.clear();
 	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
@@ -563,6 +566,17 @@ void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_
 		else order.resize(before);                       // rejected chains keep their anchors claimed
 	}
 	if (u.empty()) { a_out.clear(); return; }
+	if (set_only) {
+		// (mark: 1 = claimed; the anchors of the kept chains are exactly those in `order`)
+		static thread_local std::vector<uint8_t> kept;
+		kept.assign((size_t)v.m, 0);
+		for (int32_t x : order) kept[(size_t)x] = 1;
+		a_out.resize(order.size());
+		size_t k = 0;
+		for (int64_t i = 0; i < v.m; ++i) if (kept[(size_t)i]) a_out[k++] = v.a[i];
+		u.clear();
+		return;
+	}
 
 	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
 	packed.resize(order.size());
@@ -590,6 +604,17 @@ void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_
 	u.assign(u_sorted.begin(), u_sorted.end());
 }
 
+void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u)
+{
+	chain_extract_impl(p, v, a_out, u, false);
+}
+
+void chain_extract_set(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out)
+{
+	static thread_local std::vector<uint64_t> u;
+	chain_extract_impl(p, v, a_out, u, true);
+}
+
 void chain_anchors_after_forward(const ChainParams &p, const int32_t *f, const int32_t *pred, std::vector<uint64_t> &a, std::vector<uint64_t> &u)
 {
 	u.clear();
@@ -607,7 +632,13 @@ void chain_forward(const ChainParams &p, const uint64_t *a_ptr, int64_t n, int32
 	chain_anchors(p, a, u, f_out, pred_out);
 }
 
-void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy, int32_t *pred_copy)
+void chain_anchors_set(const ChainParams &p, std::vector<uint64_t> &a)
+{
+	static thread_local std::vector<uint64_t> u;
+	chain_anchors(p, a, u, nullptr, nullptr, true);
+}
+
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy, int32_t *pred_copy, bool set_only)
 {
 	u.clear();
 	const int64_t n = (int64_t)a.size();
@@ -651,7 +682,7 @@ void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<u
 	if (f_copy) memcpy(f_copy, f.data(), (size_t)n * 4), memcpy(pred_copy, pred.data(), (size_t)n * 4);
 	a_in.assign(a.begin(), a.end());
 	const ChainView v{ n, n, nullptr, f.data(), pred.data(), a_in.data() };
-	chain_extract(p, v, a, u);
+	chain_extract_impl(p, v, a, u, set_only);
 }
 
 } // namespace mpa

@@ -38,7 +38,9 @@ struct ChainParams {
 };
 // a: sorted anchors, rewritten with the anchors of the kept chains (chain by chain, ascending);
 // u: one entry per chain, score<<32 | n_anchors
-void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy = nullptr, int32_t *pred_copy = nullptr);
+void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy = nullptr, int32_t *pred_copy = nullptr, bool set_only = false);
+// a: rewritten with the anchors of the kept chains as an ascending set (the pre-chain: its chains are dissolved right away)
+void chain_anchors_set(const ChainParams &p, std::vector<uint64_t> &a);
 // The state after the forward pass (chain.c:181-209) of a chaining problem with n_total anchors.  A dense view holds all of
 // them (pos == nullptr, m == n_total).  A sparse view (only valid when min_cnt > 1) may leave out anchors that have no
 // predecessor and are nobody's predecessor; pos[] are then the ascending positions of the m anchors it does hold.
@@ -50,6 +52,8 @@ struct ChainView {
 	const uint64_t *a;       // [m] the anchors
 };
 void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u);
+// the anchors of the kept chains as an ascending set, without the chain list (what the pre-chain's caller needs)
+void chain_extract_set(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out);
 // chain_anchors() when the forward pass was done elsewhere (the device, dev_chain_forward): extraction only
 void chain_anchors_after_forward(const ChainParams &p, const int32_t *f, const int32_t *pred, std::vector<uint64_t> &a, std::vector<uint64_t> &u);
 // the forward pass alone (reference values for the operator test of k_chain_fwd)

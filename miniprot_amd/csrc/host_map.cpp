@@ -538,8 +538,7 @@ static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint6
 	{ AccTimer tm(1); sort_anchors_by_block(a); }
 	if (prechain_enabled(opt)) {
 		AccTimer tm(2);
-		chain_anchors(prechain_params(mi, opt), a, u);
-		sort_u64(a.data(), a.data() + a.size());
+		chain_anchors_set(prechain_params(mi, opt), a);          // (ascending: the sort of map.c:192 is implied)
 		g_acc[15] += (int64_t)a.size() * 1000;
 	}
 }
@@ -548,15 +547,13 @@ static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint6
 static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const PrechainSparse &ps, std::vector<uint64_t> &a)
 {
 	AccTimer tm(2);
-	static thread_local std::vector<uint64_t> u;
 	const int64_t c0 = ps.cfirst[qs.qid], m = ps.cfirst[qs.qid + 1] - c0;
 	a.clear();
 	g_acc[14] += qs.n_anchor * 1000;
 	if (m == 0) return;
 	// (the device hands the predecessors over as indices into the query's part of the view)
 	const ChainView v{ qs.n_anchor, m, ps.pos + c0, ps.f + c0, ps.pred + c0, ps.a + c0 };
-	chain_extract(prechain_params(b->mi, b->opt), v, a, u);
-	sort_u64(a.data(), a.data() + a.size());
+	chain_extract_set(prechain_params(b->mi, b->opt), v, a);      // (ascending already: no sort)
 	g_acc[15] += (int64_t)a.size() * 1000;
 }
 
