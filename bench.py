@@ -11,7 +11,7 @@ PAF text) over ONE mini-batch.  The K timed steps are the mini-batches k mod 10,
 (what miniprot's own batch loop, map.c:273-345, would call): pipeline fill and drain are inside the timed region.  Every
 output line of every timed step is compared with the reference's output for the same proteins (`paf_identical`).
 
-    python bench.py                                    # N=1, config 3, 60 steps (6 passes over the 20 000 proteins, ~6 s timed)
+    python bench.py                                    # N=1, config 3, 80 steps (8 passes over the 20 000 proteins, ~6 s timed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
 N>1 (BASELINE.json configs[3]): the SAME job -- the same K mini-batches of the same proteins -- dealt round-robin over the ranks
@@ -209,13 +209,15 @@ def roofline_record(st, elapsed, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--scale", type=float, default=1.0, help="(debug) shrink genome and protein set by this factor; the line is then NOT the named config")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = cores / ranks, at most 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N=1, config 3: skip the config-2 and config-5 records")
+    ap.add_argument("--debug-shared-gpu", action="store_true", help="(debug) all ranks on cuda:0 with the gloo backend: exercises the N>1 code path on a "
+                    "one-GPU box; the line is NOT a scaling measurement")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,11 +228,15 @@ def main():
     if "RANK" in os.environ:                                # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.debug_shared_gpu:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DP kernels have no CPU fallback")
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cpu") if a.debug_shared_gpu else torch.device("cuda", local_rank)
 
     import miniprot_amd as mpa
     from miniprot_amd import dist as mdist
@@ -238,7 +244,9 @@ def main():
     ncpu = os.cpu_count() or 1
     # host threads of the planning stage (the other pipeline stages take a quarter each): the host stages are memory-bound and
     # more than 64 threads lose (measured at config 3 on the 256-thread host: 32 -> 0.98 s, 64 -> 1.00 s, 96 -> 1.10 s, 128 -> 1.22 s)
-    n_threads = a.threads if a.threads > 0 else max(1, min(64, ncpu // max(world, 1)))
+    # (a rank's pipeline runs about 2.75 x n_threads host threads: two planners with half each, two seeders, four DP lanes and
+    # the output stage with a quarter each -- so N ranks share the host's hardware threads without oversubscribing them)
+    n_threads = a.threads if a.threads > 0 else max(4, min(64, int(ncpu / max(world, 1) / 2.75)))
 
     def barrier():
         if dist is not None:

@@ -12,6 +12,7 @@ rm -rf $OUT/trace; rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python
 DB=$(find $OUT/trace -name "t_results.db" | head -1)
 python tools/rocpd_stats.py $DB > $OUT/kernel_trace_stats.txt 2>&1; head -12 $OUT/kernel_trace_stats.txt
 python tools/timeline.py $DB 2500 60 > $OUT/dispatch_timeline.txt 2>&1
-find $OUT/trace -name "*.db" -size +30M -delete
+rm -rf $OUT/trace                      # (only the summaries travel back: gpurun returns at most 64 MiB)
 bash tools/pmc_round.sh $OUT/pmc
-find $OUT/pmc -name "*.db" -size +30M -delete
+find $OUT/pmc -name "*.db" -delete; find $OUT/pmc -type d -empty -delete
+du -sh $OUT
