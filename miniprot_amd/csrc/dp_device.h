@@ -6,6 +6,14 @@
 #define __device__
 #endif
 
+// The short kernels around the DP rounds (row records, profiles, backtrack, seeding, scans) share the GPU with round kernels of
+// other batches whose waves are long-lived and VALU-bound; instruction issue on a SIMD goes by priority, then by age, so a young
+// wave at the default priority gets only the slots the old DP waves leave.  They raise their priority once, at entry: they are
+// short, latency-critical (a DP lane or a pipeline stage waits for them) and cost the rounds next to nothing.
+#ifdef __HIPCC__
+#define MPA_SHORT_KERNEL() __builtin_amdgcn_s_setprio(2)
+#endif
+
 namespace mpa {
 
 // One DP call as the kernels see it (built by the executor from mpa_dp_task_t).

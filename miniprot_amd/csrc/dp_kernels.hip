@@ -192,6 +192,7 @@ __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off,
 // ns_prep_seq_left (nasw-sse.c:157-210).  int8 wrap-around of the reference's arrays is preserved.
 __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tasks, const PrepChunk *chunks, uint32_t *rec, DpConst c, DevTables tb)
 {
+	MPA_SHORT_KERNEL();
 	const PrepChunk ch = chunks[blockIdx.x];
 	const DTask t = tasks[ch.task];
 	const int32_t i = ch.row0 + (int32_t)threadIdx.x, nl = t.nl;
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 // query profile prof[a][col] = mat[a][aa(col)] (ns_gen_prof nasw-sse.c:212-224); columns >= al score -32768
 __global__ __launch_bounds__(256) void k_prep_prof(const DTask *tasks, const char *qseq, int16_t *prof, DevTables tb)
 {
+	MPA_SHORT_KERNEL();
 	const DTask t = tasks[blockIdx.x];
 	const int left = (t.flag & 2) != 0;
 	for (int idx = threadIdx.x; idx < 22 * t.pw; idx += blockDim.x) {
@@ -1139,6 +1141,7 @@ __global__ __launch_bounds__(64) void k_ext_huge(GlobArgs a)
 __global__ __launch_bounds__(64) void k_ext_replay(const DTask *tasks, const int32_t *list, int32_t n_list, const unsigned long long *rowkey64,
                                                    ExtOut *out, DpConst c, PenTable pen)
 {
+	MPA_SHORT_KERNEL();
 	if ((int32_t)blockIdx.x >= n_list) return;
 	const int32_t tid = list[blockIdx.x];
 	const DTask t = tasks[tid];
@@ -1369,6 +1372,7 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_backtrack(const DTask *tasks, const int32_t *list, int32_t n_list, const uint16_t *tbpool, uint32_t *cigpool, int32_t *n_cigar)
 {
+	MPA_SHORT_KERNEL();
 	if ((int32_t)blockIdx.x >= n_list) return;
 	const int32_t tid = list[blockIdx.x];
 	const DTask t = tasks[tid];
@@ -1448,6 +1452,7 @@ __global__ __launch_bounds__(64) void k_backtrack(const DTask *tasks, const int3
 __global__ __launch_bounds__(64) void k_cigar_gather(const DTask *tasks, const int32_t *list, const int64_t *dst_off, int32_t n_list,
                                                      const int32_t *n_cigar, const uint32_t *src, uint32_t *dst)
 {
+	MPA_SHORT_KERNEL();
 	if ((int32_t)blockIdx.x >= n_list) return;
 	const int32_t tid = list[blockIdx.x], n = n_cigar[tid];
 	const uint32_t *from = src + tasks[tid].cig_off;

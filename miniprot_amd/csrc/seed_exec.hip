@@ -23,6 +23,7 @@ struct SeedJobDev { int64_t kb_off, dst; int32_t cnt, qpos, qid, pad; };
 
 __global__ __launch_bounds__(256) void k_seed_gather(const SeedJobDev *jobs, int32_t n_jobs, const uint32_t *kb, int nb, uint64_t *key, uint32_t *val)
 {
+	MPA_SHORT_KERNEL();
 	const int32_t j = blockIdx.x;
 	if (j >= n_jobs) return;
 	const SeedJobDev s = jobs[j];
@@ -73,6 +74,7 @@ __device__ __forceinline__ int32_t d_link_score(uint64_t kcur, uint32_t qcur, ui
 __global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, PreParams p,
                                                       int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (s >= n) return;
 	const uint64_t ks = key[s];
@@ -167,6 +169,7 @@ __device__ __forceinline__ int32_t d_link_score_a(uint64_t cur, uint64_t prev, c
 __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n, const int64_t *first, int32_t n_prob, PreParams p,
                                                    int32_t *f, int32_t *pred, int32_t *mark)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (s >= n) return;
 	// the problem this anchor belongs to: largest q with first[q] <= s
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n,
 
 __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i < n) f[i] = kmer, pred[i] = -1, mark[i] = -1, flag[i] = 0;
 }
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int3
 __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
                                                       const uint32_t *idx, const int32_t *f, const int32_t *pred, int32_t *o_pos, int32_t *o_f, int32_t *o_pred, uint64_t *o_a)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= n || !flag[i]) return;
 	const uint64_t k = key[i];
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const
 // compact offset of every query's first anchor (+ the total)
 __global__ __launch_bounds__(256) void k_seed_bounds(const int64_t *qfirst, int32_t n_query, int64_t n, const uint32_t *idx, const uint32_t *flag, int64_t *cfirst)
 {
+	MPA_SHORT_KERNEL();
 	const int32_t q = blockIdx.x * 256 + threadIdx.x;
 	if (q > n_query) return;
 	const int64_t i = qfirst[q];
@@ -270,6 +276,7 @@ __device__ __forceinline__ uint32_t d_hash32_mask(uint32_t key, uint32_t mask)  
 __global__ __launch_bounds__(256) void k_refine_scan(DevGenome g, const RefineWindowDev *wins, const RefineChunk *chunks, const int64_t *qw_first, const uint32_t *qwords,
                                                      RefineTab rt, int32_t kmer, int32_t min_aa_len, int32_t hs_log2, uint4 *hits, unsigned long long *n_hits, unsigned long long cap)
 {
+	MPA_SHORT_KERNEL();
 	extern __shared__ uint32_t lds_refine[];
 	const int32_t HS = 1 << hs_log2;
 	uint32_t *table = lds_refine;                                   // [HS] open addressing, 0xffffffff = empty
@@ -408,12 +415,14 @@ __global__ __launch_bounds__(256) void k_index_scan(IndexScanArgs a, uint32_t *c
 // flag[i] = 1 where sorted key i differs from key i - 1
 __global__ __launch_bounds__(256) void k_index_flag(const uint64_t *keys, int64_t n, uint32_t *flag)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 // the distinct keys: kb[] = their block ids, cnt[bucket] = how many per bucket
 __global__ __launch_bounds__(256) void k_index_compact(const uint64_t *keys, int64_t n, const uint32_t *flag, const uint64_t *idx, uint32_t *kb, unsigned long long *cnt)
 {
+	MPA_SHORT_KERNEL();
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= n || !flag[i]) return;
 	kb[idx[i]] = (uint32_t)keys[i];
