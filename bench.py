@@ -4,14 +4,15 @@
 Workload (default, `--config 3` = BASELINE.json configs[2], the one `metric` is quoted on): synthetic 3 Gbp human-like genome
 (24 contigs x 125 Mbp, 5 % N runs, 2 % tandem pseudo-paralogs of planted genes) x 20 000 proteins (~400 aa, 15 % diverged),
 flags `-I -u` (max_intron from the genome size, options.c:31-37), generator miniprot_amd/synth.py, index
-built once and resident in HBM before the timed region.  The 20 000 proteins are 10 distinct mini-batches of 2 000.
+built once and resident in HBM before the timed region.  The 20 000 proteins are 5 distinct mini-batches of 4 000 (the
+reference's own mini-batch is 2 M residues, about 5 000 of these proteins: main.c -K).
 
 A "step" is one pass of the whole per-query hot path (seed -> chain -> refine -> spliced DP on the GPU -> CIGAR/statistics ->
-PAF text) over ONE mini-batch.  The K timed steps are the mini-batches k mod 10, handed to mpa_map_batches() as one stream
+PAF text) over ONE mini-batch.  The K timed steps are the mini-batches k mod 5, handed to mpa_map_batches() as one stream
 (what miniprot's own batch loop, map.c:273-345, would call): pipeline fill and drain are inside the timed region.  Every
 output line of every timed step is compared with the reference's output for the same proteins (`paf_identical`).
 
-    python bench.py                                    # N=1, config 3, 80 steps (8 passes over the 20 000 proteins, ~6 s timed)
+    python bench.py                                    # N=1, config 3, 80 steps (16 passes over the 20 000 proteins, ~11 s timed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
 N>1 (BASELINE.json configs[3]): the SAME job -- the same K mini-batches of the same proteins -- dealt round-robin over the ranks
@@ -47,7 +48,7 @@ CONFIGS = {
     2: dict(name="config 2: synthetic 50 Mbp genome (1 contig) x 1 000 proteins, flags -u", genome_mb=50, n_ctg=1, n_prot=1000, seed=12, batch=1000,
             gen=dict(), flags=["-u"]),
     3: dict(name="config 3: synthetic 3 Gbp human-like genome (24 contigs x 125 Mbp, 5 % N runs, 2 % tandem pseudo-paralogs) x 20 000 proteins, flags -I -u",
-            genome_mb=3000, n_ctg=24, n_prot=20000, seed=3, batch=2000,
+            genome_mb=3000, n_ctg=24, n_prot=20000, seed=3, batch=4000,
             gen=dict(mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02), flags=["-I", "-u"]),
     5: dict(name="config 5: long-intron stress, 3 Gbp genome x 2 000 proteins with >= 4 exons, introns to 450 kb, flags -G 500k -u",
             genome_mb=3000, n_ctg=24, n_prot=2000, seed=3, batch=500,
@@ -88,7 +89,8 @@ class Workload:
         t0 = time.time()
         mpi, faa = os.path.join(share_dir, "g.mpi"), os.path.join(share_dir, "p.faa")
         self.mpi, self.faa = mpi, faa
-        if rank == 0:
+        cached = os.path.exists(mpi) and os.path.exists(faa)        # (--workload-cache: a previous run on this box left them)
+        if rank == 0 and not cached:
             n_prot = max(10, int(cfg["n_prot"] * scale))
             contigs, prots, names = synth.generate(int(cfg["genome_mb"] * 1e6 * scale), cfg["n_ctg"], n_prot, cfg["seed"], **cfg["gen"])
             self.t_generate = time.time() - t0
@@ -101,13 +103,13 @@ class Workload:
             synth.write_fasta_aa(faa, prots, names)
             self.idx.dump(mpi)                                # for the other ranks and for the reference binary
         barrier()
-        if rank != 0:
+        if rank != 0 or cached:
             self.idx = mpa.Index.restore(mpi)
             names, prots = [], []
             for line in open(faa, "rb"):
                 (names if line.startswith(b">") else prots).append(line[1:].strip().decode() if line.startswith(b">") else line.strip())
             self.t_generate = self.t_index = 0.0
-            self.index_built_on = "rank 0"
+            self.index_built_on = "cache" if cached else "rank 0"
         self.prots, self.names = prots, names
         b = cfg["batch"]
         self.batches = [mpa.Queries(prots[i:i + b], names[i:i + b]) for i in range(0, len(prots), b)]
@@ -215,6 +217,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="(debug) shrink genome and protein set by this factor; the line is then NOT the named config")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the non-DP stages (0 = cores / ranks, at most 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="proteins per mini-batch (0 = the config's own)")
+    ap.add_argument("--workload-cache", default="", help="(debug) keep the generated genome index and proteins in this directory and reuse them if present")
     ap.add_argument("--no-extra", action="store_true", help="N=1, config 3: skip the config-2 and config-5 records")
     ap.add_argument("--debug-shared-gpu", action="store_true", help="(debug) all ranks on cuda:0 with the gloo backend: exercises the N>1 code path on a "
                     "one-GPU box; the line is NOT a scaling measurement")
@@ -260,8 +264,10 @@ def main():
     share_root = os.path.join(base, "mpa_bench_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
 
     def run_config(cid, steps, warmup, with_cpu):
-        cfg = CONFIGS[cid]
-        share = os.path.join(share_root, "c%d" % cid)
+        cfg = dict(CONFIGS[cid])
+        if a.batch > 0 and cid == a.config:
+            cfg["batch"] = a.batch
+        share = os.path.join(a.workload_cache or share_root, "c%d%s" % (cid, "" if a.scale == 1.0 else "_x%g" % a.scale))
         if rank == 0:
             os.makedirs(share, exist_ok=True)
         barrier()
@@ -310,7 +316,7 @@ def main():
         ctx.close()
         wl.idx.close()
         barrier()
-        if rank == 0:
+        if rank == 0 and not a.workload_cache:
             shutil.rmtree(share, ignore_errors=True)
         return rec
 

@@ -93,6 +93,7 @@ struct mpa_ctx_s {
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
 	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey, xg, units;
+	HostPinned h_up, h_down, h_pool;          // staging of a DP round's descriptors (host -> device) and of its results: no pageable copies, one wait
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
@@ -283,7 +284,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
 	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first }) b->release();
-	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred }) h->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -747,6 +748,15 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	};
 	std::sort(ext_ids.begin(), ext_ids.end(), by_class_then_len);
 	std::sort(glob_ids.begin(), glob_ids.end(), by_class_then_len);
+	if (getenv("MPA_CLASS_HIST")) {                         // diagnostics: rows (and calls) per kernel class of this DP round
+		int64_t er[8] = { 0 }, gr[8] = { 0 }, ec[8] = { 0 }, gc[8] = { 0 };
+		for (int32_t id : ext_ids) er[T[id].pad_] += T[id].nl, ec[T[id].pad_]++;
+		for (int32_t id : glob_ids) gr[T[id].pad_] += T[id].nl, gc[T[id].pad_]++;
+		std::string l = "[mpamd] class-hist";
+		for (int k = 0; k < 8; ++k) l += " e" + std::to_string(k) + "=" + std::to_string(ec[k]) + "/" + std::to_string(er[k]);
+		for (int k = 0; k < 8; ++k) l += " g" + std::to_string(k) + "=" + std::to_string(gc[k]) + "/" + std::to_string(gr[k]);
+		fprintf(stderr, "%s\n", l.c_str());
+	}
 
 	int64_t rec_total = 0, prof_total = 0, cig_total = 0, bnd_total = 0;
 	int32_t max_nl = 0;
@@ -825,6 +835,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	for (auto &r : rounds) tb_max = std::max(tb_max, r.tb_words);
 
 	timing_note("  dp: classify/sort/layout", now_ms() - t_begin);
+	double t_mark = now_ms();
+	auto mark = [&](const char *what) { const double t = now_ms(); timing_note(what, t - t_mark); t_mark = t; };   // (MPA_TIMING: wall clock between marks)
 	// ---- device memory
 	const int64_t q_bytes = q->q_off[q->n_seq] - q->q_off[0];
 	int rc;
@@ -834,11 +846,27 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	    (rc = ctx->tb.ensure((size_t)tb_max * 2 + 16)) || (rc = ctx->cig.ensure((size_t)cig_total * 4 + 16)) || (rc = ctx->ncig.ensure(n * 4)) ||
 	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->rowkey.ensure((size_t)(n_wide_groups * 2 * key_stride * 4 + 64))) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->hkey.ensure((size_t)hkey_total * 8 + 16 + (sizeof(GlobWave) + 4) * (huge_ids.size() + 1))) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
 		return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, T.data(), sizeof(DTask) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, chunks.data(), sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, q->seqs + q->q_off[0], q_bytes, hipMemcpyHostToDevice, s));
-	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, ewaves.data(), sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemsetAsync(ctx->rec.p, 0, (size_t)rec_total * 4, s));
+	// Everything the device needs from the host goes through ONE pinned staging buffer (sections below), so that no copy is
+	// staged by the runtime and the host never waits for one: a DP round is enqueued in one go and waited for once.
+	auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t up_tasks = 0, up_chunks = up_tasks + al256(sizeof(DTask) * n), up_q = up_chunks + al256(sizeof(PrepChunk) * chunks.size()),
+	             up_waves = up_q + al256((size_t)q_bytes), up_list = up_waves + al256(sizeof(ExtWave) * ewaves.size()),
+	             up_gw = up_list + al256(4 * glob_ids.size()), up_units = up_gw + al256(sizeof(GlobWave) * (glob_ids.size() + 8)),
+	             up_off = up_units + al256(sizeof(DpUnit) * (4 * ewaves.size() + glob_ids.size() + 64)),
+	             up_ids = up_off + al256(8 * glob_ids.size()), up_end = up_ids + al256(4 * glob_ids.size());
+	if ((rc = ctx->h_up.ensure(up_end + 256))) return rc;
+	char *hup = ctx->h_up.as<char>();
+	memcpy(hup + up_tasks, T.data(), sizeof(DTask) * n);
+	memcpy(hup + up_chunks, chunks.data(), sizeof(PrepChunk) * chunks.size());
+	memcpy(hup + up_q, q->seqs + q->q_off[0], (size_t)q_bytes);
+	memcpy(hup + up_waves, ewaves.data(), sizeof(ExtWave) * ewaves.size());
+	mark("    dp: buffers");
+	HIP_TRY(hipMemcpyAsync(ctx->tasks.p, hup + up_tasks, sizeof(DTask) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->chunks.p, hup + up_chunks, sizeof(PrepChunk) * chunks.size(), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, hup + up_q, q_bytes, hipMemcpyHostToDevice, s));
+	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, hup + up_waves, sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
+	// (k_prep_rows writes every row of every call; only the padding the kernels prefetch behind the last call is cleared)
+	HIP_TRY(hipMemsetAsync((char*)ctx->rec.p + (size_t)(rec_total - (max_nl + 96)) * 4, 0, (size_t)(max_nl + 96) * 4, s));
 	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));
 	// split classes: boundary granules (16 B per row and boundary: 3 boundaries per 1024-column group, 1 per 512-column group),
 	// then the per-group completion counters and the error flag; all zero before the launch (a granule's tag is row + 1)
@@ -882,6 +910,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(ctx->ev[1], s));
+	mark("    dp: uploads + prep enqueued");
 	// ---- fork: every kernel class (extension classes and the traceback classes of the first round) gets its
 	// own stream, so the long single-wave tails of the classes overlap instead of adding up
 	HIP_TRY(hipEventRecord(ctx->fork_ev, s));
@@ -951,12 +980,18 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		}
 		if (cu.empty()) return MPA_OK;
 		std::stable_sort(cu.begin(), cu.end(), [](const Cost &x, const Cost &y) { return x.cost > y.cost; });   // (stable: the workgroups of a split group stay adjacent, in column order)
-		std::vector<DpUnit> units(cu.size());
-		for (size_t k = 0; k < cu.size(); ++k) units[k] = cu[k].u;
+		DpUnit *units = (DpUnit*)(hup + up_units);          // (pinned: the copy below needs no wait)
+		const size_t n_units = cu.size();
+		if (sizeof(DpUnit) * n_units > up_off - up_units) { set_error("internal: more DP units than the staging buffer holds"); return MPA_ERR_HIP; }
+		// MPA_UNIT_PRIO (default 1): the units that bound the round's duration issue ahead of the short ones they share a SIMD with
+		static const bool unit_prio = [] { const char *e = getenv("MPA_UNIT_PRIO"); return e ? atoi(e) != 0 : true; }();
+		for (size_t k = 0; k < cu.size(); ++k) {
+			units[k] = cu[k].u;
+			if (unit_prio) units[k].pad_ = cu[k].cost * 2 >= cu[0].cost ? 3 : cu[k].cost * 4 >= cu[0].cost ? 2 : cu[k].cost * 10 >= cu[0].cost ? 1 : 0;
+		}
 		int rc2;
-		if ((rc2 = ctx->units.ensure(units.size() * sizeof(DpUnit)))) return rc2;
-		HIP_TRY(hipMemcpyAsync(ctx->units.p, units.data(), units.size() * sizeof(DpUnit), hipMemcpyHostToDevice, s));
-		HIP_TRY(hipStreamSynchronize(s));                  // (units is a local)
+		if ((rc2 = ctx->units.ensure(n_units * sizeof(DpUnit)))) return rc2;
+		HIP_TRY(hipMemcpyAsync(ctx->units.p, units, n_units * sizeof(DpUnit), hipMemcpyHostToDevice, s));
 		ea.waves = ctx->waves.as<ExtWave>();
 		wa.waves = ctx->waves.as<ExtWave>();                // absolute descriptor indices: the rowkey slot of group g is g - first wide group
 		wa.rowkey = ctx->rowkey.as<uint32_t>() - (int64_t)ewave_first[3] * 2 * key_stride;
@@ -968,7 +1003,10 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			const char *e = getenv("MPA_ROUND_WG_PER_CU");
 			int w = e ? atoi(e) : 4;
 			w = w < 1 ? 1 : w > 5 ? 5 : w;
-			const size_t pad = ((size_t)160 * 1024 / w) & ~(size_t)255;
+			// one more workgroup than wanted must NOT fit; what is left (160 KB / (w + 1), less the rounding) stays free for the
+			// LDS of the seeding kernels (radix-sort passes, refinement scan) -- dividing the whole LDS by w would starve them
+			size_t pad = (((size_t)160 * 1024 / (w + 1)) + 256) & ~(size_t)255;
+			if (const char *k = getenv("MPA_ROUND_LDS_KB")) pad = (size_t)atoi(k) * 1024;
 			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
 		}();
 		static bool attr_set = false;
@@ -977,7 +1015,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			attr_set = true;
 		}
 		HIP_TRY(hipEventRecord(ev_round0, s));
-		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)units.size()), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
+		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)n_units), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(ev_round1, s));
 		round_launched = true;
@@ -1024,6 +1062,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 
 	// ---- K2 + traceback walk
 	float ms_glob = 0, ms_bt = 0;
+	bool glob_timed = false;
 	std::vector<GlobWave> gwaves;
 	std::vector<int32_t> glist;
 	for (size_t ri = 0; ri < rounds.size(); ++ri) {
@@ -1050,15 +1089,21 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			}
 			cnt[cls] = (int)gwaves.size() - first[cls];
 		}
-		if (!concurrent) {                                                // join everything before the buffers are reused
+		if (!concurrent) {                                                // join everything before the buffers (and their staging) are reused
 			for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
 			HIP_TRY(hipStreamSynchronize(s));
+			float a = 0, b = 0;                                              // (the previous chunk's sweep and walk)
+			(void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
+			(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
+			ms_glob += a, ms_bt += b;
 		}
 		int32_t *d_list = ctx->list.as<int32_t>();
 		GlobWave *d_gw = (GlobWave*)((char*)ctx->list.p + (((size_t)n * 4 + 63) & ~(size_t)63));
-		HIP_TRY(hipMemcpyAsync(d_list, glist.data(), glist.size() * 4, hipMemcpyHostToDevice, s));
-		HIP_TRY(hipMemcpyAsync(d_gw, gwaves.data(), gwaves.size() * sizeof(GlobWave), hipMemcpyHostToDevice, s));
-		HIP_TRY(hipStreamSynchronize(s));                                 // gwaves/glist are reused by the next round
+		memcpy(hup + up_list, glist.data(), glist.size() * 4);
+		memcpy(hup + up_gw, gwaves.data(), gwaves.size() * sizeof(GlobWave));
+		HIP_TRY(hipMemcpyAsync(d_list, hup + up_list, glist.size() * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_gw, hup + up_gw, gwaves.size() * sizeof(GlobWave), hipMemcpyHostToDevice, s));
+		mark("    dp: traceback lists enqueued");
 		ga.tb = ctx->tb.as<uint16_t>();
 		// classes 0,1,2,7 share one launch ("narrow"); every wide class has its own
 		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
@@ -1079,6 +1124,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		if (in_round) {
 			if ((rc = launch_round(first, cnt, &gwaves, d_gw)) != MPA_OK) return rc;
 			ctx->stats.launches_glob++;
+			mark("    dp: units up, round launched");
 		}
 		const int order[5] = { 6, 5, 4, 3, -1 };
 		for (int oi = 0; oi < 5; ++oi) {
@@ -1100,17 +1146,33 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		                   ctx->tb.as<uint16_t>(), ctx->cig.as<uint32_t>(), ctx->ncig.as<int32_t>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(ctx->ev[5], s));
-		HIP_TRY(hipStreamSynchronize(s));
+		glob_timed = true;                                                // (ev[3..5] are read after the next wait)
+	}
+	if (one_launch && !round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
+	mark("    dp: (round without traceback launched)");
+	// ---- join
+	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
+	HIP_TRY(hipEventRecord(ctx->ev[2], s));
+	// results into pinned memory behind the last kernel: extension outputs, traceback scores and CIGAR lengths, hand-off error flag
+	const size_t dn_eo = 0, dn_sc = dn_eo + al256(sizeof(ExtOut) * n), dn_nc = dn_sc + al256(4 * n), dn_err = dn_nc + al256(4 * n), dn_end = dn_err + 256;
+	if ((rc = ctx->h_down.ensure(dn_end))) return rc;
+	char *hdn = ctx->h_down.as<char>();
+	*(int32_t*)(hdn + dn_err) = 0;
+	if (!ext_ids.empty()) HIP_TRY(hipMemcpyAsync(hdn + dn_eo, ctx->extout.p, sizeof(ExtOut) * n, hipMemcpyDeviceToHost, s));
+	if (!glob_ids.empty()) {
+		HIP_TRY(hipMemcpyAsync(hdn + dn_sc, ctx->score.p, n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(hdn + dn_nc, ctx->ncig.p, n * 4, hipMemcpyDeviceToHost, s));
+	}
+	if (n_split) HIP_TRY(hipMemcpyAsync(hdn + dn_err, wa.err, 4, hipMemcpyDeviceToHost, s));
+	mark("    dp: round enqueued");
+	HIP_TRY(hipStreamSynchronize(s));
+	mark("    dp: round (wait)");
+	if (glob_timed) {
 		float a = 0, b = 0;
 		(void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
 		(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
 		ms_glob += a, ms_bt += b;
 	}
-	if (one_launch && !round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
-	// ---- join
-	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
-	HIP_TRY(hipEventRecord(ctx->ev[2], s));
-	HIP_TRY(hipStreamSynchronize(s));
 	float ms_ext_sum = 0;                                                 // sum of the per-launch durations of the extension kernels
 	if (round_launched) {
 		(void)hipEventElapsedTime(&ms_ext_sum, ev_round0, ev_round1);
@@ -1122,41 +1184,34 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		if (l.is_ext) ms_ext_sum += ms;
 	}
 
-	if (n_split) {                                                        // a boundary hand-off that never arrived (bounded spin in the kernel)
-		int32_t kerr = 0;
-		HIP_TRY(hipMemcpy(&kerr, wa.err, 4, hipMemcpyDeviceToHost));
-		if (kerr) { set_error("k_ext_wide_split: a column-block hand-off between workgroups timed out"); return MPA_ERR_HIP; }
+	if (*(const int32_t*)(hdn + dn_err)) {                                // a boundary hand-off that never arrived (bounded spin in the kernel)
+		set_error("k_ext_wide_split: a column-block hand-off between workgroups timed out"); return MPA_ERR_HIP;
 	}
 	timing_note("  dp: upload+kernels (wall)", now_ms() - t_begin);
 	const double t_res = now_ms();
 	// ---- results
-	std::vector<ExtOut> eo;
-	std::vector<int32_t> sc, nc;
-	if (!ext_ids.empty()) { eo.resize(n); HIP_TRY(hipMemcpy(eo.data(), ctx->extout.p, sizeof(ExtOut) * n, hipMemcpyDeviceToHost)); }
+	const ExtOut *eo = (const ExtOut*)(hdn + dn_eo);
+	const int32_t *sc = (const int32_t*)(hdn + dn_sc), *nc = (const int32_t*)(hdn + dn_nc);
 	int64_t pool_n = 0;
-	std::vector<int64_t> dense_off;
-	if (!glob_ids.empty()) {
-		sc.resize(n), nc.resize(n);
-		HIP_TRY(hipMemcpy(sc.data(), ctx->score.p, n * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(nc.data(), ctx->ncig.p, n * 4, hipMemcpyDeviceToHost));
-		dense_off.resize(glob_ids.size());
-		for (size_t g = 0; g < glob_ids.size(); ++g) dense_off[g] = pool_n, pool_n += nc[glob_ids[g]];
-	}
+	int64_t *dense_off = (int64_t*)(hup + up_off);                        // (the staging buffer's earlier sections have been consumed)
+	for (size_t g = 0; g < glob_ids.size(); ++g) dense_off[g] = pool_n, pool_n += nc[glob_ids[g]];
 	uint32_t *pool = (uint32_t*)malloc((size_t)(pool_n > 0 ? pool_n : 1) * 4);
 	if (pool_n > 0) {
 		// the slots were sized for the worst case (nl+al+4 words each): gather the real CIGARs into a dense pool on the
 		// device and copy only that over PCIe
 		int rc2;
-		if ((rc2 = ctx->cigd.ensure((size_t)pool_n * 4)) || (rc2 = ctx->cigoff.ensure(glob_ids.size() * 12 + 64))) { free(pool); return rc2; }
+		if ((rc2 = ctx->cigd.ensure((size_t)pool_n * 4)) || (rc2 = ctx->cigoff.ensure(glob_ids.size() * 12 + 64)) || (rc2 = ctx->h_pool.ensure((size_t)pool_n * 4))) { free(pool); return rc2; }
 		int64_t *d_off = ctx->cigoff.as<int64_t>();
 		int32_t *d_ids = (int32_t*)(d_off + glob_ids.size());
-		HIP_TRY(hipMemcpyAsync(d_off, dense_off.data(), glob_ids.size() * 8, hipMemcpyHostToDevice, s));
-		HIP_TRY(hipMemcpyAsync(d_ids, glob_ids.data(), glob_ids.size() * 4, hipMemcpyHostToDevice, s));
+		memcpy(hup + up_ids, glob_ids.data(), glob_ids.size() * 4);
+		HIP_TRY(hipMemcpyAsync(d_off, dense_off, glob_ids.size() * 8, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_ids, hup + up_ids, glob_ids.size() * 4, hipMemcpyHostToDevice, s));
 		hipLaunchKernelGGL(k_cigar_gather, dim3((unsigned)glob_ids.size()), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_ids, d_off, (int32_t)glob_ids.size(),
 		                   ctx->ncig.as<int32_t>(), ctx->cig.as<uint32_t>(), ctx->cigd.as<uint32_t>());
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(pool, ctx->cigd.p, (size_t)pool_n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(ctx->h_pool.p, ctx->cigd.p, (size_t)pool_n * 4, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
+		memcpy(pool, ctx->h_pool.p, (size_t)pool_n * 4);
 	}
 	{
 		size_t g = 0;
@@ -1199,6 +1254,9 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	(void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); st.ms_prep = ms;
 	st.ms_ext = ms_ext_sum;
 	st.ms_glob = ms_glob, st.ms_backtrack = ms_bt;
+	timing_note("    dp: GPU prep kernels", st.ms_prep);
+	timing_note("    dp: GPU round kernel", ctx->stats.ms_round);
+	timing_note("    dp: GPU walk", ms_bt);
 	{ float w = 0; (void)hipEventElapsedTime(&w, ctx->ev[0], ctx->ev[2]); st.ms_total = w; }   // wall time of the whole batch on the device
 	{
 		mpa_dp_stats_t &t = ctx->total;

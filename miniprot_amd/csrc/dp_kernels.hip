@@ -1337,6 +1337,12 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 	const DpUnit u = units[blockIdx.x];
 	const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const WavePos one{ lds, lane, 0, lane };                      // a one-wave unit: its LDS region is set per case
+	switch (u.pad_) {                                             // issue priority by expected duration (dp_exec.hip, launch_round)
+	case 3: __builtin_amdgcn_s_setprio(3); break;
+	case 2: __builtin_amdgcn_s_setprio(2); break;
+	case 1: __builtin_amdgcn_s_setprio(1); break;
+	default: break;
+	}
 	switch (u.kind) {
 	case U_EXT16: if (wv < u.count) ext_narrow<16>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_EXT32: if (wv < u.count) ext_narrow<32>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;

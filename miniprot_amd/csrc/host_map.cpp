@@ -1315,14 +1315,14 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<Slot> slot((size_t)n_batches);
 	std::mutex mu;
 	std::condition_variable cv;
-	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK;
+	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK, next_seed = 0, next_plan = 0;
 	std::string err;
 	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so four
 	// lanes fit next to the seeding streams; measured at config 3 (20 000 proteins in 10 batches, two planners, two seeders):
 	// 3 lanes 0.91 s, 4 lanes 0.865 s; with one planner and one seeder the host stages bound the stream (1.00 s, any lane count)
 	int n_lanes = 4;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
-	n_lanes = std::max(1, std::min(n_lanes, 4));
+	n_lanes = std::max(1, std::min(n_lanes, 6));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
 	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
@@ -1340,7 +1340,15 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	int n_seed = 2;
 	if (const char *e = getenv("MPA_SEEDERS")) n_seed = atoi(e);
 	n_seed = std::max(1, std::min(n_seed, 3));
-	const int n_seed_ctx = n_plan + n_seed;
+	// Depth of the pipeline.  A seeding context is busy from the start of a batch's seeding to the end of its planning, and a
+	// planned batch waits for a DP lane: seeding of batch k waits for the plan of batch k - n_seed_ctx, the plan of batch k for
+	// the end of the DP of batch k - (lanes + planners).  MPA_SEED_CTX_EXTRA more contexts / MPA_PLAN_AHEAD more planned batches
+	// loosen that coupling; measured at config 3 they change nothing (70.1 vs 70.3 ms per step with 2 / 3), because the stages
+	// share one GPU whose wide, memory-bound seeding kernels are what the stream is bound by -- so the defaults stay at 0.
+	int seed_extra = 0, plan_ahead = 0;
+	if (const char *e = getenv("MPA_SEED_CTX_EXTRA")) seed_extra = std::max(0, std::min(atoi(e), 6));
+	if (const char *e = getenv("MPA_PLAN_AHEAD")) plan_ahead = std::max(0, std::min(atoi(e), 8));
+	const int n_seed_ctx = n_plan + n_seed + seed_extra;
 	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
 	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
@@ -1348,9 +1356,12 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
 	auto seeder_body = [&](int sd) { try {
 		tl_pool_lane = sd == 0 ? 1 : 5 + sd, tl_thread_div = 4;
-		for (int32_t k = sd; k < n_batches; k += n_seed) {
+		for (;;) {
+			int32_t k;
 			{	// its result lives in a seeding context until the batch is planned: wait for the batch that had this context before
 				std::unique_lock<std::mutex> g(mu);
+				if (next_seed >= n_batches) return;
+				k = next_seed++;                                      // (a free seeder takes the next batch in input order)
 				cv.wait(g, [&] { return rc_all != MPA_OK || k < n_seed_ctx || slot[k - n_seed_ctx].begun; });
 				if (rc_all != MPA_OK) return;
 			}
@@ -1367,10 +1378,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
 	auto planner_body = [&](int pl) { try {
 		tl_pool_lane = pl == 0 ? 3 : 3 + pl, tl_thread_div = n_plan;
-		for (int32_t k = pl; k < n_batches; k += n_plan) {
-			{	// stay at most a planner's worth of batches ahead of the ones in their DP rounds
+		for (;;) {
+			int32_t k;
+			{	// stay a bounded number of batches ahead of the ones in their DP rounds (planned batches hold their windows and tasks)
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1); });
+				if (next_plan >= n_batches) return;
+				k = next_plan++;
+				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1 + plan_ahead); });
 				if (rc_all != MPA_OK) return;
 			}
 			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "begin");
@@ -1414,9 +1428,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
 				if (rc_all != MPA_OK) return;
 			}
-			trace(d == 0 ? "dp0" : d == 1 ? "dp1" : d == 2 ? "dp2" : "dp3", k, "begin");
+			static const char *const lane_name[6] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5" };
+			trace(lane_name[d], k, "begin");
 			const int rc = run_dp_rounds(cd, mi, &batches[k], slot[k].b);
-			trace(d == 0 ? "dp0" : d == 1 ? "dp1" : d == 2 ? "dp2" : "dp3", k, "end");
+			trace(lane_name[d], k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].dp_done = true, ++n_dp_done;

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
-CMD="python bench.py --scale 0.1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+CMD="python bench.py --scale 0.1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra --workload-cache /dev/shm/mpa_wl"
 declare -A PASS
 PASS[sq]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 PASS[lds]="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
