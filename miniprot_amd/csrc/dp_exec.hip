@@ -75,6 +75,7 @@ struct SeedBufs {
 	HostPinned h_jobs, h_pos, h_f, h_pred, h_a;
 	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
 	HostPinned h_rhits;
+	DevBuf pf_w, pf_dst, pf_rem, pf_jfirst, pf_qfirst2, pf_err, val64[2];   // pre-sort anchor filter (k_seed_prefilter)
 	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first;                // chain forward pass (k_chain_fwd)
 	HostPinned hc_a, hc_f, hc_pred;
 };
@@ -283,7 +284,8 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
-	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first }) b->release();
+	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first,
+	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1] }) b->release();
 	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
@@ -333,6 +335,92 @@ void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 } // namespace mpa
 
 namespace mpa {
+// dev_prechain_forward() with the pre-sort filter (MPA_SEED_PREFILTER=1).  The caller has uploaded the jobs and qfirst and made
+// sure the per-anchor buffers exist for all n anchors; only the kept anchors (8-16 % at genome scale) are gathered and sorted.
+static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_block, const PreParams &pp, int nb, int qb, int32_t n_query, const int64_t *qfirst,
+                                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin)
+{
+	SeedBufs &B = ctx->seed;
+	hipStream_t s = ctx->seed_stream;
+	const int64_t n = qfirst[n_query];
+	if (n >= (int64_t)1 << 32) { set_error("GPU seeding: more than 2^32 anchors in a batch"); return MPA_ERR_UNSUPPORTED; }
+	// ranges of PF_PART_BLOCKS blocks over the index's block ids [0, n_block); the kernel reports a block past the last range
+	const int32_t n_part = (int32_t)(((uint64_t)n_block + PF_PART_BLOCKS - 1) / PF_PART_BLOCKS);
+	std::vector<int64_t> jfirst((size_t)n_query + 1, 0);
+	for (int64_t j = 0; j < n_jobs; ++j) ++jfirst[(size_t)jobs[j].qid + 1];
+	for (int32_t q = 0; q < n_query; ++q) jfirst[(size_t)q + 1] += jfirst[(size_t)q];
+	if (B.pf_w.ensure((size_t)n * 4) != MPA_OK || B.pf_dst.ensure((size_t)n * 4) != MPA_OK || B.pf_rem.ensure((size_t)n_query * n_part * 4 + 16) != MPA_OK ||
+	    B.pf_jfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_qfirst2.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_err.ensure(16) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(B.pf_jfirst.p, jfirst.data(), ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(B.pf_err.p, 0, 16, s));
+	static bool attr_set = false;
+	if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_seed_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS)); attr_set = true; }
+	HIP_TRY(hipStreamSynchronize(s));                       // (jfirst is a local)
+	hipLaunchKernelGGL(k_seed_prefilter, dim3((unsigned)n_part, (unsigned)n_query), dim3(PF_THREADS), PF_LDS, s, B.jobs.as<SeedJobDev>(), B.pf_jfirst.as<int64_t>(), d->kb,
+	                   n_part, B.pf_w.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_err.as<int32_t>());
+	HIP_TRY(hipGetLastError());
+	size_t scan_bytes = 0;
+	auto keep_it = rocprim::make_transform_iterator(B.pf_w.as<uint32_t>(), KeepBit());
+	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, keep_it, B.pf_dst.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+	if (B.tmp.ensure(scan_bytes + 256) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, keep_it, B.pf_dst.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+	hipLaunchKernelGGL(k_seed_prefilter_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.qfirst.as<int64_t>(), n_query, n, n_part, B.pf_w.as<uint32_t>(),
+	                   B.pf_dst.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_qfirst2.as<int64_t>());
+	HIP_TRY(hipGetLastError());
+	std::vector<int64_t> qfirst2((size_t)n_query + 1, 0);
+	int32_t kerr = 0;
+	HIP_TRY(hipMemcpyAsync(qfirst2.data(), B.pf_qfirst2.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&kerr, B.pf_err.p, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (kerr) { set_error("k_seed_prefilter: a block id past the last range"); return MPA_ERR_HIP; }
+	const int64_t n2 = qfirst2[(size_t)n_query];
+	timing_note("    seed: pre-sort filter (wait)", now_ms() - t_begin);
+	if (n2 == 0) return MPA_OK;
+	for (int k = 0; k < 2; ++k) if (B.val64[k].ensure((size_t)n2 * 8) != MPA_OK) return MPA_ERR_HIP;
+	const unsigned nblk = (unsigned)((n2 + 255) / 256);
+	hipLaunchKernelGGL(k_seed_gather_kept, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, n_part, B.pf_w.as<uint32_t>(),
+	                   B.pf_dst.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.key[0].as<uint64_t>(), B.val64[0].as<uint64_t>());
+	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n2, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	HIP_TRY(hipGetLastError());
+	size_t tmp_bytes = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val64[0].as<uint64_t>(), B.val64[1].as<uint64_t>(),
+	                                  (size_t)n2, 0u, (unsigned)(nb + qb), s));
+	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
+	if (B.tmp.ensure(std::max(tmp_bytes, scan_bytes) + 256) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(rocprim::radix_sort_pairs(B.tmp.p, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val64[0].as<uint64_t>(), B.val64[1].as<uint64_t>(),
+	                                  (size_t)n2, 0u, (unsigned)(nb + qb), s));
+	const uint64_t *key = B.key[1].as<uint64_t>();
+	const uint64_t *val = B.val64[1].as<uint64_t>();
+	hipLaunchKernelGGL(k_prechain_fwd<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
+	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
+	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.pf_qfirst2.as<int64_t>(), n_query, n2, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
+	                   B.cfirst.as<int64_t>());
+	HIP_TRY(hipGetLastError());
+	const double t_issued = now_ms();
+	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const double t_kernels = now_ms();
+	const int64_t m = out.cfirst[n_query];
+	out.m = m;
+	if (m == 0) return MPA_OK;
+	if (B.o_pos.ensure((size_t)m * 4) != MPA_OK || B.o_f.ensure((size_t)m * 4) != MPA_OK || B.o_pred.ensure((size_t)m * 4) != MPA_OK || B.o_a.ensure((size_t)m * 8) != MPA_OK ||
+	    B.h_pos.ensure((size_t)m * 4) != MPA_OK || B.h_f.ensure((size_t)m * 4) != MPA_OK || B.h_pred.ensure((size_t)m * 4) != MPA_OK || B.h_a.ensure((size_t)m * 8) != MPA_OK) return MPA_ERR_HIP;
+	hipLaunchKernelGGL(k_seed_compact<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
+	                   B.pred.as<int32_t>(), B.o_pos.as<int32_t>(), B.o_f.as<int32_t>(), B.o_pred.as<int32_t>(), B.o_a.as<uint64_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(B.h_pos.p, B.o_pos.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
+	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
+	timing_note("    seed: compact + download", now_ms() - t_kernels);
+	return MPA_OK;
+}
+
 // GPU seeding for one mini-batch: anchors -> sort -> forward pass of the pre-chain -> the anchors that have a neighbour.
 // jobs: the kept seeds of all queries (qid ascending, within a query ascending query position, dst = running anchor
 // offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
@@ -394,6 +482,13 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	    B.flag.ensure((size_t)n * 4) != MPA_OK || B.idx.ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(B.qfirst.p, qfirst, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
+	// MPA_SEED_PREFILTER=1: drop the anchors that have no neighbour within one block before they are gathered and sorted
+	// (k_seed_prefilter, seed_exec.hip); the rest of the stage then runs on the kept ones with a 64-bit sort value
+	{
+		const char *e = getenv("MPA_SEED_PREFILTER");
+		if (e && atoi(e) != 0 && pp.max_dblock == 1)
+			return dev_prechain_forward_filtered(ctx, d, mi->n_block, pp, nb, qb, n_query, qfirst, jobs, n_jobs, out, t_begin);
+	}
 	const unsigned nblk = (unsigned)((n + 255) / 256);
 	hipLaunchKernelGGL(k_seed_gather, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, B.key[0].as<uint64_t>(), B.val[0].as<uint32_t>());
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
@@ -409,7 +504,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	                                  (size_t)n, 0u, (unsigned)(nb + qb), s));
 	const uint64_t *key = B.key[1].as<uint64_t>();
 	const uint32_t *val = B.val[1].as<uint32_t>();
-	hipLaunchKernelGGL(k_prechain_fwd, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
+	hipLaunchKernelGGL(k_prechain_fwd<uint32_t>, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
 	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
@@ -425,7 +520,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	if (m == 0) return MPA_OK;
 	if (B.o_pos.ensure((size_t)m * 4) != MPA_OK || B.o_f.ensure((size_t)m * 4) != MPA_OK || B.o_pred.ensure((size_t)m * 4) != MPA_OK || B.o_a.ensure((size_t)m * 8) != MPA_OK ||
 	    B.h_pos.ensure((size_t)m * 4) != MPA_OK || B.h_f.ensure((size_t)m * 4) != MPA_OK || B.h_pred.ensure((size_t)m * 4) != MPA_OK || B.h_a.ensure((size_t)m * 8) != MPA_OK) return MPA_ERR_HIP;
-	hipLaunchKernelGGL(k_seed_compact, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
+	hipLaunchKernelGGL(k_seed_compact<uint32_t>, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
 	                   B.pred.as<int32_t>(), B.o_pos.as<int32_t>(), B.o_f.as<int32_t>(), B.o_pred.as<int32_t>(), B.o_a.as<uint64_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(B.h_pos.p, B.o_pos.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));

@@ -70,8 +70,16 @@ __device__ __forceinline__ int32_t d_link_score(uint64_t kcur, uint32_t qcur, ui
 	return sc;
 }
 
+// The value that travels with an anchor through the sort: its query position (uint32_t), or -- when the anchors were filtered
+// before the sort (k_seed_prefilter) -- query position | the number of the query's dropped anchors that sort below it << 32.
+__device__ __forceinline__ uint32_t qpos_of(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t qpos_of(uint64_t v) { return (uint32_t)v; }
+__device__ __forceinline__ int32_t dropped_below(uint32_t) { return 0; }
+__device__ __forceinline__ int32_t dropped_below(uint64_t v) { return (int32_t)(v >> 32); }
+
 // one thread per anchor; the thread of a run's first anchor walks the run (mp_chain's forward loop, chain.c:181-209)
-__global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, PreParams p,
+template<typename V>
+__global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const V *val, int64_t n, int nb, const int64_t *qfirst, PreParams p,
                                                       int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)
 {
 	MPA_SHORT_KERNEL();
@@ -90,19 +98,19 @@ __global__ __launch_bounds__(256) void k_prechain_fwd(const uint64_t *key, const
 	int32_t hot_f = 0;
 	for (int64_t i = s; i < e; ++i) {
 		const uint64_t ki = key[i];
-		const uint32_t qi = val[i];
+		const uint32_t qi = qpos_of(val[i]);
 		const int32_t me = (int32_t)(i - q0);
 		int64_t best_j = -1;
 		int32_t best = p.kmer, skipped = 0;
 		while (win < i && (int64_t)((ki - key[win]) << p.bbit) > p.max_dist_x) ++win;
 		if (hot >= 0 && hot >= win) {
-			const int32_t l = d_link_score(ki, qi, key[hot], val[hot], p);
+			const int32_t l = d_link_score(ki, qi, key[hot], qpos_of(val[hot]), p);
 			const int32_t sc = hot_f + l;                                  // (INT32_MIN + hot_f stays far below kmer, as on the host)
 			if (sc > best) best = sc, best_j = hot;
 		} else hot_f = 0, hot = -1;
 		if (i - win > p.max_iter) win = i - p.max_iter;
 		for (int64_t j = i - 1; j >= win; --j) {
-			int32_t sc = d_link_score(ki, qi, key[j], val[j], p);
+			int32_t sc = d_link_score(ki, qi, key[j], qpos_of(val[j]), p);
 			if (sc == D_INCOMPAT) continue;
 			sc += f[j];
 			if (sc > best) {
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int3
 	if (i < n) f[i] = kmer, pred[i] = -1, mark[i] = -1, flag[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const uint32_t *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
+template<typename V>
+__global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const V *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
                                                       const uint32_t *idx, const int32_t *f, const int32_t *pred, int32_t *o_pos, int32_t *o_f, int32_t *o_pred, uint64_t *o_a)
 {
 	MPA_SHORT_KERNEL();
@@ -232,11 +241,11 @@ __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const
 	const uint64_t k = key[i];
 	const uint32_t d = idx[i];
 	const int64_t q0 = qfirst[k >> nb];
-	o_pos[d] = (int32_t)(i - q0);
+	o_pos[d] = (int32_t)(i - q0) + dropped_below(val[i]);            // position in the query's FULL sorted anchor list
 	// the predecessor as an index into the query's part of the compacted view (a chained-onto anchor is always in the view)
 	const int32_t pr = pred[i];
 	o_f[d] = f[i], o_pred[d] = pr < 0 ? -1 : (int32_t)(idx[q0 + pr] - idx[q0]);
-	o_a[d] = (k & ((1ULL << nb) - 1)) << 32 | val[i];
+	o_a[d] = (k & ((1ULL << nb) - 1)) << 32 | qpos_of(val[i]);
 }
 
 // compact offset of every query's first anchor (+ the total)
@@ -247,6 +256,148 @@ __global__ __launch_bounds__(256) void k_seed_bounds(const int64_t *qfirst, int3
 	if (q > n_query) return;
 	const int64_t i = qfirst[q];
 	cfirst[q] = i < n ? (int64_t)idx[i] : (n > 0 ? (int64_t)idx[n - 1] + flag[n - 1] : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-sort anchor filter (MPA_SEED_PREFILTER=1; off by default until it has been measured at scale).
+//
+// The pre-chain (map.c:186-192: mp_chain with max_dist_x = one block) can only link anchors of a query that lie in the same
+// or in adjacent 256-bp blocks, and an anchor that is neither linked nor linked onto never reaches the host.  84-92 % of the
+// anchors at genome scale have no such neighbour, yet all of them are gathered, sorted, walked and compacted.  Whether a block
+// has a neighbour needs no order: one workgroup per (query, range of 131 008 blocks) takes a two-bit census of the range in LDS
+// (bit 0: a hit in this block, bit 1: a second hit) from the query's occurrence lists -- each of which is ascending, so the
+// part of a list inside the range is two binary searches away -- and then decides, block by block,
+//     keep = hit && (second hit || hit in block - 1 || hit in block + 1)
+// exactly (one halo block on either side of the range).  Kept anchors go on to the sort; a dropped anchor is alone in its
+// block, so the number of dropped anchors that sort below a kept one is the number of dropped BLOCKS below its block: a prefix
+// popcount over the census, carried along as the high half of a 64-bit sort value, from which k_seed_compact restores the
+// anchor's position in the query's full sorted list (the host's sparse replay of the reference's sort needs it, host_core.cpp).
+// ------------------------------------------------------------------------------------------------
+#define PF_THREADS 256                                    /* = PF_WORDS / 32: one group of 32 words per thread in the prefix scan */
+#define PF_WORDS 8192                                     /* 16 two-bit fields per word: 131 072 fields = 32 KB of LDS */
+#define PF_PART_BLOCKS (PF_WORDS * 16 - 64)               /* blocks a workgroup owns: field 0 and field PF_PART_BLOCKS + 1 are halo */
+#define PF_LDS ((size_t)PF_WORDS * 4 + (size_t)PF_THREADS * 4 + 64 * 4)
+struct KeepBit { __host__ __device__ uint32_t operator()(uint32_t x) const { return x >> 31; } };
+
+__device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, uint64_t x)   // first index with a[i] >= x
+{
+	int32_t lo = 0, hi = n;
+	while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((uint64_t)a[mid] < x) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+// w[gather position of an anchor] = 1 << 31 | (dropped blocks of its range below its block) for a kept anchor, 0 for a dropped one;
+// rem[query * n_part + range] = dropped anchors of the range
+__global__ __launch_bounds__(PF_THREADS) void k_seed_prefilter(const SeedJobDev *jobs, const int64_t *jfirst, const uint32_t *kb, int32_t n_part,
+                                                               uint32_t *w, uint32_t *rem, int32_t *err)
+{
+	extern __shared__ uint32_t pf_lds[];
+	uint32_t *bm = pf_lds, *tsum = pf_lds + PF_WORDS, *wsum = tsum + PF_THREADS;
+	const int32_t part = blockIdx.x, q = blockIdx.y, t = threadIdx.x;
+	const int64_t base = (int64_t)part * PF_PART_BLOCKS;             // first block this workgroup owns
+	const int64_t j0 = jfirst[q], j1 = jfirst[q + 1];
+#pragma unroll
+	for (int k = 0; k < PF_WORDS / PF_THREADS; ++k) bm[t + PF_THREADS * k] = 0;
+	__syncthreads();
+	// ---- census of [base - 1, base + PF_PART_BLOCKS]
+	int32_t mine = 0;
+	for (int64_t j = j0 + t; j < j1; j += PF_THREADS) {
+		const SeedJobDev s = jobs[j];
+		const uint32_t *list = kb + s.kb_off;
+		const int32_t lo = d_lower_bound(list, s.cnt, (uint64_t)(base > 0 ? base - 1 : 0));
+		const int32_t hi = d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS + 1);
+		for (int32_t k = lo; k < hi; ++k) {
+			const uint32_t fi = (uint32_t)((int64_t)list[k] - base + 1);
+			const uint32_t sh = (fi & 15u) * 2u;
+			const uint32_t old = atomicOr(&bm[fi >> 4], 1u << sh);
+			if ((old >> sh) & 1u) atomicOr(&bm[fi >> 4], 2u << sh);
+		}
+		mine += hi - lo;
+		if (part == n_part - 1 && d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS) < s.cnt) *err = 1;   // a block past the last range: n_part is wrong
+	}
+	if (__syncthreads_or(mine > 0) == 0) { if (t == 0) rem[(int64_t)q * n_part + part] = 0; return; }
+	// ---- fields: bit 0 stays "hit", bit 1 becomes "dropped" (neighbours only ever read bit 0, which does not change)
+#pragma unroll 4
+	for (int k = 0; k < PF_WORDS / PF_THREADS; ++k) {
+		const int idx = k * PF_THREADS + t;
+		const uint32_t c = bm[idx], l = idx > 0 ? bm[idx - 1] : 0u, r = idx + 1 < PF_WORDS ? bm[idx + 1] : 0u;
+		const uint32_t S = c & 0x55555555u, M = (c >> 1) & 0x55555555u;
+		const uint32_t L = (S << 2) | ((l >> 30) & 1u), R = (S >> 2) | ((r & 1u) << 30);
+		uint32_t rm = S & ~(M | L | R);
+		if (idx == 0) rm &= ~1u;                                            // the halo fields belong to the neighbouring ranges
+		if (idx == (PF_PART_BLOCKS + 1) >> 4) rm &= ~(1u << (((PF_PART_BLOCKS + 1) & 15) * 2));
+		bm[idx] = S | (rm << 1);
+		uint32_t cnt = (uint32_t)__popc(rm);                                // dropped blocks of this group of 32 words
+#pragma unroll
+		for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+		if ((t & 31) == 0) tsum[idx >> 5] = cnt;
+	}
+	__syncthreads();
+	{	// exclusive scan of the group counts (one per thread)
+		const uint32_t v = tsum[t];
+		uint32_t inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if ((t & 63) >= off) inc += o; }
+		if ((t & 63) == 63) wsum[t >> 6] = inc;
+		__syncthreads();
+		uint32_t before = 0;
+		for (int k = 0; k < (t >> 6); ++k) before += wsum[k];
+		tsum[t] = before + inc - v;
+		if (t == PF_THREADS - 1) rem[(int64_t)q * n_part + part] = before + inc;
+	}
+	__syncthreads();
+	// ---- verdicts of the anchors this workgroup owns: blocks [base, base + PF_PART_BLOCKS)
+	for (int64_t j = j0 + t; j < j1; j += PF_THREADS) {
+		const SeedJobDev s = jobs[j];
+		const uint32_t *list = kb + s.kb_off;
+		const int32_t lo = d_lower_bound(list, s.cnt, (uint64_t)base);
+		const int32_t hi = d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS);
+		for (int32_t k = lo; k < hi; ++k) {
+			const uint32_t fi = (uint32_t)((int64_t)list[k] - base + 1);
+			const uint32_t word = fi >> 4, sh = (fi & 15u) * 2u;
+			const uint32_t c = bm[word];
+			uint32_t out = 0;
+			if (!((c >> (sh + 1)) & 1u)) {
+				uint32_t below = tsum[word >> 5];
+				for (uint32_t x = word & ~31u; x < word; ++x) below += (uint32_t)__popc(bm[x] & 0xAAAAAAAAu);
+				below += (uint32_t)__popc(c & 0xAAAAAAAAu & ((1u << sh) - 1u));
+				out = 0x80000000u | below;
+			}
+			w[s.dst + k] = out;
+		}
+	}
+}
+
+// per query: exclusive prefix of its ranges' dropped counts; first kept anchor of every query (+ the total)
+__global__ __launch_bounds__(256) void k_seed_prefilter_bounds(const int64_t *qfirst, int32_t n_query, int64_t n, int32_t n_part, const uint32_t *w, const uint32_t *dst2,
+                                                              uint32_t *rem, int64_t *qfirst2)
+{
+	const int32_t q = blockIdx.x * 256 + threadIdx.x;
+	if (q > n_query) return;
+	const int64_t i = qfirst[q];
+	qfirst2[q] = i < n ? (int64_t)dst2[i] : (n > 0 ? (int64_t)dst2[n - 1] + (w[n - 1] >> 31) : 0);
+	if (q == n_query) return;
+	uint32_t acc = 0;
+	for (int32_t k = 0; k < n_part; ++k) { const uint32_t v = rem[(int64_t)q * n_part + k]; rem[(int64_t)q * n_part + k] = acc; acc += v; }
+}
+
+// the kept anchors, in gather order: key = query << nb | block, value = dropped anchors of the query below it << 32 | query position
+__global__ __launch_bounds__(256) void k_seed_gather_kept(const SeedJobDev *jobs, int32_t n_jobs, const uint32_t *kb, int nb, int32_t n_part, const uint32_t *w,
+                                                          const uint32_t *dst2, const uint32_t *rem, uint64_t *key, uint64_t *val)
+{
+	MPA_SHORT_KERNEL();
+	const int32_t j = blockIdx.x;
+	if (j >= n_jobs) return;
+	const SeedJobDev s = jobs[j];
+	const uint64_t hi = (uint64_t)s.qid << nb;
+	for (int32_t k = threadIdx.x; k < s.cnt; k += 256) {
+		const uint32_t ww = w[s.dst + k];
+		if (!(ww >> 31)) continue;
+		const uint32_t b = kb[s.kb_off + k];
+		const uint32_t d = dst2[s.dst + k];
+		key[d] = hi | b;
+		val[d] = (uint64_t)(rem[(int64_t)s.qid * n_part + (int32_t)(b / PF_PART_BLOCKS)] + (ww & 0x7fffffffu)) << 32 | (uint32_t)s.qpos;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

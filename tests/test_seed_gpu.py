@@ -25,8 +25,11 @@ def survivors(ctx, idx, mo, q, threads=4):
     return off, a
 
 
+@pytest.mark.parametrize("prefilter", ["0", "1"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_device_seeding_equals_host_seeding(seed):
+def test_device_seeding_equals_host_seeding(seed, prefilter, monkeypatch):
+    # prefilter = "1": anchors without a neighbour within one block are dropped before the sort (k_seed_prefilter)
+    monkeypatch.setenv("MPA_SEED_PREFILTER", prefilter)
     rng = np.random.default_rng(seed)
     contigs, prots, names, planted = gen_synth.generate(3000000, 2, 40, 20 + seed, return_planted=True)
     # tandem copies: re-plant the locus of a few genes several times back to back, on both strands of contig 0
@@ -56,6 +59,41 @@ def test_device_seeding_equals_host_seeding(seed):
         assert np.array_equal(off_h, off_d)
         assert np.array_equal(a_h, a_d)
         assert off_h[-1] > 0
+    idx.close()
+    ctx.close()
+
+
+def test_prefilter_across_block_ranges(monkeypatch):
+    """k_seed_prefilter splits a query's blocks into ranges of 131 008 blocks (33.5 Mbp per strand): a genome with nine
+    ranges, and a gene planted right across the fourth range boundary, so that kept anchors need the halo block of the
+    neighbouring range and the dropped-anchor counts of lower ranges (host side of this test checked on CPU: query 0 keeps
+    anchors in the three blocks below and the two blocks above the boundary)."""
+    codon = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTG", "M": "ATG",
+             "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    contigs, prots, names = gen_synth.generate(150000000, 1, 30, 77)
+    g = contigs[0]
+    bblock = 4 * 131008
+    boundary = bblock * 256
+    p = bytes(prots[0]).decode()                             # the coding sequence of protein 0, back-translated, across the boundary
+    nt = np.array([code[c] for a in p for c in codon.get(a, "GCT")], np.uint8)
+    g[boundary - 600:boundary - 600 + len(nt)] = nt
+    idx = mpa.Index.from_nt4(contigs, ["chr1"])
+    ctx = mpa.Context(0)
+    assert idx.build_kmers(4, ctx) == "gpu"
+    idx.to_device(ctx)
+    q = mpa.Queries([bytes(p) for p in prots])
+    mo = mpa.default_mapopt()
+    mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+    off_h, a_h = survivors(None, idx, mo, q, threads=16)
+    for prefilter in ("0", "1"):
+        monkeypatch.setenv("MPA_SEED_PREFILTER", prefilter)
+        off_d, a_d = survivors(ctx, idx, mo, q, threads=16)
+        assert np.array_equal(off_h, off_d), prefilter
+        assert np.array_equal(a_h, a_d), prefilter
+    # the planted copies are really there: anchors of query 0 in the blocks either side of the boundary
+    blocks = (a_h[off_h[0]:off_h[1]] >> 32).astype(np.int64)
+    assert ((blocks >= bblock - 4) & (blocks < bblock)).any() and ((blocks >= bblock) & (blocks < bblock + 6)).any()
     idx.close()
     ctx.close()
 
