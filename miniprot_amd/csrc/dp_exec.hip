@@ -76,6 +76,8 @@ struct SeedBufs {
 	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
 	HostPinned h_rhits;
 	DevBuf pf_w, pf_dst, pf_rem, pf_jfirst, pf_qfirst2, pf_err, val64[2];   // pre-sort anchor filter (k_seed_prefilter)
+	DevBuf s_meta, s_cur, s_cur2, s_kept, s_base, s_out, s_flag, dkey;      // k_seed_sift: segments + per-query tables, list cursors, per-segment results, dense keys
+	HostPinned h_meta, h_back;                                             // ... their staging (up) and qfirst2 / flags / cfirst (down)
 	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first;                // chain forward pass (k_chain_fwd)
 	HostPinned hc_a, hc_f, hc_pred;
 };
@@ -285,8 +287,9 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
 	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first,
-	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1] }) b->release();
-	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
+	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1],
+	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey }) b->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -421,6 +424,124 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	return MPA_OK;
 }
 
+// MPA_SEED_MODE: "sift" (default) = k_seed_sift, per-query merge + LDS sort + isolation filter; "census" = k_seed_prefilter, then
+// a global radix sort of the kept anchors; "sort" = gather and radix-sort every anchor (round 1).  MPA_SEED_PREFILTER=0/1 is the
+// older spelling of sort/census.
+static int seed_mode()
+{
+	if (const char *e = getenv("MPA_SEED_MODE")) return !strcmp(e, "sort") ? 0 : !strcmp(e, "census") ? 1 : 2;
+	if (const char *e = getenv("MPA_SEED_PREFILTER")) return atoi(e) != 0 ? 1 : 0;
+	return 2;
+}
+
+// dev_prechain_forward() with k_seed_sift (the default).  The caller has uploaded the jobs.  Per-anchor memory: 16 bytes of
+// staging; everything behind the sift is sized by the kept anchors.  The result arrays are written by k_seed_compact straight
+// into pinned host memory (no copy kernels, no second pass over HBM).
+static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_block, const PreParams &pp, int nb, int32_t n_query, const int64_t *qfirst,
+                                     const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin)
+{
+	SeedBufs &B = ctx->seed;
+	hipStream_t s = ctx->seed_stream;
+	const int64_t n = qfirst[n_query];
+	if (n_block >= 0x7fffffffu) { set_error("GPU seeding: more than 2^31 blocks"); return MPA_ERR_UNSUPPORTED; }
+	// ---- segments: a query's block space in pieces of ~seg_target anchors (evenly, the kernel adapts inside a segment)
+	const int64_t seg_target = [] { const char *e = getenv("MPA_SIFT_SEG"); const int64_t v = e ? atoll(e) : 49152; return v < 256 ? (int64_t)256 : v; }();   // (read per call: the tests flip it)
+	static thread_local std::vector<SiftSeg> segs;
+	static thread_local std::vector<int64_t> jfirst;
+	static thread_local std::vector<int32_t> qseg;
+	segs.clear();
+	jfirst.assign((size_t)n_query + 1, 0), qseg.assign((size_t)n_query + 1, 0);
+	for (int64_t j = 0; j < n_jobs; ++j) ++jfirst[(size_t)jobs[j].qid + 1];
+	for (int32_t q = 0; q < n_query; ++q) jfirst[(size_t)q + 1] += jfirst[(size_t)q];
+	for (int32_t q = 0; q < n_query; ++q) {
+		const int64_t na = qfirst[q + 1] - qfirst[q];
+		qseg[(size_t)q] = (int32_t)segs.size();
+		if (na == 0) continue;
+		if (na >= (int64_t)1 << 31) { set_error("GPU seeding: a query with more than 2^31 anchors"); return MPA_ERR_UNSUPPORTED; }
+		if (jfirst[(size_t)q + 1] - jfirst[(size_t)q] > (1 << 20)) { set_error("GPU seeding: a query with more than 2^20 seeds"); return MPA_ERR_UNSUPPORTED; }
+		const int64_t ns = std::min<int64_t>((na + seg_target - 1) / seg_target, n_block);
+		for (int64_t k = 0; k < ns; ++k) {
+			const uint32_t lo = (uint32_t)((uint64_t)n_block * (uint64_t)k / (uint64_t)ns), hi = (uint32_t)((uint64_t)n_block * (uint64_t)(k + 1) / (uint64_t)ns);
+			if (hi > lo) segs.push_back(SiftSeg{ q, lo, hi, 0 });
+		}
+	}
+	qseg[(size_t)n_query] = (int32_t)segs.size();
+	const int32_t n_seg = (int32_t)segs.size();
+	if (n_seg == 0) return MPA_OK;
+	// one pinned block up: qfirst | jfirst | segments | qseg
+	const size_t meta_q = ((size_t)n_query + 1) * 8, seg_bytes = (size_t)n_seg * sizeof(SiftSeg);
+	const size_t off_jf = meta_q, off_seg = 2 * meta_q, off_qs = off_seg + seg_bytes, meta_bytes = off_qs + ((size_t)n_query + 1) * 4;
+	int rc;
+	if ((rc = B.h_meta.ensure(meta_bytes))) return rc;
+	char *hm = B.h_meta.as<char>();
+	memcpy(hm, qfirst, meta_q), memcpy(hm + off_jf, jfirst.data(), meta_q), memcpy(hm + off_seg, segs.data(), seg_bytes), memcpy(hm + off_qs, qseg.data(), ((size_t)n_query + 1) * 4);
+	if ((rc = B.s_meta.ensure(meta_bytes)) || (rc = B.s_cur.ensure((size_t)n_jobs * 4)) || (rc = B.s_cur2.ensure((size_t)n_jobs * 4)) ||
+	    (rc = B.s_kept.ensure((size_t)n_seg * 4)) || (rc = B.s_base.ensure((size_t)n_seg * 8)) || (rc = B.s_out.ensure(((size_t)n_seg + 1) * 8)) ||
+	    (rc = B.s_flag.ensure((size_t)n_query * 4 + 16)) || (rc = B.pf_qfirst2.ensure(meta_q)) || (rc = B.cfirst.ensure(meta_q)) ||
+	    (rc = B.key[0].ensure((size_t)n * 8)) || (rc = B.key[1].ensure((size_t)n * 8)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;
+	HIP_TRY(hipMemcpyAsync(B.s_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(B.s_flag.p, 0, (size_t)n_query * 4 + 16, s));
+	const char *dm = B.s_meta.as<char>();
+	const int64_t *d_qfirst = (const int64_t*)dm, *d_jfirst = (const int64_t*)(dm + off_jf);
+	const SiftSeg *d_segs = (const SiftSeg*)(dm + off_seg);
+	const int32_t *d_qseg = (const int32_t*)(dm + off_qs);
+	hipLaunchKernelGGL(k_seed_sift, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d->kb, n_block, nb,
+	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
+	                   B.s_flag.as<int32_t>());
+	hipLaunchKernelGGL(k_sift_offsets, dim3(1), dim3(256), 0, s, d_segs, n_seg, n_query, d_qseg, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_out.as<int64_t>(),
+	                   B.pf_qfirst2.as<int64_t>());
+	HIP_TRY(hipGetLastError());
+	int64_t *h_qfirst2 = B.h_back.as<int64_t>(), *h_cfirst = h_qfirst2 + (n_query + 1);
+	int32_t *h_flag = (int32_t*)(h_cfirst + (n_query + 1));
+	HIP_TRY(hipMemcpyAsync(h_qfirst2, B.pf_qfirst2.p, meta_q, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_flag, B.s_flag.p, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const double t_sift = now_ms();
+	timing_note("    seed: segments + sift (wait)", t_sift - t_begin);
+	int32_t n_declined = 0;
+	for (int32_t q = 0; q < n_query; ++q) n_declined += h_flag[q] != 0;
+	if (n_declined) {
+		out.on_host.assign((size_t)n_query, 0);
+		for (int32_t q = 0; q < n_query; ++q) out.on_host[(size_t)q] = h_flag[q] != 0;
+	}
+	const int64_t n2 = h_qfirst2[n_query];
+	if (n2 == 0) return MPA_OK;
+	if ((rc = B.dkey.ensure((size_t)n2 * 8)) || (rc = B.val64[0].ensure((size_t)n2 * 8)) || (rc = B.f.ensure((size_t)n2 * 4)) || (rc = B.pred.ensure((size_t)n2 * 4)) ||
+	    (rc = B.mark.ensure((size_t)n2 * 4)) || (rc = B.flag.ensure((size_t)n2 * 4)) || (rc = B.idx.ensure((size_t)n2 * 4))) return rc;
+	const unsigned nblk = (unsigned)((n2 + 255) / 256);
+	const uint64_t *key = B.dkey.as<uint64_t>();
+	const uint64_t *val = B.val64[0].as<uint64_t>();
+	hipLaunchKernelGGL(k_sift_copy, dim3((unsigned)n_seg), dim3(256), 0, s, d_segs, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(), B.s_out.as<int64_t>(),
+	                   B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.dkey.as<uint64_t>(), B.val64[0].as<uint64_t>());
+	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n2, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	hipLaunchKernelGGL(k_prechain_fwd<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
+	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
+	HIP_TRY(hipGetLastError());
+	size_t scan_bytes = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
+	if ((rc = B.tmp.ensure(scan_bytes + 256))) return rc;
+	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
+	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.pf_qfirst2.as<int64_t>(), n_query, n2, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
+	                   B.cfirst.as<int64_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(h_cfirst, B.cfirst.p, meta_q, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const double t_kernels = now_ms();
+	memcpy(out.cfirst.data(), h_cfirst, meta_q);
+	const int64_t m = out.cfirst[n_query];
+	out.m = m;
+	timing_note("    seed: copy + pre-chain + scan (wait)", t_kernels - t_sift);
+	if (m == 0) return MPA_OK;
+	if ((rc = B.h_pos.ensure((size_t)m * 4)) || (rc = B.h_f.ensure((size_t)m * 4)) || (rc = B.h_pred.ensure((size_t)m * 4)) || (rc = B.h_a.ensure((size_t)m * 8))) return rc;
+	hipLaunchKernelGGL((k_seed_compact<uint64_t, true>), dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(),
+	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), B.h_pos.as<int32_t>(), B.h_f.as<int32_t>(), B.h_pred.as<int32_t>(), B.h_a.as<uint64_t>());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
+	timing_note("    seed: compact into pinned memory", now_ms() - t_kernels);
+	return MPA_OK;
+}
+
 // GPU seeding for one mini-batch: anchors -> sort -> forward pass of the pre-chain -> the anchors that have a neighbour.
 // jobs: the kept seeds of all queries (qid ascending, within a query ascending query position, dst = running anchor
 // offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
@@ -430,7 +551,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 {
 	const int64_t n = qfirst[n_query];
 	out.cfirst.assign((size_t)n_query + 1, 0);
-	out.pos = out.f = out.pred = nullptr, out.a = nullptr, out.m = 0;
+	out.pos = out.f = out.pred = nullptr, out.a = nullptr, out.m = 0, out.on_host.clear();
 	if (n == 0 || n_jobs == 0) return MPA_OK;
 	if (pre.bbit <= 0) { set_error("GPU pre-chain needs block anchors (bbit > 0)"); return MPA_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -455,12 +576,14 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	while ((1ULL << nb) < (uint64_t)mi->n_block + (uint64_t)pp.max_dblock + 2) ++nb;
 	while ((1LL << qb) < n_query) ++qb;
 	if (nb + qb > 64) { set_error("GPU pre-chain: too many queries x blocks for a 64-bit key"); return MPA_ERR_UNSUPPORTED; }
-	{	// the working set is ~60 bytes per anchor; a batch that does not fit stays on the host (the caller falls back)
+	const int mode = pp.max_dblock == 1 ? seed_mode() : 0;     // (the filters assume the pre-chain's one-block reach)
+	{	// the working set is ~60 bytes per anchor (sift: 16 of staging, the rest sized by the kept ones); a batch that does not fit
+		// stays on the host (the caller falls back)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			const SeedBufs &Bc = ctx->seed;
 			const size_t have = Bc.key[0].cap + Bc.key[1].cap + Bc.val[0].cap + Bc.val[1].cap + Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap;
-			if ((size_t)n * 60 > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
+			if ((size_t)n * (mode == 2 ? 28 : 60) > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
 		}
 	}
 	SeedBufs &B = ctx->seed;
@@ -475,20 +598,18 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	if (B.h_jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
 	SeedJobDev *hj = B.h_jobs.as<SeedJobDev>();
 	for (int64_t i = 0; i < n_jobs; ++i) hj[i] = SeedJobDev{ jobs[i].kb_off, jobs[i].dst, jobs[i].cnt, jobs[i].qpos, jobs[i].qid, 0 };
-	if (B.jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK || B.qfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK ||
-	    B.cfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK) return MPA_ERR_HIP;
+	if (B.jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
+	// the default: merge the occurrence lists per query in block order, keep what has a neighbour (k_seed_sift, seed_exec.hip)
+	if (mode == 2) return dev_prechain_forward_sift(ctx, d, mi->n_block, pp, nb, n_query, qfirst, jobs, n_jobs, out, t_begin);
+	if (B.qfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.cfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK) return MPA_ERR_HIP;
 	for (int k = 0; k < 2; ++k) if (B.key[k].ensure((size_t)n * 8) != MPA_OK || B.val[k].ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
 	if (B.f.ensure((size_t)n * 4) != MPA_OK || B.pred.ensure((size_t)n * 4) != MPA_OK || B.mark.ensure((size_t)n * 4) != MPA_OK ||
 	    B.flag.ensure((size_t)n * 4) != MPA_OK || B.idx.ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(B.qfirst.p, qfirst, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
-	// MPA_SEED_PREFILTER=1: drop the anchors that have no neighbour within one block before they are gathered and sorted
+	// MPA_SEED_MODE=census: drop the anchors that have no neighbour within one block before they are gathered and sorted
 	// (k_seed_prefilter, seed_exec.hip); the rest of the stage then runs on the kept ones with a 64-bit sort value
-	{
-		const char *e = getenv("MPA_SEED_PREFILTER");
-		if (e && atoi(e) != 0 && pp.max_dblock == 1)
-			return dev_prechain_forward_filtered(ctx, d, mi->n_block, pp, nb, qb, n_query, qfirst, jobs, n_jobs, out, t_begin);
-	}
+	if (mode == 1) return dev_prechain_forward_filtered(ctx, d, mi->n_block, pp, nb, qb, n_query, qfirst, jobs, n_jobs, out, t_begin);
 	const unsigned nblk = (unsigned)((n + 255) / 256);
 	hipLaunchKernelGGL(k_seed_gather, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, B.key[0].as<uint64_t>(), B.val[0].as<uint32_t>());
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());

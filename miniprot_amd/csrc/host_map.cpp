@@ -546,6 +546,7 @@ static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint6
 // (2, GPU) the same from the sparse result of dev_prechain_forward(): extraction only
 static void stage_anchors_from_device(mpa_batch_s *b, QueryState &qs, const PrechainSparse &ps, std::vector<uint64_t> &a)
 {
+	if (!ps.on_host.empty() && ps.on_host[(size_t)qs.qid]) { stage_anchors_host(b, qs, a); return; }   // (the device declined this query: degenerate input)
 	AccTimer tm(2);
 	const int64_t c0 = ps.cfirst[qs.qid], m = ps.cfirst[qs.qid + 1] - c0;
 	a.clear();

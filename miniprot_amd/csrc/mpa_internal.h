@@ -83,6 +83,7 @@ struct PrechainSparse {              // result for a mini-batch: the chained anc
 	int64_t m = 0;
 	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call; pred = index into the query's part of the view, -1 for none
 	const uint64_t *a = nullptr;
+	std::vector<uint8_t> on_host;    // [n_query] 1 = the device declined this query (k_seed_sift: too many anchors in one block): seed it on the host; empty = none
 };
 struct RefineWindow { int64_t as; int32_t qid, vid, len; };    // strand-local window [as, as + len) on vid, refined for query qid
 struct RefineHits { std::vector<int64_t> first; std::vector<uint64_t> hits; };

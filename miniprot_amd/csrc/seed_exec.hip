@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int3
 	if (i < n) f[i] = kmer, pred[i] = -1, mark[i] = -1, flag[i] = 0;
 }
 
-template<typename V>
+// ABS_POS: the high half of the value IS the anchor's rank in the query's full sorted list (k_seed_sift) rather than the
+// number of dropped anchors below it (k_seed_prefilter).  The outputs may be pinned host memory: every element is written once.
+template<typename V, bool ABS_POS = false>
 __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const V *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
                                                       const uint32_t *idx, const int32_t *f, const int32_t *pred, int32_t *o_pos, int32_t *o_f, int32_t *o_pred, uint64_t *o_a)
 {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const
 	const uint64_t k = key[i];
 	const uint32_t d = idx[i];
 	const int64_t q0 = qfirst[k >> nb];
-	o_pos[d] = (int32_t)(i - q0) + dropped_below(val[i]);            // position in the query's FULL sorted anchor list
+	o_pos[d] = ABS_POS ? dropped_below(val[i]) : (int32_t)(i - q0) + dropped_below(val[i]);   // position in the query's FULL sorted anchor list
 	// the predecessor as an index into the query's part of the compacted view (a chained-onto anchor is always in the view)
 	const int32_t pr = pred[i];
 	o_f[d] = f[i], o_pred[d] = pr < 0 ? -1 : (int32_t)(idx[q0 + pr] - idx[q0]);
@@ -398,6 +400,273 @@ __global__ __launch_bounds__(256) void k_seed_gather_kept(const SeedJobDev *jobs
 		key[d] = hi | b;
 		val[d] = (uint64_t)(rem[(int64_t)s.qid * n_part + (int32_t)(b / PF_PART_BLOCKS)] + (ww & 0x7fffffffu)) << 32 | (uint32_t)s.qpos;
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_seed_sift: anchors of a query, merged from its occurrence lists IN ORDER, isolated ones dropped on the way (default seeding
+// path; replaces k_seed_gather + the global radix sort of every anchor, and the census of k_seed_prefilter).
+//
+// The anchors of a query (map.c:163-177) are the union of its seeds' occurrence lists, each of which is ascending in the block
+// id, and the order the reference sorts them into (map.c:178, radix_sort_mp64 on block << 32 | query position) is (block, seed)
+// with the seeds in ascending query position -- the order of the query's jobs.  One workgroup owns a SEGMENT of a query's block
+// space (a whole query when it has fewer than ~64 k anchors) and walks it in ascending ranges with one cursor per list: the
+// anchors of a range -- at most SIFT_CAP, the range is halved until they fit -- go to LDS as (block - range start + 1) << LB |
+// list, are sorted there (bitonic), and every anchor that has another one in its own or in an adjacent block (the only ones the
+// pre-chain, map.c:186-192 with max_dist_x = one block, can link) is written out at its final sorted position together with
+// its rank in the query's FULL sorted list (which the host's replay of the reference's unstable chain-end sort needs,
+// host_core.cpp sorted_chain_ends_sparse).  Anchors in the last block of a range wait for the next range (the "carry"): whether
+// they have a right neighbour is not known yet.  Segments are independent: the first cursor positions come from one binary
+// search per list, which also gives the number of the query's anchors below the segment (the rank base) and whether block
+// lo - 1 / block hi hold an anchor.  A query whose anchors of ONE block (plus carry) exceed the buffer -- thousands of seeds
+// hitting the same block: degenerate low-complexity input -- is flagged and seeded on the host.
+// ------------------------------------------------------------------------------------------------
+#define SIFT_THREADS 256
+#define SIFT_CAP 2048                                     /* anchors per LDS buffer (8 KB) */
+#define SIFT_CARRY_MAX 1024                               /* anchors that may wait for the next range */
+#define SIFT_TARGET 1280u                                 /* anchors a range is sized for */
+struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t pad; };     // blocks [lo, hi) of query qid
+
+__device__ __forceinline__ uint32_t sift_wave_sum(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+// sum over the workgroup (4 waves); scr = 4 words of LDS
+__device__ __forceinline__ uint32_t sift_block_sum(uint32_t v, volatile uint32_t *scr)
+{
+	v = sift_wave_sum(v);
+	__syncthreads();                                        // (scr may still be read from the previous call)
+	if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+	__syncthreads();
+	return scr[0] + scr[1] + scr[2] + scr[3];
+}
+// first index c in [c0, cnt) with list[c] >= hi (list ascending), reading eight entries per dependent step
+__device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0, int32_t cnt, uint32_t hi)
+{
+	int32_t c = c0;
+	while (c < cnt) {
+		const int32_t m = cnt - c < 8 ? cnt - c : 8;
+		uint32_t v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = list[c + (k < m ? k : m - 1)];
+		int32_t below = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) below += (k < m && v[k] < hi) ? 1 : 0;
+		c += below;
+		if (below < 8) break;
+	}
+	return c;
+}
+
+// skey/sval: staging, indexed like the unfiltered anchors (a segment writes its kept anchors from qfirst[q] + rank base on: the
+// kept ones can never outnumber the anchors below them); seg_kept[seg] / seg_base[seg]: how many and from where.
+__global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const uint32_t *kb,
+                                                            uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
+                                                            int64_t *seg_base, int32_t *qflag)
+{
+	MPA_SHORT_KERNEL();
+	__shared__ uint32_t keys[SIFT_CAP];
+	__shared__ uint32_t scr[4];
+	__shared__ uint32_t wtot[4];
+	__shared__ uint32_t fill;                                  // slots of `keys` taken while a range is loaded
+	const int t = threadIdx.x;
+	const SiftSeg sg = segs[blockIdx.x];
+	const int32_t q = sg.qid;
+	const int64_t j0 = jfirst[q];
+	const int32_t nl = (int32_t)(jfirst[q + 1] - j0);
+	const int64_t n_anchor = qfirst[q + 1] - qfirst[q];
+	int LB = 1;
+	while ((1 << LB) < nl) ++LB;
+	const uint32_t lmask = (1u << LB) - 1u;
+	const uint32_t w_max = (LB >= 31 ? 1u : (1u << (32 - LB))) - 2u;           // widest range whose local block numbers fit next to LB list bits
+	const uint32_t lo0 = sg.lo, hi0 = sg.hi;
+
+	// ---- cursors at the segment's first block; rank base; is there an anchor in block lo0 - 1?
+	uint32_t below = 0, left_nb = 0;
+	for (int32_t l = t; l < nl; l += SIFT_THREADS) {
+		const SeedJobDev s = jobs[j0 + l];
+		const uint32_t *list = kb + s.kb_off;
+		int32_t c = 0;
+		if (lo0 > 0) {
+			c = d_lower_bound(list, s.cnt, (uint64_t)lo0);
+			if (c > 0 && list[c - 1] == lo0 - 1) left_nb = 1;
+		}
+		cur[j0 + l] = c;
+		below += (uint32_t)c;
+	}
+	const uint32_t pos_base = sift_block_sum(below, scr);
+	left_nb = sift_block_sum(left_nb, scr) ? 1u : 0u;
+	const int64_t out0 = qfirst[q] + (int64_t)pos_base;       // where this segment's kept anchors start in the staging arrays
+
+	uint32_t lo = lo0, n_carry = 0, kept_total = 0, emitted = pos_base;
+	uint32_t prev_blk = left_nb ? lo0 - 1 : 0xffffffffu;      // block of the last anchor below the buffer (0xffffffff: none that matters)
+	// width of the first range: SIFT_TARGET anchors if the query's anchors were spread evenly over the genome
+	uint32_t width;
+	{
+		const uint64_t wv = n_anchor > 0 ? (uint64_t)n_block * SIFT_TARGET / (uint64_t)n_anchor : (uint64_t)n_block;
+		width = (uint32_t)(wv < 1 ? 1 : wv > w_max ? w_max : wv);
+	}
+	while (lo < hi0) {
+		// ---- the range [lo, hi): count its anchors, halve it until they fit
+		uint32_t hi, total;
+		for (;;) {
+			hi = hi0 - lo > width ? lo + width : hi0;
+			uint32_t mine = 0;
+			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
+				const SeedJobDev s = jobs[j0 + l];
+				const int32_t c0 = cur[j0 + l];
+				const int32_t c1 = sift_advance(kb + s.kb_off, c0, s.cnt, hi);
+				cur2[j0 + l] = c1;
+				mine += (uint32_t)(c1 - c0);
+			}
+			total = sift_block_sum(mine, scr);
+			if (n_carry + total <= SIFT_CAP) break;
+			if (hi - lo <= 1) {                                    // one block alone does not fit: the host seeds this query
+				if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
+				return;
+			}
+			width = (hi - lo) >> 1;
+		}
+		// ---- load: (block - lo + 1) << LB | list; the carry sits in keys[0, n_carry) with local block 0
+		if (t == 0) fill = n_carry;
+		__syncthreads();
+		for (int32_t l = t; l < nl; l += SIFT_THREADS) {
+			const int32_t c0 = cur[j0 + l], c1 = cur2[j0 + l];
+			if (c1 > c0) {
+				const uint32_t *list = kb + jobs[j0 + l].kb_off;
+				uint32_t slot = atomicAdd(&fill, (uint32_t)(c1 - c0));
+				for (int32_t c = c0; c < c1; ++c) keys[slot++] = ((list[c] - lo + 1u) << LB) | (uint32_t)l;
+				cur[j0 + l] = c1;
+			}
+		}
+		const uint32_t n = n_carry + total;
+		uint32_t P = 64;
+		while (P < n) P <<= 1;
+		__syncthreads();
+		for (uint32_t i = n + t; i < P; i += SIFT_THREADS) keys[i] = 0xffffffffu;
+		__syncthreads();
+		// ---- bitonic sort of keys[0, P)
+		for (uint32_t k = 2; k <= P; k <<= 1)
+			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for (uint32_t i = t; i < (P >> 1); i += SIFT_THREADS) {
+					const uint32_t a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
+					const uint32_t x = keys[a], y = keys[b];
+					if ((x > y) == ((a & k) == 0u)) keys[a] = y, keys[b] = x;
+				}
+				__syncthreads();
+			}
+		// ---- which anchors are decided now: all of them in the segment's last range, else all below block hi - 1
+		const bool last = hi == hi0;
+		uint32_t right_nb = 0;
+		if (last && hi0 < n_block) {                            // is there an anchor in block hi0 (it belongs to the next segment)?
+			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
+				const SeedJobDev s = jobs[j0 + l];
+				const int32_t c = cur[j0 + l];
+				if (c < s.cnt && kb[s.kb_off + c] == hi0) right_nb = 1;
+			}
+			right_nb = sift_block_sum(right_nb, scr) ? 1u : 0u;
+		}
+		uint32_t n_emit = n;
+		if (!last) {                                             // first key with local block hi - lo (= block hi - 1)
+			const uint32_t bound = (hi - lo) << LB;
+			uint32_t a = 0, b = n;
+			while (a < b) { const uint32_t mid = (a + b) >> 1; if (keys[mid] < bound) a = mid + 1; else b = mid; }
+			n_emit = a;
+		}
+		if (n - n_emit > SIFT_CARRY_MAX) {                        // (uniform) too many anchors in one block to carry
+			if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
+			return;
+		}
+		const int64_t left0 = prev_blk == 0xffffffffu ? -(int64_t)(1 << 30) : (int64_t)prev_blk - (int64_t)lo + 1;   // local block of the anchor below the buffer
+		const int64_t right_end = last && right_nb ? (int64_t)(hi0 - lo) + 1 : ((int64_t)1 << 40);                      // ... of the one above it
+		for (uint32_t base = 0; base < n_emit; base += SIFT_THREADS) {
+			const uint32_t i = base + t;
+			bool keep = false;
+			uint32_t key = 0;
+			if (i < n_emit) {
+				key = keys[i];
+				const int64_t b = (int64_t)(key >> LB);
+				const int64_t lf = i > 0 ? (int64_t)(keys[i - 1] >> LB) : left0;
+				const int64_t rt = i + 1 < n ? (int64_t)(keys[i + 1] >> LB) : right_end;
+				keep = b - lf <= 1 || rt - b <= 1;
+			}
+			const unsigned long long bal = __ballot(keep);
+			const uint32_t lane = t & 63, wv = t >> 6;
+			const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+			__syncthreads();                                       // (wtot of the previous chunk has been read)
+			if (lane == 0) wtot[wv] = (uint32_t)__popcll(bal);
+			__syncthreads();
+			uint32_t off = kept_total + before;
+			for (uint32_t w = 0; w < wv; ++w) off += wtot[w];
+			if (keep) {
+				const uint32_t l = key & lmask;
+				skey[out0 + off] = ((uint64_t)(uint32_t)q << nb) | (uint64_t)(lo + (key >> LB) - 1u);
+				sval[out0 + off] = ((uint64_t)(emitted + i) << 32) | (uint32_t)jobs[j0 + l].qpos;
+			}
+			kept_total += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+		}
+		// ---- the carry moves to the front (local block 0 of the next range); the range is done
+		if (n_emit > 0) prev_blk = lo + (keys[n_emit - 1] >> LB) - 1u;
+		uint32_t cv[SIFT_CARRY_MAX / SIFT_THREADS];
+#pragma unroll
+		for (int k = 0; k < SIFT_CARRY_MAX / SIFT_THREADS; ++k) {
+			const uint32_t i = n_emit + t + k * SIFT_THREADS;
+			cv[k] = i < n ? keys[i] & lmask : 0u;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < SIFT_CARRY_MAX / SIFT_THREADS; ++k) {
+			const uint32_t i = t + k * SIFT_THREADS;
+			if (n_emit + i < n) keys[i] = cv[k];
+		}
+		n_carry = n - n_emit;
+		emitted += n_emit;
+		lo = hi;
+		if (total < SIFT_TARGET / 2) width = width > w_max / 2 ? w_max : width * 2;     // sparse here: wider ranges
+		__syncthreads();
+	}
+	if (t == 0) seg_kept[blockIdx.x] = kept_total, seg_base[blockIdx.x] = out0;
+}
+
+// exclusive prefix of the segments' kept counts (a flagged query's segments count as empty), then the first kept anchor of
+// every query: qseg[q] = the query's first segment, or, for a query without anchors, that of the next query that has some
+// (qseg[n_query] = n_seg).  One workgroup: there are a few thousand segments.
+__global__ __launch_bounds__(256) void k_sift_offsets(const SiftSeg *segs, int32_t n_seg, int32_t n_query, const int32_t *qseg, const int32_t *qflag,
+                                                      const uint32_t *seg_kept, int64_t *seg_out, int64_t *qfirst2)
+{
+	__shared__ uint32_t wpre[4];
+	const int t = threadIdx.x;
+	int64_t running = 0;
+	for (int32_t base = 0; base < n_seg; base += 256) {
+		const int32_t i = base + t;
+		uint32_t v = 0;
+		if (i < n_seg && !qflag[segs[i].qid]) v = seg_kept[i];
+		uint32_t inc = v;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+		__syncthreads();                                        // (wpre of the previous chunk has been read)
+		if ((t & 63) == 63) wpre[t >> 6] = inc;
+		__syncthreads();
+		uint32_t before = 0;
+		for (int w = 0; w < (t >> 6); ++w) before += wpre[w];
+		if (i < n_seg) seg_out[i] = running + before + inc - v;
+		running += (int64_t)wpre[0] + wpre[1] + wpre[2] + wpre[3];
+	}
+	if (t == 0) seg_out[n_seg] = running;
+	__syncthreads();                                            // (one workgroup: its global writes are visible to it behind the barrier)
+	for (int32_t q = t; q <= n_query; q += 256) qfirst2[q] = seg_out[qseg[q]];
+}
+// staging -> dense, segment by segment
+__global__ __launch_bounds__(256) void k_sift_copy(const SiftSeg *segs, const int32_t *qflag, const uint32_t *seg_kept, const int64_t *seg_base, const int64_t *seg_out,
+                                                   const uint64_t *skey, const uint64_t *sval, uint64_t *key, uint64_t *val)
+{
+	MPA_SHORT_KERNEL();
+	const int32_t sgi = blockIdx.x;
+	if (qflag[segs[sgi].qid]) return;
+	const uint32_t n = seg_kept[sgi];
+	const int64_t from = seg_base[sgi], to = seg_out[sgi];
+	for (uint32_t i = threadIdx.x; i < n; i += 256) key[to + i] = skey[from + i], val[to + i] = sval[from + i];
 }
 
 // ------------------------------------------------------------------------------------------------

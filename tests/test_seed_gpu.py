@@ -25,11 +25,15 @@ def survivors(ctx, idx, mo, q, threads=4):
     return off, a
 
 
-@pytest.mark.parametrize("prefilter", ["0", "1"])
+@pytest.mark.parametrize("mode", ["sort", "census", "sift", "sift-small-segments"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_device_seeding_equals_host_seeding(seed, prefilter, monkeypatch):
-    # prefilter = "1": anchors without a neighbour within one block are dropped before the sort (k_seed_prefilter)
-    monkeypatch.setenv("MPA_SEED_PREFILTER", prefilter)
+def test_device_seeding_equals_host_seeding(seed, mode, monkeypatch):
+    # sort: every anchor is gathered and radix-sorted; census: anchors without a neighbour within one block are dropped before
+    # the sort (k_seed_prefilter); sift (the default): per-query merge in block order + LDS sort + the same filter (k_seed_sift),
+    # also with segments so small that every query is cut into many of them
+    monkeypatch.setenv("MPA_SEED_MODE", mode.split("-")[0])
+    if mode.endswith("segments"):
+        monkeypatch.setenv("MPA_SIFT_SEG", "300")
     rng = np.random.default_rng(seed)
     contigs, prots, names, planted = gen_synth.generate(3000000, 2, 40, 20 + seed, return_planted=True)
     # tandem copies: re-plant the locus of a few genes several times back to back, on both strands of contig 0
@@ -86,14 +90,41 @@ def test_prefilter_across_block_ranges(monkeypatch):
     mo = mpa.default_mapopt()
     mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
     off_h, a_h = survivors(None, idx, mo, q, threads=16)
-    for prefilter in ("0", "1"):
-        monkeypatch.setenv("MPA_SEED_PREFILTER", prefilter)
+    for mode, seg in (("sort", None), ("census", None), ("sift", None), ("sift", "2000")):
+        monkeypatch.setenv("MPA_SEED_MODE", mode)
+        if seg:
+            monkeypatch.setenv("MPA_SIFT_SEG", seg)          # ~20 segments per query: segment boundaries all over the genome
         off_d, a_d = survivors(ctx, idx, mo, q, threads=16)
-        assert np.array_equal(off_h, off_d), prefilter
-        assert np.array_equal(a_h, a_d), prefilter
+        assert np.array_equal(off_h, off_d), (mode, seg)
+        assert np.array_equal(a_h, a_d), (mode, seg)
     # the planted copies are really there: anchors of query 0 in the blocks either side of the boundary
     blocks = (a_h[off_h[0]:off_h[1]] >> 32).astype(np.int64)
     assert ((blocks >= bblock - 4) & (blocks < bblock)).any() and ((blocks >= bblock) & (blocks < bblock + 6)).any()
+    idx.close()
+    ctx.close()
+
+
+def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypatch):
+    """k_seed_sift holds the anchors of one range in a 2 048-entry LDS buffer; a query whose seeds put more than that into ONE
+    block (here: 3 000 identical k-mers of a poly-K protein over poly-A stretches of the genome) is flagged by the kernel and
+    seeded on the host, the other queries of the batch stay on the device -- same survivors as the host stage for all of them"""
+    monkeypatch.setenv("MPA_SEED_MODE", "sift")
+    contigs, prots, names, planted = gen_synth.generate(2000000, 1, 20, 31, return_planted=True)
+    g = contigs[0]
+    for at in (300000, 300700, 900000, 1500000):
+        g[at:at + 420] = 0                                      # AAA AAA ...: lysine codons, an ORF of 140 codons on the forward strand
+    idx = mpa.Index.from_nt4(contigs, ["chr1"])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
+    ctx = mpa.Context(0)
+    idx.to_device(ctx)
+    seqs = [bytes(p) for p in planted[:8]] + [b"M" + b"K" * 3000, b"K" * 1500 + bytes(planted[0])] + [bytes(p) for p in planted[8:12]]
+    q = mpa.Queries(seqs)
+    mo = mpa.default_mapopt()
+    mo.max_occ = 100000
+    off_h, a_h = survivors(None, idx, mo, q)
+    off_d, a_d = survivors(ctx, idx, mo, q)
+    assert np.array_equal(off_h, off_d) and np.array_equal(a_h, a_d)
+    assert off_h[9] - off_h[8] > 1000                            # the poly-K query does have (many) anchors in the stretches
     idx.close()
     ctx.close()
 
