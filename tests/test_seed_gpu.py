@@ -106,25 +106,25 @@ def test_prefilter_across_block_ranges(monkeypatch):
 
 def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypatch):
     """k_seed_sift holds the anchors of one range in a 2 048-entry LDS buffer; a query whose seeds put more than that into ONE
-    block (here: 3 000 identical k-mers of a poly-K protein over poly-A stretches of the genome) is flagged by the kernel and
+    block (here: 3 000 identical k-mers of a poly-L protein over CTG repeats in the genome) is flagged by the kernel and
     seeded on the host, the other queries of the batch stay on the device -- same survivors as the host stage for all of them"""
     monkeypatch.setenv("MPA_SEED_MODE", "sift")
     contigs, prots, names, planted = gen_synth.generate(2000000, 1, 20, 31, return_planted=True)
     g = contigs[0]
     for at in (300000, 300700, 900000, 1500000):
-        g[at:at + 420] = 0                                      # AAA AAA ...: lysine codons, an ORF of 140 codons on the forward strand
+        g[at:at + 420] = np.tile(np.array([1, 3, 2], np.uint8), 140)   # CTG CTG ...: leucine codons, an ORF of 140 codons on the forward strand
     idx = mpa.Index.from_nt4(contigs, ["chr1"])
     mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
     ctx = mpa.Context(0)
     idx.to_device(ctx)
-    seqs = [bytes(p) for p in planted[:8]] + [b"M" + b"K" * 3000, b"K" * 1500 + bytes(planted[0])] + [bytes(p) for p in planted[8:12]]
+    seqs = [bytes(p) for p in planted[:8]] + [b"M" + b"L" * 3000, b"L" * 1500 + bytes(planted[0])] + [bytes(p) for p in planted[8:12]]
     q = mpa.Queries(seqs)
     mo = mpa.default_mapopt()
     mo.max_occ = 100000
     off_h, a_h = survivors(None, idx, mo, q)
     off_d, a_d = survivors(ctx, idx, mo, q)
     assert np.array_equal(off_h, off_d) and np.array_equal(a_h, a_d)
-    assert off_h[9] - off_h[8] > 1000                            # the poly-K query does have (many) anchors in the stretches
+    assert off_h[9] - off_h[8] > 1000                            # the poly-L query does have (many) anchors in the repeats
     idx.close()
     ctx.close()
 
