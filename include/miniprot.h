@@ -144,6 +144,8 @@ void mp_idx_print_stat(const mp_idx_t *mi, int32_t max_occ);
 int32_t mp_ntseq_read_spsc(mp_ntdb_t *nt, const char *fn, int32_t max_sc);
 void mp_set_spsc(const char *fn, mp_idx_t *mi, mp_mapopt_t *mo, int32_t keep_io);
 
+/* a thread buffer owns a device context (HIP streams + device pools), taken from a pool by its first mp_map() and parked
+ * there again by mp_tbuf_destroy(): creating and destroying buffers per mini-batch, as map.c does, costs nothing extra */
 mp_tbuf_t *mp_tbuf_init(void);
 void mp_tbuf_destroy(mp_tbuf_t *b);
 /* all hits of one protein.  The array and every ->p / ->feat are malloc'd; the caller frees them. */

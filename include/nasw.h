@@ -4,7 +4,8 @@
  * is uploaded as a one-contig genome, the three kernels (row records, extension or traceback sweep, backtrack) run on
  * the default device and the result comes back in the reference's ns_rst_t.  Results are bit-identical to the
  * reference's SSE2 kernel, including the traceback's striping artefacts.  It exists for callers of the operator ABI;
- * throughput comes from batching (mpa_dp_run / mpa_map_batches), not from this entry point.
+ * throughput comes from batching (mpa_dp_run / mpa_map_batches), not from this entry point: every call builds and uploads a
+ * one-contig index of its own and holds the library's global lock while it runs (a compatibility shim, not a fast path).
  *
  * Memory: ns_rst_t::cigar is allocated with malloc() when km == NULL.  A non-NULL km is a kalloc arena of the caller;
  * it is honoured when the program itself provides kmalloc() (weak reference), otherwise the call aborts with a message.

@@ -265,10 +265,24 @@ mp_tbuf_t *mp_tbuf_init(void)
 	return b;                                            // its device context is created by the first mp_map() that uses it
 }
 
+// Device contexts of thread buffers are pooled: the reference's own calling pattern (map.c:273-345, worker_pipeline) creates
+// and destroys n_threads buffers per mini-batch, and a context is a set of HIP streams, events and grow-only device pools that
+// is expensive to build.  A destroyed buffer parks its context; the next mp_map() on a fresh buffer picks it up.
+static std::vector<mpa_ctx_t*> g_ctx_pool;              // (guarded by g_mu; contexts of default_device())
+static mpa_ctx_t *pooled_ctx()                          // caller holds g_mu
+{
+	if (!g_ctx_pool.empty()) { mpa_ctx_t *c = g_ctx_pool.back(); g_ctx_pool.pop_back(); return c; }
+	return mpa_ctx_create(default_device());
+}
+
 void mp_tbuf_destroy(mp_tbuf_t *b)
 {
 	if (!b) return;
-	if (b->ctx) mpa_ctx_destroy(b->ctx);
+	if (b->ctx) {
+		std::lock_guard<std::mutex> g(g_mu);
+		if (g_ctx_pool.size() < 64) g_ctx_pool.push_back(b->ctx);
+		else mpa_ctx_destroy(b->ctx);
+	}
 	free(b);
 }
 
@@ -315,12 +329,13 @@ mp_reg1_t *mp_map(const mp_idx_t *mi, int qlen, const char *seq, int *n_reg, mp_
 	mpa_ctx_t *ctx;
 	std::unique_lock<std::mutex> g(g_mu);
 	if (b) {
-		if (!b->ctx && !(b->ctx = mpa_ctx_create(default_device()))) die("mp_map: no usable HIP device (there is no CPU fallback)");
+		if (!b->ctx && !(b->ctx = pooled_ctx())) die("mp_map: no usable HIP device (there is no CPU fallback)");
 		ctx = b->ctx;
-	} else ctx = shared_ctx();
+	} else if (!(ctx = pooled_ctx())) die("mp_map: no usable HIP device (there is no CPU fallback)");   // no buffer: a pooled context for this one call
 	if (mpa_idx_to_device(ctx, c->impl) != MPA_OK) die("mp_map: index upload");
-	if (b) g.unlock();                                   // a caller-owned buffer = its own context: calls run concurrently
+	g.unlock();                                          // every call has a context of its own by now: calls run concurrently
 	if (mpa_map_batch(ctx, c->impl, reinterpret_cast<const mpa_mapopt_t*>(opt), &q, 1, &res) != MPA_OK) die("mp_map");
+	if (!b) { g.lock(); g_ctx_pool.push_back(ctx); g.unlock(); }
 	mp_reg1_t *regs = regs_from_result(res, 0, n_reg);
 	mpa_result_destroy(res);
 	return regs;
@@ -387,7 +402,7 @@ int32_t mp_map_file(const mp_idx_t *idx, const char *fn, const mp_mapopt_t *opt,
 // ---- ns_global_gs16b: one call of the batched operator ------------------------------------------------------
 void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r)
 {
-	r->n_cigar = 0, r->nt_len = r->aa_len = 0, r->score = INT32_MIN;
+	r->n_cigar = 0, r->nt_len = nl, r->aa_len = al, r->score = INT32_MIN;   // (NS_GEN_PREPARE sets the lengths before its early return, nasw-sse.c:236)
 	if (nl <= 0 || al <= 0) return;
 	if (opt->asize != 22 || (opt->nt4 && opt->nt4 != ns_tab_nt4) || (opt->aa20 && opt->aa20 != ns_tab_aa20) || (opt->codon && opt->codon != ns_tab_codon)) {
 		set_error("ns_opt_t must use the library's own tables (ns_tab_nt4 / ns_tab_aa20 / ns_tab_codon) and asize 22");

@@ -115,6 +115,8 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	HIP_TRY(hipSetDevice(ctx->device));
 	DeviceIndex *d = new DeviceIndex();
 	d->device = ctx->device;
+	// (an upload that fails half-way gives everything back: the caller may retry, e.g. on the host path, and must not leak HBM)
+	struct Undo { DeviceIndex *d; ~Undo() { if (!d) return; (void)hipFree(d->seq); (void)hipFree(d->ctg_off); (void)hipFree(d->ctg_len); (void)hipFree(d->spsc); delete d; } } undo{ d };
 	const size_t n = mi->ctg.size();
 	std::vector<int64_t> off(n), len(n);
 	for (size_t i = 0; i < n; ++i) off[i] = mi->ctg[i].off, len[i] = mi->ctg[i].len;
@@ -129,6 +131,7 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 		HIP_TRY(hipMemcpy(d->spsc, mi->spsc.data(), mi->spsc.size(), hipMemcpyHostToDevice));
 	}
 	mi->dev = d;
+	undo.d = nullptr;
 	return MPA_OK;
 }
 
@@ -172,6 +175,19 @@ static int build_pen_table(float coef, int32_t max_x, PenTable *pt)
 	return 0;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember it per (kernel, device), under a lock -- several
+// DP lanes and seeders get here at once, and a process may hold contexts on several devices
+static hipError_t ensure_dynamic_lds(const void *fn, int device, size_t bytes)
+{
+	static std::mutex mu;
+	static std::vector<std::pair<const void*, int>> done;
+	std::lock_guard<std::mutex> g(mu);
+	for (auto &d : done) if (d.first == fn && d.second == device) return hipSuccess;
+	const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e == hipSuccess) done.emplace_back(fn, device);
+	return e;
+}
+
 struct ExtClass { int G, NB; };
 // classes 0..2: k_ext_narrow, several calls per wave.  classes 3..6: k_ext_wide<NW>, NW waves per pair of calls.
 static const ExtClass kExtClasses[] = { {16, 1}, {32, 1}, {64, 1}, {64, 2}, {64, 4}, {64, 8}, {64, 16} };
@@ -199,7 +215,9 @@ template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_g
 {
 	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 12 * NW * 4 + (NW <= 4 ? 64 : 128) * 8 + 128 * (2 * NW + 1) * 4;
 	if (lds > 48 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void*)k_ext_wide<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		hipError_t e = ensure_dynamic_lds((const void*)k_ext_wide<NW>, dev, lds);
 		if (e != hipSuccess) return e;
 	}
 	hipLaunchKernelGGL((k_ext_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
@@ -356,8 +374,7 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	    B.pf_jfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_qfirst2.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_err.ensure(16) != MPA_OK) return MPA_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(B.pf_jfirst.p, jfirst.data(), ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(B.pf_err.p, 0, 16, s));
-	static bool attr_set = false;
-	if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_seed_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS)); attr_set = true; }
+	HIP_TRY(ensure_dynamic_lds((const void*)k_seed_prefilter, ctx->device, PF_LDS));
 	HIP_TRY(hipStreamSynchronize(s));                       // (jfirst is a local)
 	hipLaunchKernelGGL(k_seed_prefilter, dim3((unsigned)n_part, (unsigned)n_query), dim3(PF_THREADS), PF_LDS, s, B.jobs.as<SeedJobDev>(), B.pf_jfirst.as<int64_t>(), d->kb,
 	                   n_part, B.pf_w.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_err.as<int32_t>());
@@ -747,21 +764,26 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	const int64_t n_kb = (int64_t)(last_idx + last_flag);
 	uint32_t *d_kb = nullptr;
 	HIP_TRY(hipMalloc((void**)&d_kb, (size_t)n_kb * 4 + 16));
+	struct KbGuard { uint32_t *&p; hipStream_t s; ~KbGuard() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } } } kb_guard{ d_kb, s };   // freed on every error path below
 	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, n_bucket * 8, s));
 	hipLaunchKernelGGL(k_index_compact, dim3(nblk), dim3(256), 0, s, sorted, n_keys, b_flag.as<uint32_t>(), b_idx.as<uint64_t>(), d_kb, b_cnt.as<unsigned long long>());
 	{
 		size_t tmp_bytes = 0;
 		HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, b_cnt.as<uint64_t>(), b_ki.as<uint64_t>(), (uint64_t)0, n_bucket, rocprim::plus<uint64_t>(), s));
-		if ((rc = b_tmp.ensure(tmp_bytes + 256))) { (void)hipFree(d_kb); return rc; }
+		if ((rc = b_tmp.ensure(tmp_bytes + 256))) return rc;
 		HIP_TRY(rocprim::exclusive_scan(b_tmp.p, tmp_bytes, b_cnt.as<uint64_t>(), b_ki.as<uint64_t>(), (uint64_t)0, n_bucket, rocprim::plus<uint64_t>(), s));
 	}
 	HIP_TRY(hipGetLastError());
-	mi->ki.resize(n_bucket), mi->kb.resize((size_t)n_kb), mi->n_kb = n_kb;
-	HIP_TRY(hipMemcpyAsync(mi->ki.data(), b_ki.p, n_bucket * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(mi->kb.data(), d_kb, (size_t)n_kb * 4, hipMemcpyDeviceToHost, s));
+	// (into temporaries: a copy that fails must not leave the index with a half-filled table)
+	std::vector<int64_t> ki_new(n_bucket);
+	std::vector<uint32_t> kb_new((size_t)n_kb);
+	HIP_TRY(hipMemcpyAsync(ki_new.data(), b_ki.p, n_bucket * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(kb_new.data(), d_kb, (size_t)n_kb * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
+	mi->ki.swap(ki_new), mi->kb.swap(kb_new), mi->n_kb = n_kb;
 	if (d->kb) (void)hipFree(d->kb);
 	d->kb = d_kb;                                          // stays resident for the seeding kernels
+	d_kb = nullptr;                                        // (ownership moved: the guard lets go)
 	timing_note("index build on the GPU", now_ms() - t0);
 	return MPA_OK;
 }
@@ -1087,7 +1109,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	// split classes: boundary granules (16 B per row and boundary: 3 boundaries per 1024-column group, 1 per 512-column group),
 	// then the per-group completion counters and the error flag; all zero before the launch (a granule's tag is row + 1)
 	const int64_t n_split = ewave_cnt[5] + ewave_cnt[6], n_bound = 3 * (int64_t)ewave_cnt[6] + ewave_cnt[5];
-	const size_t xg_bytes = (size_t)n_bound * key_stride * 16, xg_tail = ((size_t)n_split + 1) * 4;
+	const size_t xg_bytes = (size_t)n_bound * key_stride * 16, xg_tail = (2 * (size_t)n_split + 1) * 4;   // + done[n_split], ticket[n_split], err
 	if (n_split) {
 		if ((rc = ctx->xg.ensure(xg_bytes + xg_tail + 64))) return rc;
 		HIP_TRY(hipMemsetAsync(ctx->xg.p, 0, xg_bytes + xg_tail, s));
@@ -1152,7 +1174,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	wa.tasks = ea.tasks, wa.rec = ea.rec, wa.prof = ea.prof, wa.out = ea.out, wa.c = dc, wa.pen = pen, wa.key_stride = key_stride;
 	wa.xg = n_split ? ctx->xg.as<unsigned long long>() : nullptr;
 	wa.done = n_split ? (int32_t*)((char*)ctx->xg.p + xg_bytes) : nullptr;
-	wa.err = n_split ? wa.done + n_split : nullptr;
+	wa.ticket = n_split ? wa.done + n_split : nullptr;
+	wa.err = n_split ? wa.ticket + n_split : nullptr;
 	// rowkey slots follow the order of the wave descriptors (classes 3, 4, 5, 6)
 	int64_t rk_first[kNumExtClasses] = { 0 };
 	{ int64_t at = 0; for (int cls = 3; cls < kNumExtClasses; ++cls) rk_first[cls] = at, at += ewave_cnt[cls]; }
@@ -1225,11 +1248,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			if (const char *k = getenv("MPA_ROUND_LDS_KB")) pad = (size_t)atoi(k) * 1024;
 			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
 		}();
-		static bool attr_set = false;
-		if (!attr_set && round_lds > 48 * 1024) {
-			HIP_TRY(hipFuncSetAttribute((const void*)k_dp_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)round_lds));
-			attr_set = true;
-		}
+		if (round_lds > 48 * 1024) HIP_TRY(ensure_dynamic_lds((const void*)k_dp_round, ctx->device, round_lds));
 		HIP_TRY(hipEventRecord(ev_round0, s));
 		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)n_units), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
 		HIP_TRY(hipGetLastError());

@@ -617,6 +617,7 @@ struct ExtWideArgs {
 	// split classes only (k_ext_wide_split): column-block boundaries travel between workgroups through HBM
 	unsigned long long *xg;   // [boundary][key_stride rows][2] granules {payload, row + 1}, zero-initialised
 	int32_t *done;            // [group] workgroups of the group that have finished, zero-initialised
+	int32_t *ticket;          // [group] workgroups of the group that have STARTED, zero-initialised: a workgroup's column block is its ticket
 	int32_t *err;             // set to 1 if a hand-off never arrived (bounded spin)
 };
 
@@ -654,14 +655,26 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 	constexpr int XIN = 96;                                      // rows of incoming boundary values kept in LDS (two fetches of 48)
 	uint2 *xin = (uint2*)(kring + 128 * KS);                     // [XIN] {carry, H} from the workgroup to the left (SPLIT only; 128 KS is even)
 	const int lane = wp.lane, w = wp.w;                          // w: wave index inside the group, scalar
-	const int gw = SPLIT ? pos.blk * NWB + w : w;                // wave index inside the call: owns columns [64 gw, 64 gw + 64)
-	const bool has_left = SPLIT && pos.blk > 0, has_right = SPLIT && pos.blk + 1 < pos.n_blk;
+	// SPLIT: which column block this workgroup sweeps is decided when it STARTS -- the k-th workgroup of the group to start takes
+	// block k -- not by its position in the grid: the workgroup it will wait for (block k - 1) is then certain to be running
+	// already, whatever order the dispatcher hands workgroups to the XCDs in and whatever else competes for the CUs, so the
+	// hand-off cannot wait for a workgroup that has no slot yet.
+	int blk = 0;
+	if (SPLIT) {
+		int32_t *slot = (int32_t*)wp.lds;
+		if (wp.tg == 0) *slot = atomicAdd(&a.ticket[pos.group], 1);
+		__syncthreads();
+		blk = __builtin_amdgcn_readfirstlane(*slot);
+		__syncthreads();                                           // (the slot is profile space from here on)
+	}
+	const int gw = SPLIT ? blk * NWB + w : w;                    // wave index inside the call: owns columns [64 gw, 64 gw + 64)
+	const bool has_left = SPLIT && blk > 0, has_right = SPLIT && blk + 1 < pos.n_blk;
 	const ExtWave *wvp = &a.waves[group_idx];
 	const DpConst c = a.c;
 	const uint32_t *recbase = a.rec + wvp->rec_base;
 	uint32_t *rowkey = a.rowkey + (int64_t)group_idx * 2 * a.key_stride;
-	unsigned long long *xg_out = SPLIT ? a.xg + ((int64_t)(pos.xg_first + pos.blk) * a.key_stride) * 2 : nullptr;
-	const unsigned long long *xg_in = SPLIT ? a.xg + ((int64_t)(pos.xg_first + pos.blk - 1) * a.key_stride) * 2 : nullptr;
+	unsigned long long *xg_out = SPLIT ? a.xg + ((int64_t)(pos.xg_first + blk) * a.key_stride) * 2 : nullptr;
+	const unsigned long long *xg_in = SPLIT ? a.xg + ((int64_t)(pos.xg_first + blk - 1) * a.key_stride) * 2 : nullptr;
 
 	int32_t tid[2], nl[2], al[2], ncol[2];
 	uint32_t roff[2];
@@ -827,7 +840,7 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 						if ((v0 >> 6) > (b0 >> 6)) b0 = v0, w0 = ww;
 						if ((v1 >> 6) > (b1 >> 6)) b1 = v1, w1 = ww;
 					}
-					const int32_t wb = SPLIT ? pos.blk * NWB : 0;
+					const int32_t wb = SPLIT ? blk * NWB : 0;
 					const uint32_t key0 = (b0 >> 6) << 16 | (0xffffu - (uint32_t)((wb + w0) * 64 + 63 - (int32_t)(b0 & 63)));
 					const uint32_t key1 = (b1 >> 6) << 16 | (0xffffu - (uint32_t)((wb + w1) * 64 + 63 - (int32_t)(b1 & 63)));
 					if (SPLIT) {                                               // best value, then smallest column, over the workgroups too
