@@ -148,6 +148,12 @@ class Workload:
         return rec, per
 
 
+def host_cpu_seconds():
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
 def run_stream(mpa, mdist, wl, ctx, n_steps, n_threads, rank, world, device):
     """n_steps mini-batches (k mod n_distinct) of the job, this rank's share through mpa_map_batches, text to rank 0."""
     nb = len(wl.batches)
@@ -161,10 +167,14 @@ def measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, 
     run_stream(mpa, mdist, wl, ctx, warmup, n_threads, rank, world, device)
     ctx.dp_stats(total=True, reset=True)
     sync()
+    cpu0 = host_cpu_seconds()
     t1 = time.time()
     texts = run_stream(mpa, mdist, wl, ctx, steps, n_threads, rank, world, device)
     sync()
-    return time.time() - t1, texts, ctx.dp_stats(total=True)
+    elapsed = time.time() - t1
+    st = ctx.dp_stats(total=True)
+    st["host_cpu_s"] = host_cpu_seconds() - cpu0              # user + system CPU time of THIS rank's process (all its threads) inside the timed region
+    return elapsed, texts, st
 
 
 def roofline_record(st, elapsed, world):
@@ -279,7 +289,7 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-            keys = ("cells_ext", "cells_glob", "alg_bytes_ext", "launches_ext", "ms_ext", "cells_ext_round", "cells_glob_round", "launches_round", "ms_round")
+            keys = ("cells_ext", "cells_glob", "alg_bytes_ext", "alg_bytes_glob", "launches_ext", "ms_ext", "cells_ext_round", "cells_glob_round", "launches_round", "ms_round", "host_cpu_s")
             tot = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device=device)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             for k, v in zip(keys, tot.tolist()):
@@ -312,7 +322,10 @@ def main():
                    "dp_cells": {"ext": st["cells_ext"], "glob": st["cells_glob"]},
                    "gcups_wall": (st["cells_ext"] + st["cells_glob"]) / elapsed / 1e9,
                    "setup_s": {"generate": wl.t_generate, "index_build": wl.t_index, "index_built_on": wl.index_built_on, "total": wl.t_setup},
-                   "host_threads_per_rank": n_threads}
+                   "host_threads_per_rank": n_threads,
+                   # CPU seconds (user + system, getrusage) all ranks' processes spent inside the timed region, per step and as a share of
+                   # the host: what one GPU's pipeline costs the host it shares with the other ranks
+                   "host_cpu_s_per_step": st["host_cpu_s"] / max(steps, 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9)}
         ctx.close()
         wl.idx.close()
         barrier()
@@ -342,6 +355,7 @@ def main():
                           "batching": "stream of mini-batches (mpa_map_batches)", "host_threads_per_rank": r["host_threads_per_rank"]},
                "elapsed_s": r["elapsed_s"], "aligned_residues": r["aligned_residues"], "input_residues_per_s": r["input_residues_per_s"],
                "paf_identical": r["paf_identical"], "md5_first_pass": r["md5_first_pass"],
+               "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"],
                "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
         out.update(extra)
         print(json.dumps(out))
