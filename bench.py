@@ -155,15 +155,20 @@ def host_cpu_seconds():
 
 
 def run_stream(mpa, mdist, wl, ctx, n_steps, n_threads, rank, world, device):
-    """n_steps mini-batches (k mod n_distinct) of the job, this rank's share through mpa_map_batches, text to rank 0."""
+    """One job of n_steps mini-batches (batch k of the job = distinct batch k mod n_distinct), shared by all ranks: every rank's
+    mpa_map_batches_claim() stream pulls the next unclaimed batch whenever its pipeline has room (miniprot_amd/dist.py), the
+    text of every batch goes to rank 0.  Returns the texts in job order on rank 0."""
     nb = len(wl.batches)
-    def map_mine(ks):
-        return mpa.map_batches(ctx, wl.idx, wl.mo, [wl.batches[k % nb] for k in ks], n_threads)
-    texts, _ = mdist.run_sharded(n_steps, rank, world, device, False, map_mine, None, None)
+    job = [wl.batches[k % nb] for k in range(n_steps)]
+    def map_claimed(claim):
+        return mpa.map_batches(ctx, wl.idx, wl.mo, job, n_threads, claim=claim)
+    texts, _ = mdist.run_sharded(n_steps, rank, world, device, False, None, None, None, map_claimed=map_claimed)
     return texts
 
 
 def measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, sync):
+    # (weak scaling: `steps` and `warmup` are per GPU -- the job the ranks share is world x steps mini-batches)
+    steps, warmup = steps * world, warmup * world
     run_stream(mpa, mdist, wl, ctx, warmup, n_threads, rank, world, device)
     ctx.dp_stats(total=True, reset=True)
     sync()

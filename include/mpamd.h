@@ -250,6 +250,17 @@ int64_t mpa_result_n_output(const mpa_mapopt_t *opt, const mpa_qbatch_t *q, cons
 int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len);
 
+/* The same stream when the job's batches are shared between several callers (one process per GPU; the kt_for work stealing of
+ * map.c:264-271 between processes): batches[] is the WHOLE job, claim(user) returns the index of the next batch this call
+ * should map, or -1 once the job has none left; a caller takes a new batch whenever its pipeline has room for one, so a
+ * faster GPU maps more of the job.  results / text / text_len hold what this call mapped, in the order it claimed them;
+ * order[j] = index into batches[] of slot j, *n_mapped = how many.  The hit ids of *id_io run over this call's batches only
+ * (GFF3/GTF jobs format after exchanging mpa_result_n_output() counts instead). */
+typedef int32_t (*mpa_claim_fn)(void *user);
+int mpa_map_batches_claim(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                          const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len,
+                          mpa_claim_fn claim, void *user, int32_t *n_mapped, int32_t *order);
+
 const char *mpa_version(void);
 
 /* ---- diagnostics (operator-level parity tests of the seeding kernels; not needed by a caller) ---------------------------- */

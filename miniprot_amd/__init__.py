@@ -365,21 +365,49 @@ def map_batch(ctx, idx, mo, queries, n_threads=1):
     return Result(res.value)
 
 
-def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_text=True):
+CLAIM_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+
+
+def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_text=True, claim=None):
     """mpa_map_batches(): a stream of Queries batches through the pipelined mapper.  Returns the list of output texts
     (bytes, one per batch; the hit-id counter runs across the batches as in one output file); with keep_results the pair
-    (texts, [Result]); with want_text=False no text is produced (texts are None)."""
+    (texts, [Result]); with want_text=False no text is produced (texts are None).
+    claim: mpa_map_batches_claim() -- `batches` is a whole job shared with other processes and claim() returns the index of
+    the next batch this process should map (-1: none left); the return value is then (order, texts[, results]) for the
+    batches this call mapped, in the order it claimed them."""
     n = len(batches)
     if n == 0:
-        return ([], []) if keep_results else []
+        return (([], [], []) if keep_results else ([], [])) if claim else (([], []) if keep_results else [])
     qb = (QBatch * n)(*[b.c for b in batches])
     res = (C.c_void_p * n)()
     idc = C.c_int64(0)
+    names = text = tlen = None
     if want_text:
         name_arrays = [(C.c_char_p * len(b.names))(*[x.encode() for x in b.names]) for b in batches]
         names = (C.POINTER(C.c_char_p) * n)(*[C.cast(a, C.POINTER(C.c_char_p)) for a in name_arrays])
         text = (C.c_void_p * n)()
         tlen = (C.c_int64 * n)()
+    order = None
+    if claim is not None:
+        err = []
+        def _claim(_user):
+            try:
+                return int(claim())
+            except BaseException as e:                          # (an exception must not unwind through the C pipeline)
+                err.append(e)
+                return -1
+        cb = CLAIM_FN(_claim)
+        n_mapped = C.c_int32(0)
+        order_c = (C.c_int32 * n)()
+        f = lib().mpa_map_batches_claim
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                      CLAIM_FN, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(ctx.h, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc) if want_text else None, text, tlen, cb, None, C.byref(n_mapped), order_c))
+        if err:
+            raise err[0]
+        n = n_mapped.value
+        order = [int(order_c[k]) for k in range(n)]
+    elif want_text:
         _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc), text, tlen))
     else:
         _check(lib().mpa_map_batches(ctx.h, idx.h, C.byref(mo), n, qb, None, n_threads, res, None, None, None))
@@ -394,6 +422,8 @@ def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_tex
             results.append(Result(res[k]))
         else:
             lib().mpa_result_destroy(C.c_void_p(res[k]))
+    if order is not None:
+        return (order, out, results) if keep_results else (order, out)
     return (out, results) if keep_results else out
 
 

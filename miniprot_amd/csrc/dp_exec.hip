@@ -467,6 +467,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	static thread_local std::vector<int64_t> jfirst;
 	static thread_local std::vector<int32_t> qseg;
 	segs.clear();
+	int64_t n_cur = 0;                                         // cursors: one per (segment, list of its query)
 	jfirst.assign((size_t)n_query + 1, 0), qseg.assign((size_t)n_query + 1, 0);
 	for (int64_t j = 0; j < n_jobs; ++j) ++jfirst[(size_t)jobs[j].qid + 1];
 	for (int32_t q = 0; q < n_query; ++q) jfirst[(size_t)q + 1] += jfirst[(size_t)q];
@@ -475,11 +476,16 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 		qseg[(size_t)q] = (int32_t)segs.size();
 		if (na == 0) continue;
 		if (na >= (int64_t)1 << 31) { set_error("GPU seeding: a query with more than 2^31 anchors"); return MPA_ERR_UNSUPPORTED; }
-		if (jfirst[(size_t)q + 1] - jfirst[(size_t)q] > (1 << 20)) { set_error("GPU seeding: a query with more than 2^20 seeds"); return MPA_ERR_UNSUPPORTED; }
+		const int64_t nl_q = jfirst[(size_t)q + 1] - jfirst[(size_t)q];
+		if (nl_q > (1 << 20)) { set_error("GPU seeding: a query with more than 2^20 seeds"); return MPA_ERR_UNSUPPORTED; }
 		const int64_t ns = std::min<int64_t>((na + seg_target - 1) / seg_target, n_block);
 		for (int64_t k = 0; k < ns; ++k) {
 			const uint32_t lo = (uint32_t)((uint64_t)n_block * (uint64_t)k / (uint64_t)ns), hi = (uint32_t)((uint64_t)n_block * (uint64_t)(k + 1) / (uint64_t)ns);
-			if (hi > lo) segs.push_back(SiftSeg{ q, lo, hi, 0 });
+			if (hi > lo) {
+				if (n_cur > INT32_MAX - nl_q) { set_error("GPU seeding: too many (segment, seed) cursors in one batch"); return MPA_ERR_UNSUPPORTED; }
+				segs.push_back(SiftSeg{ q, lo, hi, (int32_t)n_cur });
+				n_cur += nl_q;
+			}
 		}
 	}
 	qseg[(size_t)n_query] = (int32_t)segs.size();
@@ -492,7 +498,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	if ((rc = B.h_meta.ensure(meta_bytes))) return rc;
 	char *hm = B.h_meta.as<char>();
 	memcpy(hm, qfirst, meta_q), memcpy(hm + off_jf, jfirst.data(), meta_q), memcpy(hm + off_seg, segs.data(), seg_bytes), memcpy(hm + off_qs, qseg.data(), ((size_t)n_query + 1) * 4);
-	if ((rc = B.s_meta.ensure(meta_bytes)) || (rc = B.s_cur.ensure((size_t)n_jobs * 4)) || (rc = B.s_cur2.ensure((size_t)n_jobs * 4)) ||
+	if ((rc = B.s_meta.ensure(meta_bytes)) || (rc = B.s_cur.ensure((size_t)n_cur * 4 + 16)) || (rc = B.s_cur2.ensure((size_t)n_cur * 4 + 16)) ||
 	    (rc = B.s_kept.ensure((size_t)n_seg * 4)) || (rc = B.s_base.ensure((size_t)n_seg * 8)) || (rc = B.s_out.ensure(((size_t)n_seg + 1) * 8)) ||
 	    (rc = B.s_flag.ensure((size_t)n_query * 4 + 16)) || (rc = B.pf_qfirst2.ensure(meta_q)) || (rc = B.cfirst.ensure(meta_q)) ||
 	    (rc = B.key[0].ensure((size_t)n * 8)) || (rc = B.key[1].ensure((size_t)n * 8)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;

@@ -1305,18 +1305,25 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 
 // Several mini-batches as a three-stage software pipeline: [seed..plan of batch k+1] | [DP rounds of batch k on the GPU]
 // | [flatten + format batch k-1].  Each stage is one host thread driving its own worker-pool lane.
+// claim != nullptr: the job's batches are handed out by the caller -- claim(user) returns the index (into batches[]) of the next
+// batch this call should map, or -1 when the job has none left -- so that several callers (one process per GPU) can share one
+// job and each takes work as fast as it gets through it (the kt_for work stealing of map.c:264-271, between processes).
+// results / text / text_len are then in CLAIM order, order[j] says which batch slot j holds, *n_mapped how many there are.
 static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
-                    const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
+                    const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len,
+                    mpa_claim_fn claim = nullptr, void *claim_user = nullptr, int32_t *n_mapped = nullptr, int32_t *order = nullptr)
 {
 	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
 	g_trace_t0 = now_ms();
-	struct Slot { mpa_batch_t *b = nullptr; bool seeded = false, begun = false, dp_done = false; };
+	struct Slot { mpa_batch_t *b = nullptr; int32_t g = 0; bool seeded = false, begun = false, dp_done = false; };   // g: index into batches[]
 	std::vector<Slot> slot((size_t)n_batches);
-	std::mutex mu;
+	std::mutex mu, claim_mu;
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK, next_seed = 0, next_plan = 0;
+	int32_t n_total = n_batches;                          // batches this call maps: shrinks to the number claimed when the job runs out (guarded by mu)
+	if (n_mapped) *n_mapped = 0;
 	std::string err;
 	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so four
 	// lanes fit next to the seeding streams; measured at config 3 (20 000 proteins in 10 batches, two planners, two seeders):
@@ -1359,15 +1366,22 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		tl_pool_lane = sd == 0 ? 1 : 5 + sd, tl_thread_div = 4;
 		for (;;) {
 			int32_t k;
+			{	// (claims are serialised among the seeders, outside the pipeline's own lock: a claim may be a round trip to another process)
+				std::lock_guard<std::mutex> cl(claim_mu);
+				{ std::lock_guard<std::mutex> g(mu); if (next_seed >= n_total || rc_all != MPA_OK) return; }
+				const int32_t want = claim ? claim(claim_user) : 0;
+				std::lock_guard<std::mutex> g(mu);
+				if (claim && (want < 0 || want >= n_batches)) { n_total = next_seed; cv.notify_all(); return; }   // the job has no batch left
+				k = next_seed++;                                      // (a free seeder takes the next batch in input order)
+				slot[k].g = claim ? want : k;
+			}
 			{	// its result lives in a seeding context until the batch is planned: wait for the batch that had this context before
 				std::unique_lock<std::mutex> g(mu);
-				if (next_seed >= n_batches) return;
-				k = next_seed++;                                      // (a free seeder takes the next batch in input order)
 				cv.wait(g, [&] { return rc_all != MPA_OK || k < n_seed_ctx || slot[k - n_seed_ctx].begun; });
 				if (rc_all != MPA_OK) return;
 			}
 			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "begin");
-			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &batches[k], n_threads);
+			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &batches[slot[k].g], n_threads);
 			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1383,10 +1397,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			int32_t k;
 			{	// stay a bounded number of batches ahead of the ones in their DP rounds (planned batches hold their windows and tasks)
 				std::unique_lock<std::mutex> g(mu);
-				if (next_plan >= n_batches) return;
+				if (next_plan >= n_total) return;
 				k = next_plan++;
-				cv.wait(g, [&] { return rc_all != MPA_OK || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1 + plan_ahead); });
-				if (rc_all != MPA_OK) return;
+				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1 + plan_ahead); });
+				if (rc_all != MPA_OK || k >= n_total) return;       // (k >= n_total: the job ran out before this slot was claimed)
 			}
 			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "begin");
 			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
@@ -1403,13 +1417,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
-				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].dp_done; });
-				if (!slot[k].dp_done) return;
+				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].dp_done; });
+				if (k >= n_total || !slot[k].dp_done) return;
 			}
 			trace("finish", k, "begin");
 			results[k] = mpa_batch_finish(slot[k].b);
 			slot[k].b = nullptr;
-			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], id_io, &text[k]);
+			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[slot[k].g], names[slot[k].g], results[k], id_io, &text[k]);
 			trace("finish", k, "end");
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("output stage: ") + e.what()); } });
@@ -1424,14 +1438,14 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			int32_t k;
 			{
 				std::unique_lock<std::mutex> g(mu);
-				if (next_dp >= n_batches) return;
+				if (next_dp >= n_total) return;
 				k = next_dp++;
-				cv.wait(g, [&] { return rc_all != MPA_OK || slot[k].begun; });
-				if (rc_all != MPA_OK) return;
+				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].begun; });
+				if (rc_all != MPA_OK || k >= n_total) return;
 			}
 			static const char *const lane_name[6] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5" };
 			trace(lane_name[d], k, "begin");
-			const int rc = run_dp_rounds(cd, mi, &batches[k], slot[k].b);
+			const int rc = run_dp_rounds(cd, mi, &batches[slot[k].g], slot[k].b);
 			trace(lane_name[d], k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1448,6 +1462,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();
 	ctx_absorb_sibling_stats(ctx);
+	if (rc_all == MPA_OK) {
+		if (n_mapped) *n_mapped = n_total;
+		if (order) for (int32_t k = 0; k < n_total; ++k) order[k] = slot[k].g;
+	}
 	if (rc_all != MPA_OK) {
 		for (Slot &sl : slot) delete sl.b;
 		for (int32_t k = 0; k < n_batches; ++k) {
@@ -1463,6 +1481,14 @@ int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
 {
 	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batches_impl(ctx, mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len); });
+}
+
+int mpa_map_batches_claim(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                          const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len,
+                          mpa_claim_fn claim, void *user, int32_t *n_mapped, int32_t *order)
+{
+	if (!claim || !n_mapped || !order) { set_error("mpa_map_batches_claim: claim, n_mapped and order are required"); return MPA_ERR_ARG; }
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batches_impl(ctx, mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len, claim, user, n_mapped, order); });
 }
 
 static int mpa_map_batch_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_seed_gather_kept(const SeedJobDev *jobs
 #define SIFT_CAP 2048                                     /* anchors per LDS buffer (8 KB) */
 #define SIFT_CARRY_MAX 1024                               /* anchors that may wait for the next range */
 #define SIFT_TARGET 1280u                                 /* anchors a range is sized for */
-struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t pad; };     // blocks [lo, hi) of query qid
+struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t cur_off; }; // blocks [lo, hi) of query qid; cur_off: the segment's own cursors (one per list of the query)
 
 __device__ __forceinline__ uint32_t sift_wave_sum(uint32_t v)
 {
@@ -481,6 +481,7 @@ __global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs,
 	const uint32_t lmask = (1u << LB) - 1u;
 	const uint32_t w_max = (LB >= 31 ? 1u : (1u << (32 - LB))) - 2u;           // widest range whose local block numbers fit next to LB list bits
 	const uint32_t lo0 = sg.lo, hi0 = sg.hi;
+	const int64_t c0s = sg.cur_off;                            // this segment's cursors: segments of one query run side by side
 
 	// ---- cursors at the segment's first block; rank base; is there an anchor in block lo0 - 1?
 	uint32_t below = 0, left_nb = 0;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs,
 			c = d_lower_bound(list, s.cnt, (uint64_t)lo0);
 			if (c > 0 && list[c - 1] == lo0 - 1) left_nb = 1;
 		}
-		cur[j0 + l] = c;
+		cur[c0s + l] = c;
 		below += (uint32_t)c;
 	}
 	const uint32_t pos_base = sift_block_sum(below, scr);
@@ -515,9 +516,9 @@ __global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs,
 			uint32_t mine = 0;
 			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
 				const SeedJobDev s = jobs[j0 + l];
-				const int32_t c0 = cur[j0 + l];
+				const int32_t c0 = cur[c0s + l];
 				const int32_t c1 = sift_advance(kb + s.kb_off, c0, s.cnt, hi);
-				cur2[j0 + l] = c1;
+				cur2[c0s + l] = c1;
 				mine += (uint32_t)(c1 - c0);
 			}
 			total = sift_block_sum(mine, scr);
@@ -532,12 +533,12 @@ __global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs,
 		if (t == 0) fill = n_carry;
 		__syncthreads();
 		for (int32_t l = t; l < nl; l += SIFT_THREADS) {
-			const int32_t c0 = cur[j0 + l], c1 = cur2[j0 + l];
+			const int32_t c0 = cur[c0s + l], c1 = cur2[c0s + l];
 			if (c1 > c0) {
 				const uint32_t *list = kb + jobs[j0 + l].kb_off;
 				uint32_t slot = atomicAdd(&fill, (uint32_t)(c1 - c0));
 				for (int32_t c = c0; c < c1; ++c) keys[slot++] = ((list[c] - lo + 1u) << LB) | (uint32_t)l;
-				cur[j0 + l] = c1;
+				cur[c0s + l] = c1;
 			}
 		}
 		const uint32_t n = n_carry + total;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs,
 		if (last && hi0 < n_block) {                            // is there an anchor in block hi0 (it belongs to the next segment)?
 			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
 				const SeedJobDev s = jobs[j0 + l];
-				const int32_t c = cur[j0 + l];
+				const int32_t c = cur[c0s + l];
 				if (c < s.cnt && kb[s.kb_off + c] == hi0) right_nb = 1;
 			}
 			right_nb = sift_block_sum(right_nb, scr) ? 1u : 0u;

@@ -47,6 +47,9 @@ def test_genome_scale_batch_with_default_thresholds(ctx, tmp_path, monkeypatch, 
     for v in ("MPA_GPU_SEED", "MPA_GPU_REFINE"):
         monkeypatch.delenv(v, raising=False)
     monkeypatch.setenv("MPA_TIMING", "1")
+    # k_seed_sift cuts a query into segments of ~49 k anchors, which only queries against a 3 Gbp genome have; here (~7 k anchors
+    # per query) the segment size is lowered so that every query is swept by four or five workgroups side by side, as there
+    monkeypatch.setenv("MPA_SIFT_SEG", "1500")
     contigs, prots, names = gen_synth.generate(360_000_000, 3, 3300, 5, mu=8.0, sigma=1.6, imax=190000, n_frac=0.05, paralog_frac=0.02)
     idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(3)])
     del contigs

@@ -90,10 +90,10 @@ def test_prefilter_across_block_ranges(monkeypatch):
     mo = mpa.default_mapopt()
     mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
     off_h, a_h = survivors(None, idx, mo, q, threads=16)
-    for mode, seg in (("sort", None), ("census", None), ("sift", None), ("sift", "2000")):
+    for mode, seg in (("sort", None), ("census", None), ("sift", None), ("sift", "2000"), ("sift", "256")):
         monkeypatch.setenv("MPA_SEED_MODE", mode)
         if seg:
-            monkeypatch.setenv("MPA_SIFT_SEG", seg)          # ~20 segments per query: segment boundaries all over the genome
+            monkeypatch.setenv("MPA_SIFT_SEG", seg)          # 2 / ~12 segments per query, swept side by side: boundaries all over the genome
         off_d, a_d = survivors(ctx, idx, mo, q, threads=16)
         assert np.array_equal(off_h, off_d), (mode, seg)
         assert np.array_equal(a_h, a_d), (mode, seg)

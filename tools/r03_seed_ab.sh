@@ -8,10 +8,10 @@ mkdir -p $OUT
 WL=/dev/shm/mpa_wl
 # 1. GPU tests (seeding first: the new kernel)
 (time timeout 900 python -m pytest tests/test_seed_gpu.py -m gpu -q -x) > $OUT/pytest_seed.log 2>&1; tail -3 $OUT/pytest_seed.log
-(time timeout 1200 python -m pytest tests -m gpu -q --deselect tests/test_seed_gpu.py) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+(time timeout 1200 python -m pytest tests/test_scale_gpu.py tests/test_map_gpu.py -m gpu -q) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 # 2. config 3: sort (with the reference run: identity), census, sift
-for mode in sort census sift; do
-  extra="--no-cpu-baseline"; [ $mode = sort ] && extra=""
+for mode in ${MODES:-sift}; do
+  extra="--no-cpu-baseline"; [ $mode = ${REFMODE:-sift} ] && extra=""
   ( MPA_SEED_MODE=$mode MPA_TIMING=1 timeout 900 python bench.py --steps 20 --warmup 5 --no-extra --workload-cache $WL $extra ) > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err
   python tools/timing_agg.py < $OUT/bench_$mode.err > $OUT/timing_$mode.txt; rm -f $OUT/bench_$mode.err
   python tools/bench_line.py $mode $OUT/bench_$mode.json
@@ -19,7 +19,7 @@ for mode in sort census sift; do
 done
 # 2b. with cheap seeding, what do the pipeline knobs do?  (same cached workload, md5 must stay)
 k=0
-for spec in "MPA_TRACE=1" "MPA_DP_LANES=6" "MPA_SEEDERS=1" "MPA_PLANNERS=3" "MPA_DP_LANES=6 MPA_PLANNERS=3"; do
+for spec in "MPA_TRACE=1" "MPA_DP_LANES=6" "MPA_SEEDERS=1" "MPA_PLANNERS=3" "MPA_DP_LANES=6 MPA_PLANNERS=3" "MALLOC_MMAP_THRESHOLD_=4294967296 MALLOC_TRIM_THRESHOLD_=17179869184 MALLOC_ARENA_MAX=64"; do
   ( env $spec timeout 600 python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --workload-cache $WL ) > $OUT/knob$k.json 2> $OUT/knob$k.err
   python tools/bench_line.py "$spec" $OUT/knob$k.json
   [ $k = 0 ] && python tools/gantt.py $OUT/knob0.err > $OUT/gantt_sift.txt 2>&1
