@@ -15,9 +15,13 @@ output line of every timed step is compared with the reference's output for the 
     python bench.py                                    # N=1, config 3, 80 steps (16 passes over the 20 000 proteins, ~11 s timed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
-N>1 (BASELINE.json configs[3]): the SAME job -- the same K mini-batches of the same proteins -- dealt round-robin over the ranks
-(one process per GPU, index replicated, no collective on the data path), output gathered to rank 0 over RCCL in input order
-(miniprot_amd/dist.py): strong scaling.  Rank 0 builds genome and index once; the other ranks restore the .mpi from /dev/shm.
+N>1 (BASELINE.json configs[3]): per-GPU work is fixed (weak scaling): the job is N x K mini-batches of the same 20 000 proteins
+(batch j of the job = distinct mini-batch j mod 5), shared by the N ranks -- one process per GPU, index replicated, no collective on
+the data path.  The deal is dynamic: every rank's pipeline claims the next unclaimed batch of the job from a shared counter whenever
+it has room for one (mpa_map_batches_claim + miniprot_amd/dist.py; the work stealing of map.c:264-271, between processes); the
+output is gathered to rank 0 over RCCL in job order and every line of it is compared with the reference's (`paf_identical`, at any
+N).  `value` = aligned residues of all N x K batches / elapsed.  Rank 0 builds genome and index once; the other ranks restore the
+.mpi from /dev/shm.
 `--config 2` / `--config 5` run the 50 Mbp x 1k and the long-intron (-G 500k) workloads instead; at N=1 they are also
 recorded as extra keys of the config-3 line unless --no-extra.  Prints ONE JSON line on rank 0.
 """
@@ -309,20 +313,24 @@ def main():
                     res_of[k % nb] = aligned_residues(t)
                 residues += res_of[k % nb]
             one_pass = b"".join(texts[k] for k in range(min(nb, len(texts))))
-            cpu, identical = None, None
+            cpu, identical, ident = None, None, None
             if with_cpu and not a.no_cpu_baseline:
+                # the reference itself on this box's host cores, outside the timed region: every output line of every timed step of
+                # every rank is compared with it (at any N); its timing is the CPU baseline, reported at N = 1 only
                 cpu, per = wl.reference(ncpu)
                 if cpu is not None:
                     bad = [k for k, t in enumerate(texts) if t != per[k % nb]]
                     identical = not bad
-                    cpu["paf_identical"] = identical
-                    cpu["lines_compared"] = sum(t.count(b"\n") for t in texts)
-                    cpu["first_differing_step"] = bad[0] if bad else None
+                    ident = {"paf_identical": identical, "lines_compared": sum(t.count(b"\n") for t in texts), "first_differing_step": bad[0] if bad else None,
+                             "reference_md5": cpu["md5"]}
+                    cpu.update(ident)
+                    if world > 1:
+                        cpu = None
             rec = {"workload": cfg["name"] + ("" if a.scale == 1.0 else " [SCALED x%g: not the named config]" % a.scale),
-                   "value": residues / elapsed, "elapsed_s": elapsed, "steps": steps, "ms_per_step": elapsed / max(steps, 1) * 1e3,
+                   "value": residues / elapsed, "elapsed_s": elapsed, "steps": steps, "steps_all_gpus": len(texts), "ms_per_step": elapsed / max(steps, 1) * 1e3,
                    "proteins_per_step": cfg["batch"], "distinct_mini_batches": nb, "aligned_residues": residues,
-                   "input_residues_per_s": sum(len(p) for k in range(steps) for p in wl.batches[k % nb].seqs) / elapsed,
-                   "md5_first_pass": hashlib.md5(one_pass).hexdigest() if len(texts) >= nb else None, "paf_identical": identical,
+                   "input_residues_per_s": sum(len(p) for k in range(len(texts)) for p in wl.batches[k % nb].seqs) / elapsed,
+                   "md5_first_pass": hashlib.md5(one_pass).hexdigest() if len(texts) >= nb else None, "paf_identical": identical, "identity": ident,
                    "roofline": roofline_record(st, elapsed, world), "cpu_baseline": cpu,
                    "dp_cells": {"ext": st["cells_ext"], "glob": st["cells_glob"]},
                    "gcups_wall": (st["cells_ext"] + st["cells_glob"]) / elapsed / 1e9,
@@ -330,7 +338,7 @@ def main():
                    "host_threads_per_rank": n_threads,
                    # CPU seconds (user + system, getrusage) all ranks' processes spent inside the timed region, per step and as a share of
                    # the host: what one GPU's pipeline costs the host it shares with the other ranks
-                   "host_cpu_s_per_step": st["host_cpu_s"] / max(steps, 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9)}
+                   "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9)}
         ctx.close()
         wl.idx.close()
         barrier()
@@ -338,7 +346,7 @@ def main():
             shutil.rmtree(share, ignore_errors=True)
         return rec
 
-    main_rec = run_config(a.config, a.steps, a.warmup, with_cpu=(world == 1))
+    main_rec = run_config(a.config, a.steps, a.warmup, with_cpu=True)
     extra = {}
     if world == 1 and a.config == 3 and not a.no_extra and a.scale == 1.0:
         for cid, (k, w) in ((2, (40, 4)), (5, (8, 4))):
@@ -354,12 +362,13 @@ def main():
         r = main_rec
         out = {"metric": "aligned protein residues/sec (whole node), 3 Gbp genome x 20k proteins" if a.config == 3 and a.scale == 1.0 else "aligned protein residues/sec (whole node)",
                "value": r["value"], "unit": "aligned residues/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"],
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
                "config": {"workload": r["workload"], "proteins_per_step": r["proteins_per_step"], "distinct_mini_batches": r["distinct_mini_batches"],
-                          "parallelism": "mini-batches dealt round-robin over %d GPU(s), index replicated, text gathered to rank 0" % world,
+                          "parallelism": "one job of %d x %d mini-batches; every rank's pipeline claims the next unclaimed batch from a shared counter (dynamic deal), "
+                                         "index replicated on %d GPU(s), no collective on the data path, text gathered to rank 0 in job order" % (world, a.steps, world),
                           "batching": "stream of mini-batches (mpa_map_batches)", "host_threads_per_rank": r["host_threads_per_rank"]},
                "elapsed_s": r["elapsed_s"], "aligned_residues": r["aligned_residues"], "input_residues_per_s": r["input_residues_per_s"],
-               "paf_identical": r["paf_identical"], "md5_first_pass": r["md5_first_pass"],
+               "paf_identical": r["paf_identical"], "identity": r["identity"], "md5_first_pass": r["md5_first_pass"], "steps_all_gpus": r["steps_all_gpus"],
                "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"],
                "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
         out.update(extra)

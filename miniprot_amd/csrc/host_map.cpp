@@ -106,7 +106,8 @@ public:
 	// never destroyed: workers outlive main().  One pool per lane, so that the pipeline stages of mpa_map_batches()
 	// (seeding of the next batch / DP-round bookkeeping / flattening + formatting of the previous one) can each run
 	// their own parallel region at the same time.
-	static WorkerPool &get(int lane) { static WorkerPool *p[8] = { new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool(), new WorkerPool() }; return *p[lane]; }
+	static const int kPools = 24;
+	static WorkerPool &get(int lane) { static WorkerPool *p = new WorkerPool[kPools]; return p[lane % kPools]; }
 	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
 		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
 		std::unique_lock<std::mutex> run_lock(run_mu_);              // one parallel region at a time
@@ -1330,7 +1331,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// 3 lanes 0.91 s, 4 lanes 0.865 s; with one planner and one seeder the host stages bound the stream (1.00 s, any lane count)
 	int n_lanes = 4;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
-	n_lanes = std::max(1, std::min(n_lanes, 6));
+	n_lanes = std::max(1, std::min(n_lanes, 8));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
 	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
@@ -1342,12 +1343,12 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// the end of planning: the result of batch k is consumed while batches k+1 .. are on the device.
 	int n_plan = 2;
 	if (const char *e = getenv("MPA_PLANNERS")) n_plan = atoi(e);
-	n_plan = std::max(1, std::min(n_plan, 3));
+	n_plan = std::max(1, std::min(n_plan, 6));
 	// Seeders: the device-seeding stage of a batch is mostly waiting for its kernels, which share the GPU with the DP rounds in
 	// flight; two batches are seeded side by side (MPA_SEEDERS, default 2)
 	int n_seed = 2;
 	if (const char *e = getenv("MPA_SEEDERS")) n_seed = atoi(e);
-	n_seed = std::max(1, std::min(n_seed, 3));
+	n_seed = std::max(1, std::min(n_seed, 4));
 	// Depth of the pipeline.  A seeding context is busy from the start of a batch's seeding to the end of its planning, and a
 	// planned batch waits for a DP lane: seeding of batch k waits for the plan of batch k - n_seed_ctx, the plan of batch k for
 	// the end of the DP of batch k - (lanes + planners).  MPA_SEED_CTX_EXTRA more contexts / MPA_PLAN_AHEAD more planned batches
@@ -1359,11 +1360,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	const int n_seed_ctx = n_plan + n_seed + seed_extra;
 	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
 	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
+	static const char *const kSeedName[4] = { "seed0", "seed1", "seed2", "seed3" };
+	static const char *const kPlanName[6] = { "plan0", "plan1", "plan2", "plan3", "plan4", "plan5" };
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
 	auto seeder_body = [&](int sd) { try {
-		tl_pool_lane = sd == 0 ? 1 : 5 + sd, tl_thread_div = 4;
+		tl_pool_lane = 10 + sd, tl_thread_div = 4;
 		for (;;) {
 			int32_t k;
 			{	// (claims are serialised among the seeders, outside the pipeline's own lock: a claim may be a round trip to another process)
@@ -1380,9 +1383,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || k < n_seed_ctx || slot[k - n_seed_ctx].begun; });
 				if (rc_all != MPA_OK) return;
 			}
-			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "begin");
+			trace(kSeedName[sd], k, "begin");
 			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &batches[slot[k].g], n_threads);
-			trace(sd == 0 ? "seed0" : sd == 1 ? "seed1" : "seed2", k, "end");
+			trace(kSeedName[sd], k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].b = b, slot[k].seeded = true;
@@ -1392,7 +1395,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<std::thread> seeders;
 	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
 	auto planner_body = [&](int pl) { try {
-		tl_pool_lane = pl == 0 ? 3 : 3 + pl, tl_thread_div = n_plan;
+		tl_pool_lane = 14 + pl, tl_thread_div = n_plan;
 		for (;;) {
 			int32_t k;
 			{	// stay a bounded number of batches ahead of the ones in their DP rounds (planned batches hold their windows and tasks)
@@ -1402,9 +1405,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || (slot[k].seeded && k <= n_dp_done + n_lanes + n_plan - 1 + plan_ahead); });
 				if (rc_all != MPA_OK || k >= n_total) return;       // (k >= n_total: the job ran out before this slot was claimed)
 			}
-			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "begin");
+			trace(kPlanName[pl], k, "begin");
 			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
-			trace(pl == 0 ? "plan0" : pl == 1 ? "plan1" : "plan2", k, "end");
+			trace(kPlanName[pl], k, "end");
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].begun = true, ++n_planned;
 			cv.notify_all();
@@ -1413,7 +1416,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<std::thread> planners;
 	for (int pl = 0; pl < n_plan; ++pl) planners.emplace_back(planner_body, pl);
 	std::thread finisher([&] { try {
-		tl_pool_lane = 2, tl_thread_div = 4;
+		tl_pool_lane = 1, tl_thread_div = 4;
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
@@ -1433,7 +1436,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// a lane that is free takes the next batch in input order (a static deal would leave lanes idle behind a slow batch)
 	int32_t next_dp = 0;
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
-		tl_thread_div = 4;
+		tl_pool_lane = 2 + d, tl_thread_div = 4;
 		for (;;) {
 			int32_t k;
 			{
@@ -1443,7 +1446,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].begun; });
 				if (rc_all != MPA_OK || k >= n_total) return;
 			}
-			static const char *const lane_name[6] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5" };
+			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
 			trace(lane_name[d], k, "begin");
 			const int rc = run_dp_rounds(cd, mi, &batches[slot[k].g], slot[k].b);
 			trace(lane_name[d], k, "end");
@@ -1457,7 +1460,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
-	tl_thread_div = 1;
+	tl_thread_div = 1, tl_pool_lane = 0;                   // (lane 0 ran on the caller's thread)
 	finisher.join();
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();

@@ -34,6 +34,22 @@ for tag, flag in (("paf", 0x4), ("gff", 0x4 | 0x8), ("gtf", 0x4 | 0x20)):
                                      lambda k, r: r.n_output(mo, batches[k]), lambda k, r, id0: mpa.format_output(idx, mo, batches[k], r, id0)[0])
     if rank == 0:
         open(sys.argv[2] + "." + tag, "wb").write(b"".join(texts))
+    # the dynamic deal: both ranks pull batch indices from the shared counter until the job is exhausted (whoever is faster maps
+    # more); the gathered output does not depend on who mapped what
+    def map_claimed(claim):
+        ks, rs = [], []
+        while True:
+            k = claim()
+            if k < 0:
+                break
+            ks.append(k)
+            rs += map_mine([k])
+        return ks, rs
+    texts, n_ids = mdist.run_sharded(len(batches), rank, world, torch.device("cpu"), needs_ids, None,
+                                     lambda k, r: r.n_output(mo, batches[k]), lambda k, r, id0: mpa.format_output(idx, mo, batches[k], r, id0)[0],
+                                     map_claimed=map_claimed)
+    if rank == 0:
+        open(sys.argv[2] + "." + tag + ".dyn", "wb").write(b"".join(texts))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -70,6 +86,7 @@ def test_two_rank_gloo_job_equals_single_process(tmp_path, oracle_built):
         single = mpa.format_output(idx, mo, q, map_batch_result(idx, mo, q, oracle_executor))[0]
         got = open(out + "." + tag, "rb").read()
         assert got == single, tag
+        assert open(out + "." + tag + ".dyn", "rb").read() == single, tag + " (dynamic deal)"
         if tag == "gff":                                        # the ids really do run across the ranks' batches
             ids = [l.split(b"ID=MP")[1][:6] for l in got.split(b"\n") if b"\tmRNA\t" in l]
             assert len(ids) > 5 and ids == [b"%06d" % (k + 1) for k in range(len(ids))]
