@@ -102,11 +102,26 @@ struct mpa_ctx_s {
 	size_t tb_budget = (size_t)8 << 30;       // bytes of traceback matrix per k_glob launch
 	std::vector<mpa_ctx_s*> siblings;         // extra contexts on the same device for concurrent sub-batches (owned)
 	SeedBufs seed;                            // buffers of the GPU seeding stage (seed_exec.hip)
+	hipEvent_t wait_ev = nullptr;             // blocking-sync event: a host thread that waits for the device SLEEPS (wait_stream)
 	int side_off = 0;                         // first side stream a round uses (lets the DP lanes of a stream of batches sit on different hardware queues)
 	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
 };
 
 namespace mpa {
+
+// Wait for everything enqueued on a stream -- asleep.  hipStreamSynchronize() spins on the completion signal by default; a
+// pipeline keeps eight or nine host threads waiting for the device at any time (DP lanes, seeders, planners), and on a host
+// that gives the process a CPU quota (16 cores per GPU on the boxes this was measured on) spinning waiters eat the very cores
+// the host stages need.  An event created with hipEventBlockingSync makes the runtime block on the signal instead.
+// MPA_SPIN_WAIT=1 restores the spinning wait.
+static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
+{
+	static const bool spin = [] { const char *e = getenv("MPA_SPIN_WAIT"); return e && atoi(e) != 0; }();
+	if (spin || !ctx->wait_ev) return hipStreamSynchronize(s);
+	hipError_t e = hipEventRecord(ctx->wait_ev, s);
+	if (e != hipSuccess) return e;
+	return hipEventSynchronize(ctx->wait_ev);
+}
 
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 {
@@ -283,6 +298,7 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreate(&ctx->fork_ev) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
 	if (!ok) {                                            // a null handle would silently alias the legacy default stream
 		set_error("creating the context's HIP streams/events failed");
 		mpa_ctx_destroy(ctx);
@@ -311,6 +327,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+	if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
 	for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
 	if (ctx->seed_stream && ctx->seed_stream != ctx->stream) (void)hipStreamDestroy(ctx->seed_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -375,7 +392,7 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	HIP_TRY(hipMemcpyAsync(B.pf_jfirst.p, jfirst.data(), ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(B.pf_err.p, 0, 16, s));
 	HIP_TRY(ensure_dynamic_lds((const void*)k_seed_prefilter, ctx->device, PF_LDS));
-	HIP_TRY(hipStreamSynchronize(s));                       // (jfirst is a local)
+	HIP_TRY(wait_stream(ctx, s));                       // (jfirst is a local)
 	hipLaunchKernelGGL(k_seed_prefilter, dim3((unsigned)n_part, (unsigned)n_query), dim3(PF_THREADS), PF_LDS, s, B.jobs.as<SeedJobDev>(), B.pf_jfirst.as<int64_t>(), d->kb,
 	                   n_part, B.pf_w.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_err.as<int32_t>());
 	HIP_TRY(hipGetLastError());
@@ -391,7 +408,7 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	int32_t kerr = 0;
 	HIP_TRY(hipMemcpyAsync(qfirst2.data(), B.pf_qfirst2.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(&kerr, B.pf_err.p, 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	if (kerr) { set_error("k_seed_prefilter: a block id past the last range"); return MPA_ERR_HIP; }
 	const int64_t n2 = qfirst2[(size_t)n_query];
 	timing_note("    seed: pre-sort filter (wait)", now_ms() - t_begin);
@@ -420,7 +437,7 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	HIP_TRY(hipGetLastError());
 	const double t_issued = now_ms();
 	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const double t_kernels = now_ms();
 	const int64_t m = out.cfirst[n_query];
 	out.m = m;
@@ -434,7 +451,7 @@ static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_
 	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
 	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
 	timing_note("    seed: compact + download", now_ms() - t_kernels);
@@ -518,7 +535,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	int32_t *h_flag = (int32_t*)(h_cfirst + (n_query + 1));
 	HIP_TRY(hipMemcpyAsync(h_qfirst2, B.pf_qfirst2.p, meta_q, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(h_flag, B.s_flag.p, (size_t)n_query * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const double t_sift = now_ms();
 	timing_note("    seed: segments + sift (wait)", t_sift - t_begin);
 	int32_t n_declined = 0;
@@ -548,7 +565,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	                   B.cfirst.as<int64_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(h_cfirst, B.cfirst.p, meta_q, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const double t_kernels = now_ms();
 	memcpy(out.cfirst.data(), h_cfirst, meta_q);
 	const int64_t m = out.cfirst[n_query];
@@ -559,7 +576,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	hipLaunchKernelGGL((k_seed_compact<uint64_t, true>), dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(),
 	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), B.h_pos.as<int32_t>(), B.h_f.as<int32_t>(), B.h_pred.as<int32_t>(), B.h_a.as<uint64_t>());
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
 	timing_note("    seed: compact into pinned memory", now_ms() - t_kernels);
 	return MPA_OK;
@@ -657,7 +674,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	HIP_TRY(hipGetLastError());
 	const double t_issued = now_ms();
 	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const double t_kernels = now_ms();
 	const int64_t m = out.cfirst[n_query];
 	out.m = m;
@@ -671,7 +688,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
 	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
 	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
@@ -729,7 +746,7 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	uint32_t last_cnt = 0;
 	HIP_TRY(hipMemcpyAsync(&last_off, b_off.as<uint64_t>() + (n_chunk - 1), 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(&last_cnt, b_count.as<uint32_t>() + (n_chunk - 1), 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const int64_t n_keys = (int64_t)(last_off + last_cnt);
 	if (n_keys == 0) { mi->ki.assign(n_bucket, 0), mi->kb.clear(), mi->n_kb = 0; return MPA_OK; }
 	{	// two key buffers, flags, scan, kb: ~40 bytes per key
@@ -766,7 +783,7 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	uint32_t last_flag = 0;
 	HIP_TRY(hipMemcpyAsync(&last_idx, b_idx.as<uint64_t>() + (n_keys - 1), 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(&last_flag, b_flag.as<uint32_t>() + (n_keys - 1), 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	const int64_t n_kb = (int64_t)(last_idx + last_flag);
 	uint32_t *d_kb = nullptr;
 	HIP_TRY(hipMalloc((void**)&d_kb, (size_t)n_kb * 4 + 16));
@@ -785,7 +802,7 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	std::vector<uint32_t> kb_new((size_t)n_kb);
 	HIP_TRY(hipMemcpyAsync(ki_new.data(), b_ki.p, n_bucket * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(kb_new.data(), d_kb, (size_t)n_kb * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	mi->ki.swap(ki_new), mi->kb.swap(kb_new), mi->n_kb = n_kb;
 	if (d->kb) (void)hipFree(d->kb);
 	d->kb = d_kb;                                          // stays resident for the seeding kernels
@@ -840,7 +857,7 @@ int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &cp, int32_t n_prob, con
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(io.f, B.c_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(io.pred, B.c_pred.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));                       // (first[] may be pageable memory of the caller: it is consumed by now)
+	HIP_TRY(wait_stream(ctx, s));                       // (first[] may be pageable memory of the caller: it is consumed by now)
 	return MPA_OK;
 }
 } // namespace mpa
@@ -870,42 +887,50 @@ int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_
 		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
 	}
 	hipStream_t s = ctx->seed_stream;
-	std::vector<RefineWindowDev> dw((size_t)n_win);
-	std::vector<RefineChunk> chunks;
-	int64_t n_pos = 0;
-	for (int64_t k = 0; k < n_win; ++k) {
-		dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
-		for (int32_t st = 0; st < wins[k].len; st += REFINE_CHUNK) chunks.push_back(RefineChunk{ (int32_t)k, st });
-		n_pos += wins[k].len;
-	}
-	if (chunks.empty()) return MPA_OK;
+	// windows, chunks, the queries' k-mer words: laid out in ONE pinned block and uploaded with one copy (pageable copies are
+	// staged by the runtime, synchronously and spinning)
+	int64_t n_pos = 0, n_chunk = 0;
+	for (int64_t k = 0; k < n_win; ++k) n_pos += wins[k].len, n_chunk += (wins[k].len + REFINE_CHUNK - 1) / REFINE_CHUNK;
+	if (n_chunk == 0) return MPA_OK;
 	const unsigned long long cap = (unsigned long long)(n_pos / 64 + (1 << 20));   // ~0.04 % of the positions hit on random sequence
 	const int64_t n_words = qw_first[n_query];
+	auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+	const size_t o_win = 0, o_chunk = al64((size_t)n_win * sizeof(RefineWindowDev)), o_qf = o_chunk + al64((size_t)n_chunk * sizeof(RefineChunk)),
+	             o_words = o_qf + al64(((size_t)n_query + 1) * 8), up_bytes = o_words + al64((size_t)n_words * 4 + 16);
 	int rc;
-	if ((rc = B.r_win.ensure(dw.size() * sizeof(RefineWindowDev))) || (rc = B.r_chunk.ensure(chunks.size() * sizeof(RefineChunk))) ||
-	    (rc = B.r_qfirst.ensure(((size_t)n_query + 1) * 8)) || (rc = B.r_words.ensure((size_t)n_words * 4 + 16)) ||
-	    (rc = B.r_hits.ensure((size_t)cap * 16)) || (rc = B.r_count.ensure(16))) return rc;
-	HIP_TRY(hipMemcpyAsync(B.r_win.p, dw.data(), dw.size() * sizeof(RefineWindowDev), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(B.r_chunk.p, chunks.data(), chunks.size() * sizeof(RefineChunk), hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(B.r_qfirst.p, qw_first, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(B.r_words.p, qwords, (size_t)n_words * 4, hipMemcpyHostToDevice, s));
+	if ((rc = B.h_meta.ensure(up_bytes + 64)) || (rc = B.r_win.ensure(up_bytes)) || (rc = B.r_hits.ensure((size_t)cap * 16)) || (rc = B.r_count.ensure(16)) ||
+	    (rc = B.h_back.ensure(64))) return rc;
+	char *hm = B.h_meta.as<char>();
+	{
+		RefineWindowDev *dw = (RefineWindowDev*)(hm + o_win);
+		RefineChunk *ch = (RefineChunk*)(hm + o_chunk);
+		int64_t c = 0;
+		for (int64_t k = 0; k < n_win; ++k) {
+			dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
+			for (int32_t st = 0; st < wins[k].len; st += REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
+		}
+		memcpy(hm + o_qf, qw_first, ((size_t)n_query + 1) * 8);
+		memcpy(hm + o_words, qwords, (size_t)n_words * 4);
+	}
+	HIP_TRY(hipMemcpyAsync(B.r_win.p, hm, up_bytes, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(B.r_count.p, 0, 16, s));
 	RefineTab rt;
 	for (int c = 0; c < 64; ++c) rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
 	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, nullptr, mi->l_seq };
 	const size_t lds = ((size_t)4 << hs_log2) + REFINE_CHUNK + 2 * REFINE_HALO;
-	HIP_TRY(hipStreamSynchronize(s));                       // (dw / chunks are locals)
-	hipLaunchKernelGGL(k_refine_scan, dim3((unsigned)chunks.size()), dim3(256), lds, s, dg, B.r_win.as<RefineWindowDev>(), B.r_chunk.as<RefineChunk>(),
-	                   B.r_qfirst.as<int64_t>(), B.r_words.as<uint32_t>(), rt, kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap);
+	const char *dm = B.r_win.as<char>();
+	hipLaunchKernelGGL(k_refine_scan, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk),
+	                   (const int64_t*)(dm + o_qf), (const uint32_t*)(dm + o_words), rt, kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap);
 	HIP_TRY(hipGetLastError());
-	unsigned long long n_hits = 0;
-	HIP_TRY(hipMemcpyAsync(&n_hits, B.r_count.p, 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	unsigned long long *h_n = B.h_back.as<unsigned long long>();
+	HIP_TRY(hipMemcpyAsync(h_n, B.r_count.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(wait_stream(ctx, s));
+	const unsigned long long n_hits = *h_n;
 	if (n_hits > cap) { set_error("refinement scan: more hits than the buffer holds"); return MPA_ERR_UNSUPPORTED; }
 	if (n_hits == 0) return MPA_OK;
 	if ((rc = B.h_rhits.ensure((size_t)n_hits * 16)) != MPA_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(B.h_rhits.p, B.r_hits.p, (size_t)n_hits * 16, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	// group by window (counting sort)
 	const uint4 *h = B.h_rhits.as<uint4>();
 	for (unsigned long long k = 0; k < n_hits; ++k) ++out.first[(size_t)h[k].x + 1];
@@ -1134,7 +1159,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		}
 		HIP_TRY(hipMemcpyAsync(d_hw, hw.data(), sizeof(GlobWave) * hw.size(), hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyAsync(d_hlist, huge_ids.data(), 4 * huge_ids.size(), hipMemcpyHostToDevice, s));
-		HIP_TRY(hipStreamSynchronize(s));                  // (hw is a local; the calls are rare)
+		HIP_TRY(wait_stream(ctx, s));                  // (hw is a local; the calls are rare)
 	}
 
 	DevTables tabs;
@@ -1332,7 +1357,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		}
 		if (!concurrent) {                                                // join everything before the buffers (and their staging) are reused
 			for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
-			HIP_TRY(hipStreamSynchronize(s));
+			HIP_TRY(wait_stream(ctx, s));
 			float a = 0, b = 0;                                              // (the previous chunk's sweep and walk)
 			(void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
 			(void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
@@ -1406,7 +1431,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	}
 	if (n_split) HIP_TRY(hipMemcpyAsync(hdn + dn_err, wa.err, 4, hipMemcpyDeviceToHost, s));
 	mark("    dp: round enqueued");
-	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(wait_stream(ctx, s));
 	mark("    dp: round (wait)");
 	if (glob_timed) {
 		float a = 0, b = 0;
@@ -1451,7 +1476,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		                   ctx->ncig.as<int32_t>(), ctx->cig.as<uint32_t>(), ctx->cigd.as<uint32_t>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(ctx->h_pool.p, ctx->cigd.p, (size_t)pool_n * 4, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
+		HIP_TRY(wait_stream(ctx, s));
 		memcpy(pool, ctx->h_pool.p, (size_t)pool_n * 4);
 	}
 	{

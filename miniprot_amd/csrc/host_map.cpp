@@ -130,7 +130,10 @@ private:
 			workers_.back().detach();
 		}
 	}
-	void work() { for (;;) { int64_t i = next_.fetch_add(1); if (i >= n_) break; (*fn_)(i); } }
+	void work() { CpuSpan cs(label_); for (;;) { int64_t i = next_.fetch_add(1); if (i >= n_) break; (*fn_)(i); } }
+public:
+	const char *label_ = "pool (outside a stream)";     // what the CPU time of this pool's parallel regions is booked under (MPA_TIMING)
+private:
 	void loop(int id) {
 		uint64_t seen = 0;
 		for (;;) {
@@ -174,11 +177,16 @@ template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 // stage A
 // ------------------------------------------------------------------------------------------------
 
-// per-substage wall-clock accumulators of stage A (summed over threads; printed with MPA_TIMING=1)
+// per-substage CPU-time accumulators of stage A (thread CPU time summed over the workers; printed with MPA_TIMING=1)
 static std::atomic<int64_t> g_acc[16];
 static const char *const kAccName[16] = { "A.sketch+lookup", "A.sort anchors", "A.pre-chain", "A.chain", "A.regions", "A.refine", "A.plan", "A.round-1 plan",
 	"  refine: fetch window", "  refine: sketch nt4", "  refine: sketch prot+sort", "  refine: pairs+sort", "  refine: chain", "  refine: n regions", "  anchors (x1000, all queries / threads)", "  pre-chain survivors (x1000)" };
-struct AccTimer { int k; double t0; AccTimer(int k_) : k(k_), t0(now_ms()) {} ~AccTimer() { g_acc[k] += (int64_t)((now_ms() - t0) * 1e6); } };
+// (thread CPU time, not wall time: under a CPU quota the wall time of a thread says how often it was throttled, not what it cost)
+struct AccTimer {
+	int k; double t0; bool on;
+	AccTimer(int k_) : k(k_), t0(0), on(timing_on()) { if (on) t0 = thread_cpu_ms(); }
+	~AccTimer() { if (on) g_acc[k] += (int64_t)((thread_cpu_ms() - t0) * 1e6); }
+};
 
 // mp_cal_max_occ (map.c:126-141): boxplot-style cutoff on the occurrence counts of the query's seeds
 static int32_t occurrence_cutoff(const mpa_idx_s *mi, const std::vector<uint64_t> &seeds)
@@ -1073,7 +1081,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	});
 	timing_note("  plan: refine..plans (wall)", now_ms() - t_b);
 	timing_note("stage A (seed..plan)", now_ms() - t0);
-	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6 / b->n_threads); }
+	if (timing_on()) for (int k = 0; k < 16; ++k) { timing_note(kAccName[k], (double)g_acc[k].exchange(0) / 1e6); }   // thread CPU ms summed over the workers (13-15: counts)
 	if (b->opt.flag & MPA_MF_NO_ALIGN) { b->round = 4; return; }
 	// the round-1 task list is part of planning too: in a stream it is ready before a DP lane picks the batch up
 	const double t1 = now_ms();
@@ -1367,6 +1375,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
 	auto seeder_body = [&](int sd) { try {
 		tl_pool_lane = 10 + sd, tl_thread_div = 4;
+		WorkerPool::get(tl_pool_lane).label_ = "seeding: worker pool";
+		CpuSpan cs("seeding: stage thread (host prep + waits)");
 		for (;;) {
 			int32_t k;
 			{	// (claims are serialised among the seeders, outside the pipeline's own lock: a claim may be a round trip to another process)
@@ -1396,6 +1406,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
 	auto planner_body = [&](int pl) { try {
 		tl_pool_lane = 14 + pl, tl_thread_div = n_plan;
+		WorkerPool::get(tl_pool_lane).label_ = "planning: worker pool";
+		CpuSpan cs("planning: stage thread (serial parts + waits)");
 		for (;;) {
 			int32_t k;
 			{	// stay a bounded number of batches ahead of the ones in their DP rounds (planned batches hold their windows and tasks)
@@ -1417,6 +1429,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int pl = 0; pl < n_plan; ++pl) planners.emplace_back(planner_body, pl);
 	std::thread finisher([&] { try {
 		tl_pool_lane = 1, tl_thread_div = 4;
+		WorkerPool::get(tl_pool_lane).label_ = "output: worker pool";
+		CpuSpan cs("output: stage thread (flatten + format)");
 		for (int32_t k = 0; k < n_batches; ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
@@ -1437,6 +1451,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	int32_t next_dp = 0;
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
 		tl_pool_lane = 2 + d, tl_thread_div = 4;
+		WorkerPool::get(tl_pool_lane).label_ = "DP lanes: worker pool";
+		CpuSpan cs("DP lanes: lane thread (round bookkeeping + waits)");
 		for (;;) {
 			int32_t k;
 			{
@@ -1465,6 +1481,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();
 	ctx_absorb_sibling_stats(ctx);
+	cpu_report_and_reset("mpa_map_batches", now_ms() - g_trace_t0);
 	if (rc_all == MPA_OK) {
 		if (n_mapped) *n_mapped = n_total;
 		if (order) for (int32_t k = 0; k < n_total; ++k) order[k] = slot[k].g;

@@ -37,6 +37,14 @@ template<typename R, typename F> static inline R guarded(R on_error, F f)
 double now_ms();
 bool timing_on();
 void timing_note(const char *what, double ms);
+double thread_cpu_ms();                                   // CPU time of the calling thread
+void cpu_add(const char *label, double ms);               // accumulate under a label (coarse: per stage call, per parallel region and worker)
+void cpu_report_and_reset(const char *header, double wall_ms);
+struct CpuSpan {                                          // CPU time of the calling thread over a scope, under a label
+	const char *label; double t0; bool on;
+	explicit CpuSpan(const char *l) : label(l), t0(0), on(timing_on()) { if (on) t0 = thread_cpu_ms(); }
+	~CpuSpan() { if (on) cpu_add(label, thread_cpu_ms() - t0); }
+};
 
 // ---- index (index.cpp) ---------------------------------------------------------------------------
 struct Contig { int64_t off, len; std::string name; };

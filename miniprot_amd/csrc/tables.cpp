@@ -7,6 +7,9 @@
 #include <cmath>
 #include <mutex>
 #include <chrono>
+#include <vector>
+#include <string>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include "mpa_internal.h"
@@ -145,6 +148,34 @@ const int8_t *blosum62() { return ns_mat_blosum62; }
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool timing_on() { const char *e = getenv("MPA_TIMING"); return e && *e && *e != '0'; }   // (read per call: the tests flip it)
 void timing_note(const char *what, double ms) { if (timing_on()) fprintf(stderr, "[mpa-timing] %-28s %9.3f ms\n", what, ms); }
+
+// CPU accounting (MPA_TIMING=1): the box gives a process a CPU quota, not the cores it sees, so what a pipeline stage COSTS is its
+// thread CPU time (CLOCK_THREAD_CPUTIME_ID: spinning in a wait counts, sleeping does not), not the wall time of its threads
+double thread_cpu_ms()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+static std::mutex g_cpu_mu;
+static std::vector<std::pair<std::string, double>> g_cpu_acc;
+void cpu_add(const char *label, double ms)
+{
+	std::lock_guard<std::mutex> g(g_cpu_mu);
+	for (auto &e : g_cpu_acc) if (e.first == label) { e.second += ms; return; }
+	g_cpu_acc.emplace_back(label, ms);
+}
+void cpu_report_and_reset(const char *header, double wall_ms)
+{
+	std::lock_guard<std::mutex> g(g_cpu_mu);
+	double tot = 0;
+	for (auto &e : g_cpu_acc) tot += e.second;
+	if (timing_on()) {
+		fprintf(stderr, "[mpa-cpu] %s: wall %.1f ms, accounted thread CPU %.1f ms (%.1f cores)\n", header, wall_ms, tot, wall_ms > 0 ? tot / wall_ms : 0.0);
+		for (auto &e : g_cpu_acc) fprintf(stderr, "[mpa-cpu]   %-44s %10.1f ms  %5.1f %%\n", e.first.c_str(), e.second, tot > 0 ? 100 * e.second / tot : 0.0);
+	}
+	g_cpu_acc.clear();
+}
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }

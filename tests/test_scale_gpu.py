@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import miniprot_amd as mpa
 import refbind
+import golden  # noqa: F401  (puts tools/ on sys.path)
 import gen_synth
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(refbind.REF_BIN), reason="oracle/_ref/miniprot not present")]
