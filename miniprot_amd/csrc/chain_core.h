@@ -1,0 +1,392 @@
+// chain_core.h -- chain extraction (mp_chain_backtrack + compact_a, chain.c:8-110) and the reference's pair sort
+// (radix_sort_mp128x, ksort.h:109-162) as ONE source for the host and the device.
+//
+// The extraction consumes the order in which the reference's unstable in-place MSD radix sort leaves chain ends of equal
+// score, so it cannot be re-derived independently for the GPU: the functions below are plain C++ on raw arrays (no
+// allocation, no library calls, no recursion) and are compiled twice -- by the host pipeline (host_core.cpp, whose results
+// tests/test_host_core.py fuzzes against the oracle) and, unchanged, into k_chain_extract (seed_exec.hip), where one
+// wavefront runs them for one chaining problem.  Whatever the host does, the device does.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#ifdef __HIPCC__
+#define MPA_HD __host__ __device__
+#else
+#define MPA_HD
+#endif
+
+namespace mpa {
+
+struct Pair64 { uint64_t x, y; };     // mp128_t (miniprot.h:32)
+
+struct ChainParams {
+	int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;
+	float coef_log;
+	int32_t is_spliced, kmer, bbit;
+};
+
+// The state after the forward pass (chain.c:181-209) of a chaining problem with n_total anchors.  A dense view holds all of
+// them (pos == nullptr, m == n_total).  A sparse view (only valid when min_cnt > 1) may leave out anchors that have no
+// predecessor and are nobody's predecessor; pos[] are then the ascending positions of the m anchors it does hold.
+struct ChainView {
+	int64_t n_total, m;
+	const int32_t *pos;      // [m] or nullptr
+	const int32_t *f;        // [m] chain score ending at the anchor
+	const int32_t *pred;     // [m] view index of the predecessor, -1 for none
+	const uint64_t *a;       // [m] the anchors
+};
+
+struct SparseItem { int64_t pos; Pair64 e; };        // an element that is not a root, and the slot it occupies
+struct SortRange { int64_t beg, end; int32_t shift, pad; };
+
+// Work space of chain_extract_core() for a view of m anchors (every array [m] unless noted).
+struct ExtractScratch {
+	int32_t *mark, *order;
+	Pair64 *ends;            // [ends_cap]: m, or n_total when the full list of chain ends has to be built (see chain_ends_full_needed)
+	int64_t ends_cap;
+	SparseItem *items, *moved, *merged;
+	Pair64 *tail8, *first;
+	uint8_t *kept;
+	uint64_t *packed, *u_sorted;
+	SortRange *stack;        // [ends_cap / 64 + 4]
+};
+
+#define MPA_ABSENT (~0ULL)   /* an anchor the view leaves out (alone in its neighbourhood) */
+
+// ---- radix_sort_mp128x (ksort.h:109-162): the order of EQUAL keys is part of the behaviour ------------------------------
+// Runs of <= 64 elements: insertion sort (stable).  Longer runs: in-place cycle-leader permutation by the byte at `shift`,
+// then the same for every bucket at the next byte.
+MPA_HD inline void pairs_insertion(Pair64 *beg, Pair64 *end)
+{
+	for (Pair64 *i = beg + 1; i < end; ++i) {
+		if (i->x >= (i - 1)->x) continue;
+		Pair64 v = *i, *j = i;
+		for (; j > beg && v.x < (j - 1)->x; --j) *j = *(j - 1);
+		*j = v;
+	}
+}
+
+// one digit level over [beg, end); cnt[256] receives the bucket sizes
+MPA_HD inline void pairs_digit_level(Pair64 *beg, Pair64 *end, int shift, uint32_t *cnt)
+{
+	uint32_t cursor[256], limit[256];
+	for (int d = 0; d < 256; ++d) cnt[d] = 0;
+	for (Pair64 *p = beg; p != end; ++p) ++cnt[p->x >> shift & 0xff];
+	bool single = false;
+	{
+		uint32_t at = 0;
+		for (int d = 0; d < 256; ++d) { cursor[d] = at, at += cnt[d], limit[d] = at; if (cnt[d] == (uint32_t)(end - beg)) single = true; }
+	}
+	for (int k = 0; !single && k < 256;) {
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(beg[cursor[k]].x >> shift & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = beg[cursor[k]];            // follow the displacement cycle until an element of bucket k turns up
+		do {
+			const Pair64 placed = carried;
+			carried = beg[cursor[d]];
+			beg[cursor[d]++] = placed;
+			d = (int)(carried.x >> shift & 0xff);
+		} while (d != k);
+		beg[cursor[k]++] = carried;
+	}
+}
+
+// every level below `shift` too (the reference recurses; the buckets are independent, so a work list gives the same result)
+MPA_HD inline void pairs_digit_pass(Pair64 *base, int64_t beg, int64_t end, int shift, SortRange *stack)
+{
+	int64_t top = 0;
+	stack[top++] = SortRange{ beg, end, shift, 0 };
+	while (top > 0) {
+		const SortRange r = stack[--top];
+		uint32_t cnt[256];
+		pairs_digit_level(base + r.beg, base + r.end, r.shift, cnt);
+		if (r.shift == 0) continue;
+		const int next = r.shift > 8 ? r.shift - 8 : 0;
+		int64_t p = r.beg;
+		for (int d = 0; d < 256; ++d) {
+			const int64_t e = p + cnt[d];
+			if (cnt[d] > 64) stack[top++] = SortRange{ p, e, next, 0 };     // (at most (end - beg) / 65 ranges are ever pending)
+			else if (cnt[d] > 1) pairs_insertion(base + p, base + e);
+			p = e;
+		}
+	}
+}
+
+// stack: [(end - beg) / 64 + 4]
+MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *stack)
+{
+	if (end - beg <= 64) { pairs_insertion(beg, end); return; }
+	// A digit level at which every key has the same byte leaves the array untouched (each element is already in "its"
+	// bucket) and just recurses into that single bucket, so the leading constant bytes can be skipped without changing the
+	// result -- keys here are chain scores or block ids, i.e. mostly zero in the top bytes.
+	uint64_t all_or = 0, all_and = ~0ULL;
+	for (const Pair64 *p = beg; p != end; ++p) all_or |= p->x, all_and &= p->x;
+	const uint64_t varying = all_or ^ all_and;
+	int shift = 56;
+	while (shift > 0 && ((varying >> shift) & 0xff) == 0) shift -= 8;
+	pairs_digit_pass(beg, 0, end - beg, shift, stack);
+}
+
+// ---- the chain ends in the order the reference's sort leaves them, from a SPARSE view --------------------------------------
+// For the common case that almost every anchor is a chain of one.  With min_cnt > 1 such "root" anchors (no predecessor,
+// score == kmer, the smallest key) never yield a chain, so only the order of the OTHER ends matters; but that order is a
+// product of the in-place MSD radix sort run over the whole array, roots included.  With all scores below 256 that sort is a
+// single digit pass, and its effect on the non-roots can be replayed without the roots: bucket `kmer` is the first region
+// [0, n_root); walking it only ever moves the non-roots found there (in ascending position) into the heads of their
+// buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
+//
+// The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest key
+// present) everywhere except at `items` (m of them, ascending pos).  Writes the m non-roots in their final order to out[0, m).
+MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, int64_t m, Pair64 *out)
+{
+	if (m == 0) return;
+	uint32_t cnt[256], cursor[256], limit[256];
+	for (int d = 0; d < 256; ++d) cnt[d] = 0;
+	for (int64_t i = 0; i < m; ++i) ++cnt[items[i].e.x & 0xff];
+	const int64_t n_root = n - m;
+	Pair64 *tail = out;
+	for (int64_t i = 0; i < m; ++i) tail[i] = Pair64{ (uint64_t)k0, MPA_ABSENT };
+	// the slots [n_root, n) as they are before the pass
+	int64_t first_tail = 0;
+	while (first_tail < m && items[first_tail].pos < n_root) ++first_tail;
+	for (int64_t i = first_tail; i < m; ++i) tail[items[i].pos - n_root] = items[i].e;
+	{
+		uint32_t at = 0;
+		for (int d = 0; d < 256; ++d) cursor[d] = at, at += cnt[d], limit[d] = at;
+	}
+	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
+	for (int64_t i = 0; i < first_tail; ++i) {
+		Pair64 carried = items[i].e;
+		int d = (int)(carried.x & 0xff);
+		do {
+			const Pair64 placed = carried;
+			carried = tail[cursor[d]];
+			tail[cursor[d]++] = placed;
+			d = (int)(carried.x & 0xff);
+		} while (d != k0);
+	}
+	// the remaining buckets, entirely inside the tail (same walk as pairs_digit_level)
+	for (int k = k0 + 1; k < 256;) {
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(tail[cursor[k]].x & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = tail[cursor[k]];
+		do {
+			const Pair64 placed = carried;
+			carried = tail[cursor[d]];
+			tail[cursor[d]++] = placed;
+			d = (int)(carried.x & 0xff);
+		} while (d != k);
+		tail[cursor[k]++] = carried;
+	}
+}
+
+MPA_HD inline int64_t view_pos(const ChainView &v, int64_t i) { return v.pos ? (int64_t)v.pos[i] : i; }
+
+// Returns the number of chain ends written to out[] (the non-roots, in the reference's order), or -1 if the preconditions do
+// not hold (the caller then builds and sorts the full list).
+MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, const ExtractScratch &S, Pair64 *out)
+{
+	const int64_t n = v.n_total;
+	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return -1;
+	SparseItem *items = S.items, *moved = S.moved, *merged = S.merged;
+	int64_t n_items = 0, n_moved = 0, n_merged = 0;
+	int32_t max_f = 0;
+	for (int64_t i = 0; i < v.m; ++i)
+		if (v.pred[i] >= 0) {
+			if (v.f[i] <= p.kmer) return -1;               // (f > kmer always holds for a chained anchor; belt and braces)
+			if (v.f[i] > max_f) max_f = v.f[i];
+			items[n_items++] = SparseItem{ view_pos(v, i), Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } };
+		}
+	if (max_f < 256) { replay_low_digit(n, p.kmer, items, n_items, out); return n_items; }
+	if (max_f >= 65536) return -1;
+	// ---- two digit levels.  Level 1 (shift 8): bucket 0 = all scores below 256 (the roots among them) is the region
+	// [0, c0); walking it moves the high scores found there into the heads of their buckets behind c0, and what they
+	// displace from there -- low scores -- into the holes they leave.
+	uint32_t cnt8[256];
+	for (int d = 0; d < 256; ++d) cnt8[d] = 0;
+	int64_t m_hi = 0;
+	for (int64_t i = 0; i < n_items; ++i) if (items[i].e.x >= 256) ++cnt8[items[i].e.x >> 8 & 0xff], ++m_hi;
+	const int64_t c0 = n - m_hi;
+	Pair64 *tail8 = S.tail8;
+	for (int64_t i = 0; i < m_hi; ++i) tail8[i] = Pair64{ (uint64_t)p.kmer, MPA_ABSENT };
+	{	// slots [c0, n) as they are: every view element there, roots included (their identity never matters)
+		int64_t i;
+		if (!v.pos) i = c0 < v.m ? c0 : v.m;
+		else {                                               // first view element at position >= c0
+			const int64_t want = c0 < INT32_MAX ? c0 : INT32_MAX;
+			int64_t lo = 0, hi = v.m;
+			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)v.pos[mid] < want) lo = mid + 1; else hi = mid; }
+			i = lo;
+		}
+		for (; i < v.m; ++i) tail8[view_pos(v, i) - c0] = Pair64{ (uint64_t)(int64_t)v.f[i], v.pred[i] >= 0 ? (uint64_t)i : MPA_ABSENT };
+	}
+	uint32_t cursor[256], limit[256], start[256];
+	{
+		uint32_t at = 0;
+		for (int d = 0; d < 256; ++d) start[d] = cursor[d] = at, at += d ? cnt8[d] : 0, limit[d] = at;
+	}
+	for (int64_t q = 0; q < n_items; ++q) {
+		const SparseItem &it = items[q];
+		if (it.pos >= c0) break;
+		if (it.e.x < 256) continue;                        // a low score inside region 0 stays where it is
+		Pair64 carried = it.e;
+		int d = (int)(carried.x >> 8 & 0xff);
+		do {
+			const Pair64 placed = carried;
+			carried = tail8[cursor[d]];
+			tail8[cursor[d]++] = placed;
+			d = (int)(carried.x >> 8 & 0xff);
+		} while (d != 0);
+		if (carried.y != MPA_ABSENT) moved[n_moved++] = SparseItem{ it.pos, carried };   // a chained anchor with a low score: it now sits in the hole
+	}
+	for (int k = 1; k < 256;) {                             // buckets 1..255 (same walk as pairs_digit_level)
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(tail8[cursor[k]].x >> 8 & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		Pair64 carried = tail8[cursor[k]];
+		do {
+			const Pair64 placed = carried;
+			carried = tail8[cursor[d]];
+			tail8[cursor[d]++] = placed;
+			d = (int)(carried.x >> 8 & 0xff);
+		} while (d != k);
+		tail8[cursor[k]++] = carried;
+	}
+	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
+	{
+		int64_t a = 0, b = 0;
+		while (a < n_items && items[a].pos < c0) {
+			if (items[a].e.x >= 256) { ++a; continue; }
+			while (b < n_moved && moved[b].pos < items[a].pos) merged[n_merged++] = moved[b++];
+			merged[n_merged++] = items[a++];
+		}
+		while (b < n_moved) merged[n_merged++] = moved[b++];
+	}
+	int64_t n_out = 0;
+	if (c0 > 64) { replay_low_digit(c0, p.kmer, merged, n_merged, out); n_out = n_merged; }
+	else {                                                  // a short bucket is insertion-sorted: stable
+		for (int64_t i = 1; i < n_merged; ++i) {
+			const SparseItem x = merged[i];
+			int64_t j = i;
+			for (; j > 0 && x.e.x < merged[j - 1].e.x; --j) merged[j] = merged[j - 1];
+			merged[j] = x;
+		}
+		for (int64_t i = 0; i < n_merged; ++i) out[n_out++] = merged[i].e;
+	}
+	// ---- level 2 inside the other buckets (all of it is present): digit pass or insertion sort, as the reference recurses
+	for (int d = 1; d < 256; ++d) {
+		Pair64 *b = tail8 + start[d], *e = b + cnt8[d];
+		if (cnt8[d] > 64) { uint32_t c2[256]; pairs_digit_level(b, e, 0, c2); }
+		else if (cnt8[d] > 1) pairs_insertion(b, e);
+		for (Pair64 *x = b; x != e; ++x) out[n_out++] = *x;
+	}
+	return n_out;
+}
+
+// Can the view be extracted without the full list of chain ends (one entry per anchor of the problem, absent ones included)?
+MPA_HD inline bool chain_ends_sparse_possible(const ChainParams &p, const ChainView &v)
+{
+	return !(p.min_cnt <= 1 || p.min_sc > p.kmer || v.n_total <= 64 || p.kmer < 0 || p.kmer > 255);
+}
+
+// chain.c:8-110 on the result of the forward pass: extraction (best chain end first), then the kept chains laid out in
+// ascending anchor order and sorted by their first target position.  a_out: [m], u: [m] (one entry per kept chain,
+// score << 32 | anchors).  set_only: the caller wants the anchors of the kept chains as a SET, ascending (the pre-chain,
+// map.c:186-192, whose chains are dissolved again by the sort that follows it): no chain list, no layout, and no sort either
+// -- the view is in ascending anchor order, so marking the kept anchors and reading the view through gives them sorted.
+// Returns 0, or 1 when the full list of chain ends is needed and S.ends_cap is too small for it (nothing written).
+MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, const ExtractScratch &S, uint64_t *a_out, int64_t *n_a_out, uint64_t *u, int64_t *n_u_out,
+                                     bool set_only)
+{
+	int64_t n_u = 0, n_order = 0;
+	*n_a_out = 0, *n_u_out = 0;
+	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
+	const int32_t *f = v.f, *pred = v.pred;
+	int32_t *mark = S.mark, *order = S.order;
+	Pair64 *ends = S.ends;
+	int64_t n_ends = sorted_chain_ends_sparse(p, v, S, ends);
+	if (n_ends < 0) {
+		// the full list: absent anchors are roots (score kmer); they can only be left out when min_cnt rejects them anyway
+		if (v.n_total > S.ends_cap) return 1;
+		n_ends = 0;
+		int64_t vi = 0;
+		for (int64_t q = 0; q < v.n_total; ++q) {
+			if (vi < v.m && view_pos(v, vi) == q) {
+				if (f[vi] >= p.min_sc) ends[n_ends++] = Pair64{ (uint64_t)(int64_t)f[vi], (uint64_t)vi };
+				++vi;
+			} else if (p.kmer >= p.min_sc) ends[n_ends++] = Pair64{ (uint64_t)(int64_t)p.kmer, MPA_ABSENT };
+		}
+		sort_pairs_by_x_core(ends, ends + n_ends, S.stack);
+	}
+	if (n_ends == 0) return 0;
+	for (int64_t i = 0; i < v.m; ++i) mark[i] = 0;
+	// anchor indices of the kept chains, each chain from its END backwards
+	for (int64_t k = n_ends - 1; k >= 0; --k) {
+		if (ends[k].y == MPA_ABSENT) continue;
+		const int64_t tail = (int64_t)ends[k].y;
+		const int32_t tail_f = (int32_t)ends[k].x;
+		if (mark[tail] != 0) continue;
+		// An unclaimed anchor without predecessor is a one-anchor chain.  When min_cnt rejects those, the only trace it
+		// would leave is its own claim mark, which nothing reads any more: every anchor chained onto it scores above
+		// kmer == f[tail] and has therefore been visited already.
+		if (pred[tail] < 0 && p.min_cnt > 1) continue;
+		// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
+		int64_t cut = tail, walk = tail, stop = -1;
+		int32_t best_suffix = 0;
+		do {
+			mark[walk] = 2;
+			stop = walk = pred[walk];
+			const int32_t s = walk < 0 ? tail_f : tail_f - f[walk];
+			if (s > best_suffix) best_suffix = s, cut = walk;
+			else if (best_suffix - s > max_drop) break;
+		} while (walk >= 0 && mark[walk] == 0);
+		for (int64_t x = tail; x >= 0 && x != stop; x = pred[x]) mark[x] = 0;
+		// claim the anchors of the suffix
+		const int64_t before = n_order;
+		int64_t x = tail;
+		for (; x != cut; x = pred[x]) order[n_order++] = (int32_t)x, mark[x] = 1;
+		const int32_t sc = x < 0 ? tail_f : tail_f - f[x];
+		const int64_t cnt = n_order - before;
+		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)cnt;
+		else n_order = before;                              // rejected chains keep their anchors claimed
+	}
+	if (n_u == 0) return 0;
+	if (set_only) {
+		// (mark: 1 = claimed; the anchors of the kept chains are exactly those in `order`)
+		uint8_t *kept = S.kept;
+		for (int64_t i = 0; i < v.m; ++i) kept[i] = 0;
+		for (int64_t i = 0; i < n_order; ++i) kept[order[i]] = 1;
+		int64_t k = 0;
+		for (int64_t i = 0; i < v.m; ++i) if (kept[i]) a_out[k++] = v.a[i];
+		*n_a_out = k;
+		return 0;
+	}
+	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
+	uint64_t *packed = S.packed, *u_sorted = S.u_sorted;
+	Pair64 *first = S.first;
+	{
+		int64_t k = 0;
+		for (int64_t c = 0; c < n_u; ++c) {
+			const int64_t cnt = (int64_t)(uint32_t)u[c];
+			for (int64_t j = 0; j < cnt; ++j) packed[k + j] = v.a[order[k + cnt - 1 - j]];
+			first[c] = Pair64{ packed[k] >> 32, (uint64_t)k << 32 | (uint64_t)c };
+			k += cnt;
+		}
+	}
+	sort_pairs_by_x_core(first, first + n_u, S.stack);
+	int64_t k = 0;
+	for (int64_t c = 0; c < n_u; ++c) {
+		const uint32_t which = (uint32_t)first[c].y;
+		const int64_t cnt = (int64_t)(uint32_t)u[which], from = (int64_t)(first[c].y >> 32);
+		u_sorted[c] = u[which];
+		for (int64_t j = 0; j < cnt; ++j) a_out[k + j] = packed[from + j];
+		k += cnt;
+	}
+	for (int64_t c = 0; c < n_u; ++c) u[c] = u_sorted[c];
+	*n_a_out = k, *n_u_out = n_u;
+	return 0;
+}
+
+} // namespace mpa

@@ -72,68 +72,14 @@ void sort_anchors_by_block(std::vector<uint64_t> &a)
 	if (src != a.data()) memcpy(a.data(), src, n * sizeof(uint64_t));
 }
 
-// Sort of (x,y) pairs by x whose treatment of EQUAL x must match the reference's in-place MSD radix sort
-// (it is unstable, and chain extraction / region order / extension limits consume the resulting order).
-// Runs of <= 64 elements use a stable insertion sort; longer runs are permuted digit by digit with the
-// same cycle-leader walk.
-static void pairs_insertion(Pair64 *beg, Pair64 *end)
-{
-	for (Pair64 *i = beg + 1; i < end; ++i) {
-		if (i->x >= (i - 1)->x) continue;
-		Pair64 v = *i, *j = i;
-		for (; j > beg && v.x < (j - 1)->x; --j) *j = *(j - 1);
-		*j = v;
-	}
-}
-
-static void pairs_digit_pass(Pair64 *beg, Pair64 *end, int shift)
-{
-	Pair64 *cursor[256], *limit[256];
-	size_t cnt[256];
-	memset(cnt, 0, sizeof(cnt));
-	for (Pair64 *p = beg; p != end; ++p) ++cnt[p->x >> shift & 0xff];
-	{
-		Pair64 *p = beg;
-		for (int d = 0; d < 256; ++d) cursor[d] = p, p += cnt[d], limit[d] = p;
-	}
-	bool single = false;
-	for (int d = 0; d < 256; ++d) if (cnt[d] == (size_t)(end - beg)) { single = true; break; }
-	for (int k = 0; !single && k < 256;) {
-		if (cursor[k] == limit[k]) { ++k; continue; }
-		int d = (int)(cursor[k]->x >> shift & 0xff);
-		if (d == k) { ++cursor[k]; continue; }
-		Pair64 carried = *cursor[k];             // follow the displacement cycle until an element of bucket k turns up
-		do {
-			Pair64 placed = carried;
-			carried = *cursor[d];
-			*cursor[d]++ = placed;
-			d = (int)(carried.x >> shift & 0xff);
-		} while (d != k);
-		*cursor[k]++ = carried;
-	}
-	if (shift == 0) return;
-	const int next = shift > 8 ? shift - 8 : 0;
-	Pair64 *p = beg;
-	for (int d = 0; d < 256; ++d) {
-		Pair64 *e = p + cnt[d];
-		if (cnt[d] > 64) pairs_digit_pass(p, e, next);
-		else if (cnt[d] > 1) pairs_insertion(p, e);
-		p = e;
-	}
-}
-
+// Sort of (x,y) pairs by x whose treatment of EQUAL x must match the reference's in-place MSD radix sort (it is unstable,
+// and chain extraction / region order / extension limits consume the resulting order): chain_core.h, shared with the device.
 void sort_pairs_by_x(Pair64 *beg, Pair64 *end)
 {
-	if (end - beg <= 64) { pairs_insertion(beg, end); return; }
-	// A digit level at which every key has the same byte leaves the array untouched (each element is already in
-	// "its" bucket) and just recurses into that single bucket, so the leading constant bytes can be skipped without
-	// changing the result -- keys here are chain scores or block ids, i.e. mostly zero in the top bytes.
-	uint64_t all_or = 0, all_and = ~0ULL;
-	for (const Pair64 *p = beg; p != end; ++p) all_or |= p->x, all_and &= p->x;
-	const uint64_t varying = all_or ^ all_and;
-	int shift = 56;
-	while (shift > 0 && ((varying >> shift) & 0xff) == 0) shift -= 8;
-	pairs_digit_pass(beg, end, shift);
+	static thread_local std::vector<SortRange> stack;
+	const size_t need = (size_t)(end - beg) / 64 + 4;
+	if (stack.size() < need) stack.resize(need);
+	sort_pairs_by_x_core(beg, end, stack.data());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,250 +304,34 @@ static inline int32_t link_score(uint64_t cur, uint64_t prev, const ChainParams 
 	return sc;
 }
 
-// The chain ends in the order the reference's sort leaves them -- for the common case that almost every anchor is a
-// chain of one.  With min_cnt > 1 such "root" anchors (no predecessor, score == kmer, the smallest key) never yield a
-// chain, so only the order of the OTHER ends matters; but that order is a product of the in-place MSD radix sort
-// (pairs_digit_pass) run over the whole array, roots included.  With all scores below 256 that sort is a single digit
-// pass, and its effect on the non-roots can be replayed without the roots: bucket `kmer` is the first region
-// [0, n_root); walking it only ever moves the non-roots found there (in ascending position) into the heads of their
-// buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
-// The view may therefore leave out anchors that are alone in their neighbourhood (v.pos != nullptr).
-// Returns false if the preconditions do not hold (the caller then builds and sorts the full list).
-struct SparseItem { int64_t pos; Pair64 e; };        // an element that is not a root, and the slot it occupies
-
-// The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest
-// key present) everywhere except at `items` (ascending pos).  Appends the non-roots in their final order.
-static void replay_low_digit(int64_t n, int k0, const std::vector<SparseItem> &items, std::vector<Pair64> &out)
-{
-	const size_t m = items.size(), base = out.size();
-	if (m == 0) return;
-	size_t cnt[256];
-	memset(cnt, 0, sizeof(cnt));
-	for (const SparseItem &it : items) ++cnt[it.e.x & 0xff];
-	const int64_t n_root = n - (int64_t)m;
-	out.resize(base + m, Pair64{ (uint64_t)k0, ~0ULL });
-	Pair64 *tail = out.data() + base;
-	// the slots [n_root, n) as they are before the pass
-	size_t first_tail = 0;
-	while (first_tail < m && items[first_tail].pos < n_root) ++first_tail;
-	for (size_t i = first_tail; i < m; ++i) tail[items[i].pos - n_root] = items[i].e;
-	size_t cursor[256], limit[256];
-	{
-		size_t at = 0;
-		for (int d = 0; d < 256; ++d) cursor[d] = at, at += cnt[d], limit[d] = at;
-	}
-	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
-	for (size_t i = 0; i < first_tail; ++i) {
-		Pair64 carried = items[i].e;
-		int d = (int)(carried.x & 0xff);
-		do {
-			const Pair64 placed = carried;
-			carried = tail[cursor[d]];
-			tail[cursor[d]++] = placed;
-			d = (int)(carried.x & 0xff);
-		} while (d != k0);
-	}
-	// the remaining buckets, entirely inside the tail (same walk as pairs_digit_pass)
-	for (int k = k0 + 1; k < 256;) {
-		if (cursor[k] == limit[k]) { ++k; continue; }
-		int d = (int)(tail[cursor[k]].x & 0xff);
-		if (d == k) { ++cursor[k]; continue; }
-		Pair64 carried = tail[cursor[k]];
-		do {
-			const Pair64 placed = carried;
-			carried = tail[cursor[d]];
-			tail[cursor[d]++] = placed;
-			d = (int)(carried.x & 0xff);
-		} while (d != k);
-		tail[cursor[k]++] = carried;
-	}
-}
-
-static bool sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, std::vector<Pair64> &out)
-{
-	const int64_t n = v.n_total;
-	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return false;
-	static thread_local std::vector<SparseItem> items, moved, merged;
-	items.clear();
-	int32_t max_f = 0;
-	for (int64_t i = 0; i < v.m; ++i)
-		if (v.pred[i] >= 0) {
-			if (v.f[i] <= p.kmer) return false;           // (f > kmer always holds for a chained anchor; belt and braces)
-			max_f = std::max(max_f, v.f[i]);
-			items.push_back(SparseItem{ v.pos ? (int64_t)v.pos[i] : i, Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } });
-		}
-	out.clear();
-	if (max_f < 256) { replay_low_digit(n, p.kmer, items, out); return true; }
-	if (max_f >= 65536) return false;
-	// ---- two digit levels.  Level 1 (shift 8): bucket 0 = all scores below 256 (the roots among them) is the region
-	// [0, c0); walking it moves the high scores found there into the heads of their buckets behind c0, and what they
-	// displace from there -- low scores -- into the holes they leave.
-	size_t cnt8[256];
-	memset(cnt8, 0, sizeof(cnt8));
-	int64_t m_hi = 0;
-	for (const SparseItem &it : items) if (it.e.x >= 256) ++cnt8[it.e.x >> 8 & 0xff], ++m_hi;
-	const int64_t c0 = n - m_hi;
-	static thread_local std::vector<Pair64> tail8;
-	const uint64_t kAbsent = ~0ULL;
-	tail8.assign((size_t)m_hi, Pair64{ (uint64_t)p.kmer, kAbsent });
-	{	// slots [c0, n) as they are: every view element there, roots included (their identity never matters)
-		int64_t i = v.m;
-		if (!v.pos) i = std::min<int64_t>(c0, v.m);
-		else i = std::lower_bound(v.pos, v.pos + v.m, (int32_t)std::min<int64_t>(c0, INT32_MAX)) - v.pos;
-		for (; i < v.m; ++i) tail8[(size_t)((v.pos ? (int64_t)v.pos[i] : i) - c0)] = Pair64{ (uint64_t)(int64_t)v.f[i], v.pred[i] >= 0 ? (uint64_t)i : kAbsent };
-	}
-	size_t cursor[256], limit[256], start[256];
-	{
-		size_t at = 0;
-		for (int d = 0; d < 256; ++d) start[d] = cursor[d] = at, at += d ? cnt8[d] : 0, limit[d] = at;
-	}
-	moved.clear(), merged.clear();
-	for (const SparseItem &it : items) {
-		if (it.pos >= c0) break;
-		if (it.e.x < 256) continue;                        // a low score inside region 0 stays where it is
-		Pair64 carried = it.e;
-		int d = (int)(carried.x >> 8 & 0xff);
-		do {
-			const Pair64 placed = carried;
-			carried = tail8[cursor[d]];
-			tail8[cursor[d]++] = placed;
-			d = (int)(carried.x >> 8 & 0xff);
-		} while (d != 0);
-		if (carried.y != kAbsent) moved.push_back(SparseItem{ it.pos, carried });   // a chained anchor with a low score: it now sits in the hole
-	}
-	for (int k = 1; k < 256;) {                             // buckets 1..255 (same walk as pairs_digit_pass)
-		if (cursor[k] == limit[k]) { ++k; continue; }
-		int d = (int)(tail8[cursor[k]].x >> 8 & 0xff);
-		if (d == k) { ++cursor[k]; continue; }
-		Pair64 carried = tail8[cursor[k]];
-		do {
-			const Pair64 placed = carried;
-			carried = tail8[cursor[d]];
-			tail8[cursor[d]++] = placed;
-			d = (int)(carried.x >> 8 & 0xff);
-		} while (d != k);
-		tail8[cursor[k]++] = carried;
-	}
-	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
-	{
-		size_t a = 0, b = 0;
-		while (a < items.size() && items[a].pos < c0) {
-			if (items[a].e.x >= 256) { ++a; continue; }
-			while (b < moved.size() && moved[b].pos < items[a].pos) merged.push_back(moved[b++]);
-			merged.push_back(items[a++]);
-		}
-		while (b < moved.size()) merged.push_back(moved[b++]);
-	}
-	if (c0 > 64) replay_low_digit(c0, p.kmer, merged, out);
-	else {                                                  // a short bucket is insertion-sorted: stable
-		std::stable_sort(merged.begin(), merged.end(), [](const SparseItem &x, const SparseItem &y) { return x.e.x < y.e.x; });
-		for (const SparseItem &it : merged) out.push_back(it.e);
-	}
-	// ---- level 2 inside the other buckets (all of it is present): digit pass or insertion sort, as the reference recurses
-	for (int d = 1; d < 256; ++d) {
-		Pair64 *b = tail8.data() + start[d], *e = b + cnt8[d];
-		if (cnt8[d] > 64) pairs_digit_pass(b, e, 0);
-		else if (cnt8[d] > 1) pairs_insertion(b, e);
-		out.insert(out.end(), b, e);
-	}
-	return true;
-}
-
-// chain.c:8-110 on the result of the forward pass: extraction (best chain end first), then the kept chains laid out in
-// ascending anchor order and sorted by their first target position.
-// set_only: the caller wants the anchors of the kept chains as a SET, ascending (the pre-chain, map.c:186-192, whose chains
-// are dissolved again by the sort that follows it): no chain list, no layout, and no sort either -- the view is in ascending
-// anchor order, so marking the kept anchors and reading the view through gives them sorted.
+// chain.c:8-110 on the result of the forward pass (chain_core.h: chain_extract_core, the same source the device compiles);
+// here only the work space.
 static void chain_extract_impl(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u, bool set_only)
 {
-	u.clear();
-	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
-	const int32_t *f = v.f, *pred = v.pred;
 	static thread_local std::vector<int32_t> mark, order;
-	static thread_local std::vector<Pair64> ends, first;
+	static thread_local std::vector<Pair64> ends, tail8, first;
+	static thread_local std::vector<SparseItem> items, moved, merged;
+	static thread_local std::vector<uint8_t> kept;
 	static thread_local std::vector<uint64_t> packed, u_sorted;
-	const uint64_t kAbsent = ~0ULL;                     // an anchor the view leaves out (alone in its neighbourhood)
-	ends.clear();
-	if (!sorted_chain_ends_sparse(p, v, ends)) {
-		// the full list: absent anchors are roots (score kmer); they can only be left out when min_cnt rejects them anyway
-		int64_t vi = 0;
-		for (int64_t q = 0; q < v.n_total; ++q) {
-			if (vi < v.m && (v.pos ? v.pos[vi] : vi) == q) {
-				if (f[vi] >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)f[vi], (uint64_t)vi });
-				++vi;
-			} else if (p.kmer >= p.min_sc) ends.push_back(Pair64{ (uint64_t)(int64_t)p.kmer, kAbsent });
-		}
-		sort_pairs_by_x(ends.data(), ends.data() + ends.size());
+	static thread_local std::vector<SortRange> stack;
+	const size_t m = (size_t)v.m;
+	const size_t ends_cap = chain_ends_sparse_possible(p, v) ? m : (size_t)std::max(v.n_total, v.m);
+	auto grow = [](auto &vec, size_t n) { if (vec.size() < n) vec.resize(n + n / 4 + 16); };
+	grow(mark, m), grow(order, m), grow(ends, std::max(ends_cap, m)), grow(tail8, m), grow(first, m), grow(items, m), grow(moved, m), grow(merged, m);
+	grow(kept, m), grow(packed, m), grow(u_sorted, m), grow(stack, std::max(ends_cap, m) / 64 + 4);
+	const ExtractScratch S{ mark.data(), order.data(), ends.data(), (int64_t)std::max(ends_cap, m), items.data(), moved.data(), merged.data(), tail8.data(), first.data(),
+	                        kept.data(), packed.data(), u_sorted.data(), stack.data() };
+	static thread_local std::vector<uint64_t> a_buf, u_buf;  // (grow-only: a resize of the outputs would zero m words per call)
+	grow(a_buf, m), grow(u_buf, m);
+	int64_t n_a = 0, n_u = 0;
+	int rc = chain_extract_core(p, v, S, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
+	if (rc != 0) {                                          // (a sparse view whose preconditions failed after all: the full list)
+		grow(ends, (size_t)v.n_total), grow(stack, (size_t)v.n_total / 64 + 4);
+		ExtractScratch S2 = S;
+		S2.ends = ends.data(), S2.ends_cap = v.n_total, S2.stack = stack.data();
+		rc = chain_extract_core(p, v, S2, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
 	}
-	if (ends.empty()) { a_out.clear(); return; }
-	mark.assign((size_t)v.m, 0);
-	order.clear();                                     // anchor indices of the kept chains, each chain from its END backwards
-	for (int64_t k = (int64_t)ends.size() - 1; k >= 0; --k) {
-		if (ends[k].y == kAbsent) continue;
-		const int64_t tail = (int64_t)ends[k].y;
-		const int32_t tail_f = (int32_t)ends[k].x;
-		if (mark[tail] != 0) continue;
-		// An unclaimed anchor without predecessor is a one-anchor chain.  When min_cnt rejects those, the only trace it
-		// would leave is its own claim mark, which nothing reads any more: every anchor chained onto it scores above
-		// kmer == f[tail] and has therefore been visited already.
-		if (pred[tail] < 0 && p.min_cnt > 1) continue;
-		// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
-		int64_t cut = tail, walk = tail, stop = -1;
-		int32_t best_suffix = 0;
-		do {
-			mark[walk] = 2;
-			stop = walk = pred[walk];
-			const int32_t s = walk < 0 ? tail_f : tail_f - f[walk];
-			if (s > best_suffix) best_suffix = s, cut = walk;
-			else if (best_suffix - s > max_drop) break;
-		} while (walk >= 0 && mark[walk] == 0);
-		for (int64_t x = tail; x >= 0 && x != stop; x = pred[x]) mark[x] = 0;
-		// claim the anchors of the suffix
-		const size_t before = order.size();
-		int64_t x = tail;
-		for (; x != cut; x = pred[x]) order.push_back((int32_t)x), mark[x] = 1;
-		const int32_t sc = x < 0 ? tail_f : tail_f - f[x];
-		const int64_t cnt = (int64_t)(order.size() - before);
-		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u.push_back((uint64_t)sc << 32 | (uint64_t)cnt);
-		else order.resize(before);                       // rejected chains keep their anchors claimed
-	}
-	if (u.empty()) { a_out.clear(); return; }
-	if (set_only) {
-		// (mark: 1 = claimed; the anchors of the kept chains are exactly those in `order`)
-		static thread_local std::vector<uint8_t> kept;
-		kept.assign((size_t)v.m, 0);
-		for (int32_t x : order) kept[(size_t)x] = 1;
-		a_out.resize(order.size());
-		size_t k = 0;
-		for (int64_t i = 0; i < v.m; ++i) if (kept[(size_t)i]) a_out[k++] = v.a[i];
-		u.clear();
-		return;
-	}
-
-	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
-	packed.resize(order.size());
-	first.resize(u.size());
-	{
-		size_t k = 0;
-		for (size_t c = 0; c < u.size(); ++c) {
-			const size_t cnt = (uint32_t)u[c];
-			for (size_t j = 0; j < cnt; ++j) packed[k + j] = v.a[order[k + cnt - 1 - j]];
-			first[c] = Pair64{ packed[k] >> 32, (uint64_t)k << 32 | (uint64_t)c };
-			k += cnt;
-		}
-	}
-	sort_pairs_by_x(first.data(), first.data() + first.size());
-	u_sorted.resize(u.size());
-	a_out.resize(packed.size());
-	size_t k = 0;
-	for (size_t c = 0; c < u.size(); ++c) {
-		const uint32_t which = (uint32_t)first[c].y;
-		const size_t cnt = (uint32_t)u[which], from = (size_t)(first[c].y >> 32);
-		u_sorted[c] = u[which];
-		memcpy(&a_out[k], &packed[from], cnt * sizeof(uint64_t));
-		k += cnt;
-	}
-	u.assign(u_sorted.begin(), u_sorted.end());
+	a_out.assign(a_buf.begin(), a_buf.begin() + n_a), u.assign(u_buf.begin(), u_buf.begin() + n_u);
 }
 
 void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u)

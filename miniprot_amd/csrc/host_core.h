@@ -7,10 +7,9 @@
 #include <cstring>
 #include <vector>
 #include "mpa_internal.h"
+#include "chain_core.h"               // Pair64, ChainParams, ChainView + the extraction / pair sort shared with the device
 
 namespace mpa {
-
-struct Pair64 { uint64_t x, y; };     // mp128_t (miniprot.h:32)
 
 // ---- sorting (ksort.h:109-162 semantics) ---------------------------------------------------------
 void sort_u64(uint64_t *beg, uint64_t *end);          // radix_sort_mp64: ties are identical values
@@ -31,26 +30,11 @@ void refine_seed_pairs(const uint8_t *nt, int64_t len, int32_t min_aa_len, int32
 void refine_pairs_from_hits(std::vector<uint64_t> &hits, const std::vector<uint64_t> &qk_sorted, int32_t max_ava, std::vector<uint64_t> &a);
 
 // ---- chaining (chain.c) -----------------------------------------------------------------------------
-struct ChainParams {
-	int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, min_cnt, min_sc;
-	float coef_log;
-	int32_t is_spliced, kmer, bbit;
-};
 // a: sorted anchors, rewritten with the anchors of the kept chains (chain by chain, ascending);
 // u: one entry per chain, score<<32 | n_anchors
 void chain_anchors(const ChainParams &p, std::vector<uint64_t> &a, std::vector<uint64_t> &u, int32_t *f_copy = nullptr, int32_t *pred_copy = nullptr, bool set_only = false);
 // a: rewritten with the anchors of the kept chains as an ascending set (the pre-chain: its chains are dissolved right away)
 void chain_anchors_set(const ChainParams &p, std::vector<uint64_t> &a);
-// The state after the forward pass (chain.c:181-209) of a chaining problem with n_total anchors.  A dense view holds all of
-// them (pos == nullptr, m == n_total).  A sparse view (only valid when min_cnt > 1) may leave out anchors that have no
-// predecessor and are nobody's predecessor; pos[] are then the ascending positions of the m anchors it does hold.
-struct ChainView {
-	int64_t n_total, m;
-	const int32_t *pos;      // [m] or nullptr
-	const int32_t *f;        // [m] chain score ending at the anchor
-	const int32_t *pred;     // [m] view index of the predecessor, -1 for none
-	const uint64_t *a;       // [m] the anchors
-};
 void chain_extract(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out, std::vector<uint64_t> &u);
 // the anchors of the kept chains as an ascending set, without the chain list (what the pre-chain's caller needs)
 void chain_extract_set(const ChainParams &p, const ChainView &v, std::vector<uint64_t> &a_out);
