@@ -275,6 +275,12 @@ int mpa_dbg_chain_forward(mpa_ctx_t *ctx, int32_t max_dist_x, int32_t max_dist_y
                           int32_t is_spliced, int32_t kmer, int32_t bbit, int32_t n_prob, const int64_t *first, const uint64_t *a, int32_t *f, int32_t *pred);
 /* the anchors that survive the pre-chain (map.c:186-192), query by query, from the host stage (ctx == NULL) or the device's */
 int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out);
+/* the main chains of every query (what mp_chain() returns at map.c:195): u = score << 32 | anchors of each chain, a = the chains'
+ * anchors; from the host stages (ctx == NULL) or from the device, which then runs both chaining rounds (k_chain_extract,
+ * k_chain_fwd).  off_u / off_a [n_seq + 1], *out_u / *out_a (mpa_free).  Returns how many queries the device handed back to the
+ * host, or a negative error code. */
+int64_t mpa_dbg_main_chains(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off_u, uint64_t **out_u,
+                            int64_t *off_a, uint64_t **out_a);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@
 #include "mpa_internal.h"
 #include "host_core.h"
 #include "dp_device.h"
+#include "chain_core.h"
 #include "dp_kernels.hip"
 #include "seed_exec.hip"
 
@@ -78,6 +79,8 @@ struct SeedBufs {
 	DevBuf pf_w, pf_dst, pf_rem, pf_jfirst, pf_qfirst2, pf_err, val64[2];   // pre-sort anchor filter (k_seed_prefilter)
 	DevBuf s_meta, s_cur, s_cur2, s_kept, s_base, s_out, s_flag, dkey;      // k_seed_sift: segments + per-query tables, list cursors, per-segment results, dense keys
 	HostPinned h_meta, h_back;                                             // ... their staging (up) and qfirst2 / flags / cfirst (down)
+	DevBuf x_all;                                                          // device chaining: views, extraction scratch, survivors, main-chain state, chains (carved up per call)
+	HostPinned h_U, h_A, h_xoff;                                           // ... the chains of every query (down)
 	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first;                // chain forward pass (k_chain_fwd)
 	HostPinned hc_a, hc_f, hc_pred;
 };
@@ -322,8 +325,8 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
 	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first,
 	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1],
-	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey }) b->release();
-	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
+	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all }) b->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_U, &B.h_A, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -471,8 +474,11 @@ static int seed_mode()
 // dev_prechain_forward() with k_seed_sift (the default).  The caller has uploaded the jobs.  Per-anchor memory: 16 bytes of
 // staging; everything behind the sift is sized by the kept anchors.  The result arrays are written by k_seed_compact straight
 // into pinned host memory (no copy kernels, no second pass over HBM).
+static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int64_t n2, int nb, const uint64_t *key, const uint64_t *val, const int64_t *d_qfirst,
+                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out);
+
 static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_block, const PreParams &pp, int nb, int32_t n_query, const int64_t *qfirst,
-                                     const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin)
+                                     const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin, const ChainParams *pre_cp, const ChainParams *main_cp)
 {
 	SeedBufs &B = ctx->seed;
 	hipStream_t s = ctx->seed_stream;
@@ -572,6 +578,14 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	out.m = m;
 	timing_note("    seed: copy + pre-chain + scan (wait)", t_kernels - t_sift);
 	if (m == 0) return MPA_OK;
+	// both chaining rounds on the device (MPA_DEVICE_CHAINS=0: hand the linked anchors to the host instead, as rounds 1-2 did)
+	{
+		static const bool device_chains = [] { const char *e = getenv("MPA_DEVICE_CHAINS"); return e ? atoi(e) != 0 : true; }();
+		if (device_chains && main_cp && pre_cp) {
+			rc = dev_chains_on_device(ctx, n_query, m, n2, nb, key, val, d_qfirst, h_flag, *pre_cp, *main_cp, out);
+			if (rc != MPA_ERR_UNSUPPORTED) { timing_note("    seed: chains on the device", now_ms() - t_kernels); return rc; }
+		}
+	}
 	if ((rc = B.h_pos.ensure((size_t)m * 4)) || (rc = B.h_f.ensure((size_t)m * 4)) || (rc = B.h_pred.ensure((size_t)m * 4)) || (rc = B.h_a.ensure((size_t)m * 8))) return rc;
 	hipLaunchKernelGGL((k_seed_compact<uint64_t, true>), dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(),
 	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), B.h_pos.as<int32_t>(), B.h_f.as<int32_t>(), B.h_pred.as<int32_t>(), B.h_a.as<uint64_t>());
@@ -582,16 +596,109 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	return MPA_OK;
 }
 
+// Both chaining rounds of every query on the device, behind the forward pass of the pre-chain (map.c:186-196):
+//   k_seed_compact      the linked anchors of every query as a sparse view (position in the full list, f, pred, anchor), in HBM
+//   k_chain_extract     pre-chain extraction (set): the survivors of every query, ascending
+//   k_chain_fwd         forward pass of the main chain over them (block anchors, max_dist_x = max_intron)
+//   k_chain_extract     main-chain extraction: chains (score, count) and their anchors, sorted by first target position
+//   k_offsets2 + k_chain_pack   the chains of all queries, densely, into pinned host memory
+// What travels back is what mp_reg_gen_from_block() consumes (a few hundred anchors per query) instead of every linked anchor
+// (~11 000 per query at 3 Gbp), and the host no longer spends a core-second per mini-batch on chaining.
+// key/val: the kept anchors (dense, sorted), with B.f / B.pred / B.flag / B.idx / B.cfirst from the pre-chain's forward pass.
+static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int64_t n2, int nb, const uint64_t *key, const uint64_t *val, const int64_t *d_qfirst,
+                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out)
+{
+	SeedBufs &B = ctx->seed;
+	hipStream_t s = ctx->seed_stream;
+	if (mainp.bbit != pre.bbit || mainp.kmer != pre.kmer) { set_error("device chains: pre-chain and main chain disagree on the anchors"); return MPA_ERR_UNSUPPORTED; }
+	// ---- one allocation, carved up: everything is indexed like the view (m entries), `ends` and `stack` have extras per problem
+	const size_t M = (size_t)m, NQ = (size_t)n_query;
+	size_t at = 0;
+	auto carve = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t o_vpos = carve(M * 4), o_vf = carve(M * 4), o_vpred = carve(M * 4), o_va = carve(M * 8);
+	const size_t o_mark = carve(M * 4), o_order = carve(M * 4), o_ends = carve((M + 64 * NQ + 64) * sizeof(Pair64)), o_tail8 = carve(M * sizeof(Pair64)),
+	             o_firstp = carve(M * sizeof(Pair64)), o_items = carve(M * sizeof(SparseItem)), o_moved = carve(M * sizeof(SparseItem)), o_merged = carve(M * sizeof(SparseItem)),
+	             o_kept = carve(M), o_packed = carve(M * 8), o_usorted = carve(M * 8), o_stack = carve((M / 64 + 6 * NQ + 16) * sizeof(SortRange));
+	const size_t o_pre_a = carve(M * 8), o_pre_u = carve(M * 8), o_pre_na = carve(NQ * 8 + 8), o_pre_nu = carve(NQ * 8 + 8), o_status = carve(NQ * 4 + 16);
+	const size_t o_mf = carve(M * 4), o_mpred = carve(M * 4), o_mmark = carve(M * 4);
+	const size_t o_out_a = carve(M * 8), o_out_u = carve(M * 8), o_na = carve(NQ * 8 + 8), o_nu = carve(NQ * 8 + 8), o_offa = carve(NQ * 8 + 16), o_offu = carve(NQ * 8 + 16);
+	int rc;
+	if ((rc = B.x_all.ensure(at))) return rc;
+	char *X = B.x_all.as<char>();
+	HIP_TRY(hipMemsetAsync(X + o_status, 0, NQ * 4 + 16, s));
+	const unsigned nblk2 = (unsigned)((n2 + 255) / 256), nblkm = (unsigned)((m + 255) / 256);
+	// the sparse view of the pre-chain's forward pass
+	hipLaunchKernelGGL((k_seed_compact<uint64_t, true>), dim3(nblk2), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(),
+	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), (int32_t*)(X + o_vpos), (int32_t*)(X + o_vf), (int32_t*)(X + o_vpred), (uint64_t*)(X + o_va));
+	ExtractArgs xa;
+	xa.first = B.cfirst.as<int64_t>(), xa.cnt = nullptr, xa.ntot_first = d_qfirst;
+	xa.v_pos = (const int32_t*)(X + o_vpos), xa.v_f = (const int32_t*)(X + o_vf), xa.v_pred = (const int32_t*)(X + o_vpred), xa.v_a = (const uint64_t*)(X + o_va);
+	xa.mark = (int32_t*)(X + o_mark), xa.order = (int32_t*)(X + o_order), xa.ends = (Pair64*)(X + o_ends), xa.tail8 = (Pair64*)(X + o_tail8), xa.firstp = (Pair64*)(X + o_firstp);
+	xa.items = (SparseItem*)(X + o_items), xa.moved = (SparseItem*)(X + o_moved), xa.merged = (SparseItem*)(X + o_merged);
+	xa.kept = (uint8_t*)(X + o_kept), xa.packed = (uint64_t*)(X + o_packed), xa.u_sorted = (uint64_t*)(X + o_usorted), xa.stack = (SortRange*)(X + o_stack);
+	xa.a_out = (uint64_t*)(X + o_pre_a), xa.u_out = (uint64_t*)(X + o_pre_u), xa.n_a = (int64_t*)(X + o_pre_na), xa.n_u = (int64_t*)(X + o_pre_nu);
+	xa.status = (int32_t*)(X + o_status), xa.p = pre, xa.set_only = 1;
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
+	HIP_TRY(hipGetLastError());
+	// the main chain over the survivors: forward pass ...
+	PreParams pm;
+	pm.max_dist_x = std::max(mainp.max_dist_x, mainp.bw), pm.max_dist_y = mainp.max_dist_y;
+	if (pm.max_dist_y < mainp.bw && !mainp.is_spliced) pm.max_dist_y = mainp.bw;
+	pm.bw = mainp.bw, pm.max_skip = mainp.max_skip, pm.max_iter = mainp.max_iter, pm.kmer = mainp.kmer, pm.bbit = mainp.bbit;
+	pm.is_spliced = mainp.is_spliced, pm.coef_log = mainp.coef_log, pm.max_dblock = pm.max_dist_x >> mainp.bbit;
+	hipLaunchKernelGGL(k_seed_fill, dim3(nblkm), dim3(256), 0, s, m, pm.kmer, (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark), (uint32_t*)(X + o_mark));
+	hipLaunchKernelGGL(k_chain_fwd, dim3(nblkm), dim3(256), 0, s, (const uint64_t*)(X + o_pre_a), m, B.cfirst.as<int64_t>(), (const int64_t*)(X + o_pre_na), n_query, pm,
+	                   (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark));
+	HIP_TRY(hipGetLastError());
+	// ... and extraction: dense views over the survivors
+	xa.cnt = (const int64_t*)(X + o_pre_na), xa.ntot_first = nullptr;
+	xa.v_pos = nullptr, xa.v_f = (const int32_t*)(X + o_mf), xa.v_pred = (const int32_t*)(X + o_mpred), xa.v_a = (const uint64_t*)(X + o_pre_a);
+	xa.a_out = (uint64_t*)(X + o_out_a), xa.u_out = (uint64_t*)(X + o_out_u), xa.n_a = (int64_t*)(X + o_na), xa.n_u = (int64_t*)(X + o_nu);
+	xa.p = mainp, xa.set_only = 0;
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
+	hipLaunchKernelGGL(k_offsets2, dim3(1), dim3(256), 0, s, (const int64_t*)(X + o_na), (const int64_t*)(X + o_nu), n_query, (int64_t*)(X + o_offa), (int64_t*)(X + o_offu));
+	HIP_TRY(hipGetLastError());
+	// offsets + status down, then the chains themselves straight into pinned memory
+	const size_t offb = (NQ + 1) * 8;
+	if ((rc = B.h_xoff.ensure(2 * offb + NQ * 4 + 64))) return rc;
+	int64_t *h_offa = B.h_xoff.as<int64_t>(), *h_offu = h_offa + (NQ + 1);
+	int32_t *h_status = (int32_t*)(h_offu + (NQ + 1));
+	HIP_TRY(hipMemcpyAsync(h_offa, X + o_offa, offb, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_offu, X + o_offu, offb, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_status, X + o_status, NQ * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(wait_stream(ctx, s));
+	const int64_t tot_a = h_offa[n_query], tot_u = h_offu[n_query];
+	if ((rc = B.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = B.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
+	if (tot_a > 0 || tot_u > 0) {
+		hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)n_query), dim3(256), 0, s, B.cfirst.as<int64_t>(), (const int64_t*)(X + o_na), (const int64_t*)(X + o_nu),
+		                   (const int64_t*)(X + o_offa), (const int64_t*)(X + o_offu), (const uint64_t*)(X + o_out_a), (const uint64_t*)(X + o_out_u),
+		                   B.h_A.as<uint64_t>(), B.h_U.as<uint64_t>());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(wait_stream(ctx, s));
+	}
+	out.a_first.assign(h_offa, h_offa + n_query + 1), out.u_first.assign(h_offu, h_offu + n_query + 1);
+	out.A = B.h_A.as<uint64_t>(), out.U = B.h_U.as<uint64_t>();
+	out.has_chains = true;
+	bool any = !out.on_host.empty();
+	for (int32_t q = 0; q < n_query && !any; ++q) any = h_status[q] != 0;
+	if (any) {
+		if (out.on_host.empty()) out.on_host.assign(NQ, 0);
+		for (int32_t q = 0; q < n_query; ++q) if (h_status[q] || (h_flag && h_flag[q])) out.on_host[(size_t)q] = 1;
+	}
+	return MPA_OK;
+}
+
 // GPU seeding for one mini-batch: anchors -> sort -> forward pass of the pre-chain -> the anchors that have a neighbour.
 // jobs: the kept seeds of all queries (qid ascending, within a query ascending query position, dst = running anchor
 // offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
 // (pred = index into the query's part of the view, -1 for none).
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
-                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out)
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main)
 {
 	const int64_t n = qfirst[n_query];
 	out.cfirst.assign((size_t)n_query + 1, 0);
 	out.pos = out.f = out.pred = nullptr, out.a = nullptr, out.m = 0, out.on_host.clear();
+	out.has_chains = false, out.U = out.A = nullptr, out.u_first.clear(), out.a_first.clear();
 	if (n == 0 || n_jobs == 0) return MPA_OK;
 	if (pre.bbit <= 0) { set_error("GPU pre-chain needs block anchors (bbit > 0)"); return MPA_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -641,7 +748,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	if (B.jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
 	// the default: merge the occurrence lists per query in block order, keep what has a neighbour (k_seed_sift, seed_exec.hip)
-	if (mode == 2) return dev_prechain_forward_sift(ctx, d, mi->n_block, pp, nb, n_query, qfirst, jobs, n_jobs, out, t_begin);
+	if (mode == 2) return dev_prechain_forward_sift(ctx, d, mi->n_block, pp, nb, n_query, qfirst, jobs, n_jobs, out, t_begin, &pre, main);
 	if (B.qfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.cfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK) return MPA_ERR_HIP;
 	for (int k = 0; k < 2; ++k) if (B.key[k].ensure((size_t)n * 8) != MPA_OK || B.val[k].ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
 	if (B.f.ensure((size_t)n * 4) != MPA_OK || B.pred.ensure((size_t)n * 4) != MPA_OK || B.mark.ensure((size_t)n * 4) != MPA_OK ||
@@ -852,7 +959,7 @@ int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &cp, int32_t n_prob, con
 	HIP_TRY(hipMemcpyAsync(B.c_first.p, first, ((size_t)n_prob + 1) * 8, hipMemcpyHostToDevice, s));
 	const unsigned nblk = (unsigned)((n + 255) / 256);
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(), B.c_mark.as<int32_t>(), B.c_flag.as<uint32_t>());
-	hipLaunchKernelGGL(k_chain_fwd, dim3(nblk), dim3(256), 0, s, B.c_a.as<uint64_t>(), n, B.c_first.as<int64_t>(), n_prob, pp, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(),
+	hipLaunchKernelGGL(k_chain_fwd, dim3(nblk), dim3(256), 0, s, B.c_a.as<uint64_t>(), n, B.c_first.as<int64_t>(), (const int64_t*)nullptr, n_prob, pp, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(),
 	                   B.c_mark.as<int32_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(io.f, B.c_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

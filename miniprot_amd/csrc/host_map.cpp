@@ -574,6 +574,7 @@ static inline ChainParams main_chain_params(const mpa_idx_s *mi, const mpa_mapop
 	                    opt.chn_coef_log, !(opt.flag & MPA_MF_NO_SPLICE), mi->opt.kmer, mi->opt.bbit };
 }
 
+static void stage_windows_from_chains(mpa_batch_s *b, QueryState &qs, const std::vector<uint64_t> &u, const std::vector<uint64_t> &a);
 // f/pred != nullptr: the forward pass of the main chain ran on the device (dev_chain_forward)
 static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a, const int32_t *f = nullptr, const int32_t *pred = nullptr)
 {
@@ -585,6 +586,14 @@ static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<u
 	const ChainParams cp = main_chain_params(mi, opt);
 	(void)is_splice;
 	{ AccTimer tm(3); if (f) chain_anchors_after_forward(cp, f, pred, a, u); else chain_anchors(cp, a, u); }
+	stage_windows_from_chains(b, qs, u, a);
+}
+
+// ... from the main chains (u: score << 32 | anchors per chain; a: their anchors, chain by chain): regions and their windows
+static void stage_windows_from_chains(mpa_batch_s *b, QueryState &qs, const std::vector<uint64_t> &u, const std::vector<uint64_t> &a)
+{
+	const mpa_idx_s *mi = b->mi;
+	const mpa_mapopt_t &opt = b->opt;
 	std::vector<Region> &regs = qs.regs;
 	AccTimer tm(4);
 	regions_from_chains(mi, u, a, regs);
@@ -871,8 +880,10 @@ static const int64_t kDeviceSeedingMinAnchors = 8000000;
 
 // Phase 1 of a batch: seeds of every query; with a device context and a batch that is worth it, also the anchors, their
 // sort and the forward pass of the pre-chain (seed_exec.hip).
-static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
+static int gpu_chain_mode();
+static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, bool want_chains = true)
 {
+	if (gpu_chain_mode() != 0) want_chains = false;
 	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
 	mpa_batch_s *b = new mpa_batch_s();
 	b->mi = mi, b->opt = *opt, b->q = *q, b->n_threads = n_threads > 1 ? n_threads : 1;
@@ -912,7 +923,11 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	});
 	const double t1 = now_ms();
 	timing_note("  A1: seed jobs", t1 - t0);
-	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse);
+	// (with the main chain's parameters the device carries on through both chaining rounds, unless MPA_GPU_CHAIN=1 asks for the older
+	// arrangement -- forward passes on the device, extraction on the host -- or the caller only wants the pre-chain)
+	const ChainParams main_cp = main_chain_params(mi, *opt);
+	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse,
+	                                    want_chains ? &main_cp : nullptr);
 	if (rc == MPA_ERR_UNSUPPORTED) {                    // e.g. the batch does not fit the device: seed on the host
 		if (timing_on()) fprintf(stderr, "[mpa-timing]   device seeding declined (%s): seeding on the host\n", mpa_last_error());
 		return b;
@@ -967,8 +982,17 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	bool dev_chain = rctx && chain_mode != 0;
 	if (!dev_chain) {
 		parallel_for(b->n_threads, n_q, [&](int64_t i) {
-			static thread_local std::vector<uint64_t> a;
-			if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, a);
+			static thread_local std::vector<uint64_t> a, u;
+			const PrechainSparse &ps = b->sparse;
+			if (b->seeded_on_device && ps.has_chains && !(!ps.on_host.empty() && ps.on_host[(size_t)i])) {
+				// both chaining rounds ran on the device: its chains are what mp_chain() returns for this query (map.c:195)
+				g_acc[14] += b->qs[i].n_anchor * 1000;
+				u.assign(ps.U + ps.u_first[(size_t)i], ps.U + ps.u_first[(size_t)i + 1]);
+				a.assign(ps.A + ps.a_first[(size_t)i], ps.A + ps.a_first[(size_t)i + 1]);
+				stage_windows_from_chains(b, b->qs[i], u, a);
+				return;
+			}
+			if (b->seeded_on_device && !ps.has_chains) stage_anchors_from_device(b, b->qs[i], ps, a);
 			else stage_anchors_host(b, b->qs[i], a);
 			stage_chain_to_windows(b, b->qs[i], a);
 		});
@@ -1143,7 +1167,7 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
 	const char *saved = getenv("MPA_GPU_SEED");
 	const std::string keep = saved ? saved : "";
 	setenv("MPA_GPU_SEED", ctx ? "1" : "0", 1);
-	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads);
+	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads, false);
 	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
 	if (!b) return MPA_ERR_ARG;
 	if (ctx && !b->seeded_on_device && q->n_seq > 0 && prechain_enabled(*opt)) { delete b; set_error("device seeding was not used"); return MPA_ERR_UNSUPPORTED; }
@@ -1160,6 +1184,47 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
 	const int64_t n = off[q->n_seq];
 	delete b;
 	return n;
+}
+
+// Test hook (not in include/mpamd.h): the MAIN chains of every query (what mp_chain() returns at map.c:195: u = score << 32 |
+// anchors per chain, a = the chains' anchors), from the host stages (ctx == NULL) or from the device, which runs both chaining
+// rounds (k_chain_extract, k_chain_fwd).  off_u / off_a [n_seq + 1]; *out_u / *out_a malloc'd (mpa_free).  Returns the number of
+// queries the device handed back to the host (>= 0) or a negative error code.
+int64_t mpa_dbg_main_chains(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off_u, uint64_t **out_u,
+                            int64_t *off_a, uint64_t **out_a)
+{
+	*out_u = *out_a = nullptr;
+	const char *saved = getenv("MPA_GPU_SEED");
+	const std::string keep = saved ? saved : "";
+	setenv("MPA_GPU_SEED", ctx ? "1" : "0", 1);
+	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads, true);
+	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	if (!b) return MPA_ERR_ARG;
+	if (ctx && q->n_seq > 0 && prechain_enabled(*opt) && !(b->seeded_on_device && b->sparse.has_chains)) { delete b; set_error("the device did not chain"); return MPA_ERR_UNSUPPORTED; }
+	std::vector<std::vector<uint64_t>> us((size_t)q->n_seq), as((size_t)q->n_seq);
+	const ChainParams cp = main_chain_params(mi, *opt);
+	int64_t n_back = 0;
+	for (int32_t i = 0; i < q->n_seq; ++i) {
+		const PrechainSparse &ps = b->sparse;
+		if (b->seeded_on_device && ps.has_chains && !(!ps.on_host.empty() && ps.on_host[(size_t)i])) {
+			us[i].assign(ps.U + ps.u_first[(size_t)i], ps.U + ps.u_first[(size_t)i + 1]);
+			as[i].assign(ps.A + ps.a_first[(size_t)i], ps.A + ps.a_first[(size_t)i + 1]);
+			continue;
+		}
+		n_back += b->seeded_on_device ? 1 : 0;
+		stage_anchors_host(b, b->qs[i], as[i]);
+		chain_anchors(cp, as[i], us[i]);
+	}
+	off_u[0] = off_a[0] = 0;
+	for (int32_t i = 0; i < q->n_seq; ++i) off_u[i + 1] = off_u[i] + (int64_t)us[i].size(), off_a[i + 1] = off_a[i] + (int64_t)as[i].size();
+	uint64_t *ou = (uint64_t*)malloc((size_t)std::max<int64_t>(off_u[q->n_seq], 1) * 8), *oa = (uint64_t*)malloc((size_t)std::max<int64_t>(off_a[q->n_seq], 1) * 8);
+	for (int32_t i = 0; i < q->n_seq; ++i) {
+		if (!us[i].empty()) memcpy(ou + off_u[i], us[i].data(), us[i].size() * 8);
+		if (!as[i].empty()) memcpy(oa + off_a[i], as[i].data(), as[i].size() * 8);
+	}
+	*out_u = ou, *out_a = oa;
+	delete b;
+	return n_back;
 }
 
 // Test hook: the forward pass of mp_chain (chain.c:181-209) for n_prob chaining problems whose sorted anchors lie back to back

@@ -8,6 +8,7 @@
 #include <exception>
 #include <vector>
 #include "../../include/mpamd.h"
+#include "chain_core.h"
 
 namespace mpa {
 
@@ -91,18 +92,24 @@ struct PrechainSparse {              // result for a mini-batch: the chained anc
 	int64_t m = 0;
 	const int32_t *pos = nullptr, *f = nullptr, *pred = nullptr;   // pinned buffers owned by the context, valid until its next call; pred = index into the query's part of the view, -1 for none
 	const uint64_t *a = nullptr;
-	std::vector<uint8_t> on_host;    // [n_query] 1 = the device declined this query (k_seed_sift: too many anchors in one block): seed it on the host; empty = none
+	std::vector<uint8_t> on_host;    // [n_query] 1 = the device declined this query (k_seed_sift: too many anchors in one block; k_chain_extract: a degenerate problem): seed and chain it on the host; empty = none
+	// has_chains: both chaining rounds ran on the device (pre-chain extraction, main-chain forward pass and extraction): what comes
+	// back are the main chains of every query -- u (score << 32 | anchors per chain) and their anchors, chain by chain -- and the
+	// arrays above are not filled
+	bool has_chains = false;
+	std::vector<int64_t> u_first, a_first;   // [n_query + 1]
+	const uint64_t *U = nullptr, *A = nullptr;   // pinned buffers of the context, valid until its next call
 };
 struct RefineWindow { int64_t as; int32_t qid, vid, len; };    // strand-local window [as, as + len) on vid, refined for query qid
 struct RefineHits { std::vector<int64_t> first; std::vector<uint64_t> hits; };
 int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t n_query, const int64_t *qw_first, const uint32_t *qwords,
                     int64_t n_win, const RefineWindow *wins, RefineHits &out);
-struct ChainParams;
 // forward pass of mp_chain (chain.c:181-209) for a batch of problems on the device; see dp_exec.hip
 struct ChainIO { uint64_t *a = nullptr; int32_t *f = nullptr, *pred = nullptr; };   // pinned buffers of the context, valid until its next chain call
 int dev_chain_buffers(mpa_ctx_t *ctx, int64_t n, ChainIO &io);
 int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &p, int32_t n_prob, const int64_t *first, const ChainIO &io);
+// main != nullptr: carry on with the main chain on the device (has_chains), if the seeding mode supports it
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
-                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out);
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main = nullptr);
 
 } // namespace mpa

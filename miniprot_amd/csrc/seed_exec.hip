@@ -174,7 +174,8 @@ __device__ __forceinline__ int32_t d_link_score_a(uint64_t cur, uint64_t prev, c
 	return sc;
 }
 
-__global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n, const int64_t *first, int32_t n_prob, PreParams p,
+// cnt != nullptr: problem q holds cnt[q] anchors from first[q] on (the slots up to first[q + 1] are unused)
+__global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n, const int64_t *first, const int64_t *cnt, int32_t n_prob, PreParams p,
                                                    int32_t *f, int32_t *pred, int32_t *mark)
 {
 	MPA_SHORT_KERNEL();
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n,
 	// the problem this anchor belongs to: largest q with first[q] <= s
 	int32_t lo = 0, hi = n_prob - 1;
 	while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (first[mid] <= s) lo = mid; else hi = mid - 1; }
-	const int64_t q0 = first[lo], q1 = first[lo + 1];
+	const int64_t q0 = first[lo], q1 = cnt ? q0 + cnt[lo] : first[lo + 1];
+	if (s >= q1) return;                                                 // an unused slot
 	const uint64_t xs = a[s] >> 32;
 	const uint64_t max_dx = (uint64_t)(p.max_dist_x >> p.bbit);          // (x_i - x_j) << bbit > max_dist_x  <=>  x_i - x_j > max_dist_x >> bbit
 	if (s > q0 && xs - (a[s - 1] >> 32) <= max_dx) return;               // not the head of its run
@@ -222,6 +224,95 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n,
 		f[i] = best, pred[i] = best_j < 0 ? -1 : (int32_t)(best_j - q0);
 		if (hot_f < best) hot_f = best, hot = i;
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_chain_extract: mp_chain_backtrack + compact_a (chain.c:8-110) on the device, one WAVEFRONT per chaining problem.
+//
+// The extraction is a sequential algorithm whose result depends on the order the reference's unstable radix sort leaves equal
+// chain scores in; it is therefore not re-derived here but COMPILED from the host's own source (chain_core.h:
+// chain_extract_core), which tests/test_host_core.py pins to the oracle.  A problem is the pre-chain of a query (sparse view
+// of the anchors that k_prechain_fwd linked, set_only: the survivors as an ascending set), its main chain (dense view over
+// those survivors: chains laid out and sorted by first target position) or a refinement chain.  The code runs on lane 0 of the
+// wave (it is serial and latency-bound; what the device buys is that 4 000 problems run side by side and that no anchor has
+// to travel to the host and back between the two chaining rounds).  Layout: the view of problem q sits at first[q] in every
+// view / scratch / output array; status[q] = 1 when the problem needs the full list of chain ends and has no room for it
+// (tiny or degenerate problems: the host takes the query over).
+// ------------------------------------------------------------------------------------------------
+struct ExtractArgs {
+	const int64_t *first;            // [n_prob + 1] offset of every problem's view
+	const int64_t *cnt;              // [n_prob] anchors in the view, or nullptr: first[q + 1] - first[q]
+	const int64_t *ntot_first;       // sparse views: n_total of problem q = ntot_first[q + 1] - ntot_first[q]; nullptr: dense views (n_total = m)
+	const int32_t *v_pos, *v_f, *v_pred;   // view arrays (v_pos == nullptr for dense views)
+	const uint64_t *v_a;
+	// scratch, all indexed like the views; ends / stack have 64 / 5 extra entries per problem
+	int32_t *mark, *order;
+	Pair64 *ends, *tail8, *firstp;
+	SparseItem *items, *moved, *merged;
+	uint8_t *kept;
+	uint64_t *packed, *u_sorted;
+	SortRange *stack;
+	// results
+	uint64_t *a_out, *u_out;         // at first[q]
+	int64_t *n_a, *n_u;              // [n_prob]
+	int32_t *status;                 // [n_prob]
+	ChainParams p;
+	int32_t set_only;
+};
+
+__global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)
+{
+	const int32_t q = blockIdx.x;
+	if (q >= n_prob || threadIdx.x != 0) return;
+	const int64_t off = x.first[q];
+	const int64_t m = x.cnt ? x.cnt[q] : x.first[q + 1] - off;
+	x.n_a[q] = 0, x.n_u[q] = 0;
+	if (m <= 0) return;
+	const int64_t n_total = x.ntot_first ? x.ntot_first[q + 1] - x.ntot_first[q] : m;
+	const ChainView v{ n_total, m, x.v_pos ? x.v_pos + off : nullptr, x.v_f + off, x.v_pred + off, x.v_a + off };
+	const int64_t eoff = off + 64 * (int64_t)q;
+	const ExtractScratch S{ x.mark + off, x.order + off, x.ends + eoff, m + 64, x.items + off, x.moved + off, x.merged + off, x.tail8 + off, x.firstp + off,
+	                        x.kept + off, x.packed + off, x.u_sorted + off, x.stack + (eoff / 64 + 5 * (int64_t)q) };
+	int64_t n_a = 0, n_u = 0;
+	const int rc = chain_extract_core(x.p, v, S, x.a_out + off, &n_a, x.u_out + off, &n_u, x.set_only != 0);
+	if (rc != 0) { x.status[q] = 1; return; }
+	x.n_a[q] = n_a, x.n_u[q] = n_u;
+}
+
+// exclusive prefixes of two per-problem counts (one workgroup; a few thousand problems), + the totals at [n]
+__global__ __launch_bounds__(256) void k_offsets2(const int64_t *c0, const int64_t *c1, int32_t n, int64_t *o0, int64_t *o1)
+{
+	__shared__ int64_t wsum[8];
+	const int t = threadIdx.x;
+	int64_t run0 = 0, run1 = 0;
+	for (int32_t base = 0; base < n; base += 256) {
+		const int32_t i = base + t;
+		const int64_t v0 = i < n ? c0[i] : 0, v1 = i < n ? c1[i] : 0;
+		int64_t i0 = v0, i1 = v1;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int64_t u0 = __shfl_up(i0, o), u1 = __shfl_up(i1, o);
+			if ((t & 63) >= o) i0 += u0, i1 += u1;
+		}
+		__syncthreads();
+		if ((t & 63) == 63) wsum[t >> 6] = i0, wsum[4 + (t >> 6)] = i1;
+		__syncthreads();
+		int64_t b0 = 0, b1 = 0;
+		for (int w = 0; w < (t >> 6); ++w) b0 += wsum[w], b1 += wsum[4 + w];
+		if (i < n) o0[i] = run0 + b0 + i0 - v0, o1[i] = run1 + b1 + i1 - v1;
+		run0 += wsum[0] + wsum[1] + wsum[2] + wsum[3], run1 += wsum[4] + wsum[5] + wsum[6] + wsum[7];
+	}
+	if (t == 0) o0[n] = run0, o1[n] = run1;
+}
+// the chains of every problem, densely: u (score << 32 | anchors) and their anchors; dst may be pinned host memory
+__global__ __launch_bounds__(256) void k_chain_pack(const int64_t *first, const int64_t *n_a, const int64_t *n_u, const int64_t *o_a, const int64_t *o_u,
+                                                    const uint64_t *a_src, const uint64_t *u_src, uint64_t *a_dst, uint64_t *u_dst)
+{
+	MPA_SHORT_KERNEL();
+	const int32_t q = blockIdx.x;
+	const int64_t off = first[q], na = n_a[q], nu = n_u[q], da = o_a[q], du = o_u[q];
+	for (int64_t i = threadIdx.x; i < na; i += 256) a_dst[da + i] = a_src[off + i];
+	for (int64_t i = threadIdx.x; i < nu; i += 256) u_dst[du + i] = u_src[off + i];
 }
 
 __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)

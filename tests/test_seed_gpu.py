@@ -104,6 +104,60 @@ def test_prefilter_across_block_ranges(monkeypatch):
     ctx.close()
 
 
+def main_chains(ctx, idx, mo, q, threads=4):
+    L = mpa.lib()
+    L.mpa_dbg_main_chains.restype = C.c_int64
+    L.mpa_dbg_main_chains.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(mpa.MapOpt), C.POINTER(mpa.QBatch), C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p)]
+    off_u, off_a = np.zeros(len(q.seqs) + 1, np.int64), np.zeros(len(q.seqs) + 1, np.int64)
+    ou, oa = C.c_void_p(), C.c_void_p()
+    n_back = L.mpa_dbg_main_chains(ctx.h if ctx else None, idx.h, C.byref(mo), C.byref(q.c), threads, off_u.ctypes.data, C.byref(ou), off_a.ctypes.data, C.byref(oa))
+    assert n_back >= 0, mpa.last_error()
+    u = np.ctypeslib.as_array(C.cast(ou, C.POINTER(C.c_uint64)), (max(int(off_u[-1]), 1),))[:off_u[-1]].copy()
+    a = np.ctypeslib.as_array(C.cast(oa, C.POINTER(C.c_uint64)), (max(int(off_a[-1]), 1),))[:off_a[-1]].copy()
+    L.mpa_free(ou), L.mpa_free(oa)
+    return n_back, off_u, u, off_a, a
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_chains_equal_host_chains(seed, monkeypatch):
+    """Both chaining rounds on the device (k_chain_extract = the host's own extraction source compiled for the GPU, k_chain_fwd)
+    against the host stages that tests/test_host_core.py pins to the oracle: the main chains (score, count, anchors, in the order
+    mp_chain() returns them) of every query -- tandem copies of genes (many equal chain scores: the tie order of the reference's
+    unstable sort decides which chain claims a shared anchor), low-complexity and tiny queries (problems of <= 64 anchors take the
+    full-list path), default and -I style parameters"""
+    rng = np.random.default_rng(seed)
+    contigs, prots, names, planted = gen_synth.generate(3000000, 2, 40, 20 + seed, return_planted=True)
+    g = contigs[0]
+    for k in range(6):
+        src = int(rng.integers(0, len(g) - 20000))
+        seg = g[src:src + int(rng.integers(2000, 9000))].copy()
+        at = int(rng.integers(0, len(g) - 10 * len(seg)))
+        for r in range(int(rng.integers(2, 6))):
+            g[at + r * len(seg):at + (r + 1) * len(seg)] = seg
+    idx = mpa.Index.from_nt4(contigs, ["chr1", "chr2"])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
+    ctx = mpa.Context(0)
+    idx.to_device(ctx)
+    extra = [b"M" + bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), 300).tolist()), b"MLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLLL", b"M", b"MA",
+             bytes(planted[0]) + bytes(planted[1]) + bytes(planted[0])]
+    q = mpa.Queries(list(prots) + [bytes(p) for p in planted[:10]] + extra)
+    n_chains = 0
+    for flags in (0, 1):
+        mo = mpa.default_mapopt()
+        if flags:
+            mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+            mo.max_occ = 200
+        _, hu_off, hu, ha_off, ha = main_chains(None, idx, mo, q)
+        n_back, du_off, du, da_off, da = main_chains(ctx, idx, mo, q)
+        assert np.array_equal(hu_off, du_off) and np.array_equal(hu, du), flags
+        assert np.array_equal(ha_off, da_off) and np.array_equal(ha, da), flags
+        assert n_back < len(q.seqs) // 2                           # the device really did most of them
+        n_chains += int(hu_off[-1])
+    assert n_chains > 50
+    idx.close()
+    ctx.close()
+
+
 def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypatch):
     """k_seed_sift holds the anchors of one range in a 2 048-entry LDS buffer; a query whose seeds put more than that into ONE
     block (here: 3 000 identical k-mers of a poly-L protein over CTG repeats in the genome) is flagged by the kernel and
