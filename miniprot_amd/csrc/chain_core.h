@@ -6,6 +6,12 @@
 // allocation, no library calls, no recursion) and are compiled twice -- by the host pipeline (host_core.cpp, whose results
 // tests/test_host_core.py fuzzes against the oracle) and, unchanged, into k_chain_extract (seed_exec.hip), where one
 // wavefront runs them for one chaining problem.  Whatever the host does, the device does.
+//
+// Execution model ("Coop" policy C).  The code is written for a team of C::width() lanes that all run it with identical
+// scalar state: the sequential parts (the sort replay, the greedy extraction) are executed by every lane redundantly -- same
+// addresses, same values, one memory transaction per wave -- and the loops that merely fill, count, scatter or compact are
+// strided over the lanes (MPA_COOP_FOR, coop_compact) and followed by C::sync().  On the host the team is one lane
+// (CoopSerial): the strided loops are plain loops and the code is the sequential algorithm.
 #pragma once
 #include <cstdint>
 #include <cstddef>
@@ -49,9 +55,38 @@ struct ExtractScratch {
 	uint8_t *kept;
 	uint64_t *packed, *u_sorted;
 	SortRange *stack;        // [ends_cap / 64 + 4]
+	uint32_t *hist;          // [1280] bucket counts / cursors / limits of the digit passes, + two 256-entry tables of the two-level replay (shared by the team: LDS on the device)
 };
 
 #define MPA_ABSENT (~0ULL)   /* an anchor the view leaves out (alone in its neighbourhood) */
+
+struct CoopSerial {          // a team of one: the host
+	static MPA_HD int lane() { return 0; }
+	static MPA_HD int width() { return 1; }
+	static MPA_HD void sync() {}
+	static MPA_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }
+	static MPA_HD int rank(uint64_t) { return 0; }                     // lanes below this one whose ballot bit is set
+	static MPA_HD int popc(uint64_t m) { return (int)m; }
+	static MPA_HD int32_t reduce_max(int32_t v) { return v; }
+	static MPA_HD bool any(bool p) { return p; }
+	static MPA_HD void count(uint32_t *slot) { ++*slot; }              // histogram increment (shared counters)
+};
+#define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
+
+// order-preserving compaction of the i in [0, n) with pred(i): emit(i, k) for the k-th of them; returns how many
+template<class C, class Pred, class Emit> MPA_HD inline int64_t coop_compact(int64_t n, Pred pred, Emit emit)
+{
+	int64_t total = 0;
+	for (int64_t base = 0; base < n; base += C::width()) {
+		const int64_t i = base + C::lane();
+		const bool p = i < n && pred(i);
+		const uint64_t mask = C::ballot(p);
+		if (p) emit(i, total + C::rank(mask));
+		total += C::popc(mask);
+	}
+	C::sync();
+	return total;
+}
 
 // ---- radix_sort_mp128x (ksort.h:109-162): the order of EQUAL keys is part of the behaviour ------------------------------
 // Runs of <= 64 elements: insertion sort (stable).  Longer runs: in-place cycle-leader permutation by the byte at `shift`,
@@ -66,10 +101,10 @@ MPA_HD inline void pairs_insertion(Pair64 *beg, Pair64 *end)
 	}
 }
 
-// one digit level over [beg, end); cnt[256] receives the bucket sizes
-MPA_HD inline void pairs_digit_level(Pair64 *beg, Pair64 *end, int shift, uint32_t *cnt)
+// one digit level over [beg, end); hist[0..255] receives the bucket sizes (hist[256..767]: cursors and limits)
+MPA_HD inline void pairs_digit_level(Pair64 *beg, Pair64 *end, int shift, uint32_t *hist)
 {
-	uint32_t cursor[256], limit[256];
+	uint32_t *cnt = hist, *cursor = hist + 256, *limit = hist + 512;
 	for (int d = 0; d < 256; ++d) cnt[d] = 0;
 	for (Pair64 *p = beg; p != end; ++p) ++cnt[p->x >> shift & 0xff];
 	bool single = false;
@@ -93,14 +128,14 @@ MPA_HD inline void pairs_digit_level(Pair64 *beg, Pair64 *end, int shift, uint32
 }
 
 // every level below `shift` too (the reference recurses; the buckets are independent, so a work list gives the same result)
-MPA_HD inline void pairs_digit_pass(Pair64 *base, int64_t beg, int64_t end, int shift, SortRange *stack)
+MPA_HD inline void pairs_digit_pass(Pair64 *base, int64_t beg, int64_t end, int shift, SortRange *stack, uint32_t *hist)
 {
 	int64_t top = 0;
 	stack[top++] = SortRange{ beg, end, shift, 0 };
 	while (top > 0) {
 		const SortRange r = stack[--top];
-		uint32_t cnt[256];
-		pairs_digit_level(base + r.beg, base + r.end, r.shift, cnt);
+		const uint32_t *cnt = hist;
+		pairs_digit_level(base + r.beg, base + r.end, r.shift, hist);
 		if (r.shift == 0) continue;
 		const int next = r.shift > 8 ? r.shift - 8 : 0;
 		int64_t p = r.beg;
@@ -114,7 +149,7 @@ MPA_HD inline void pairs_digit_pass(Pair64 *base, int64_t beg, int64_t end, int 
 }
 
 // stack: [(end - beg) / 64 + 4]
-MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *stack)
+MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *stack, uint32_t *hist)
 {
 	if (end - beg <= 64) { pairs_insertion(beg, end); return; }
 	// A digit level at which every key has the same byte leaves the array untouched (each element is already in "its"
@@ -125,7 +160,7 @@ MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *sta
 	const uint64_t varying = all_or ^ all_and;
 	int shift = 56;
 	while (shift > 0 && ((varying >> shift) & 0xff) == 0) shift -= 8;
-	pairs_digit_pass(beg, 0, end - beg, shift, stack);
+	pairs_digit_pass(beg, 0, end - beg, shift, stack, hist);
 }
 
 // ---- the chain ends in the order the reference's sort leaves them, from a SPARSE view --------------------------------------
@@ -138,22 +173,29 @@ MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *sta
 //
 // The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest key
 // present) everywhere except at `items` (m of them, ascending pos).  Writes the m non-roots in their final order to out[0, m).
-MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, int64_t m, Pair64 *out)
+template<class C> MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, int64_t m, Pair64 *out, uint32_t *hist)
 {
 	if (m == 0) return;
-	uint32_t cnt[256], cursor[256], limit[256];
-	for (int d = 0; d < 256; ++d) cnt[d] = 0;
-	for (int64_t i = 0; i < m; ++i) ++cnt[items[i].e.x & 0xff];
+	uint32_t *cnt = hist, *cursor = hist + 256, *limit = hist + 512;
+	MPA_COOP_FOR(C, d, 256) cnt[d] = 0;
+	C::sync();
+	MPA_COOP_FOR(C, i, m) C::count(&cnt[items[i].e.x & 0xff]);
 	const int64_t n_root = n - m;
 	Pair64 *tail = out;
-	for (int64_t i = 0; i < m; ++i) tail[i] = Pair64{ (uint64_t)k0, MPA_ABSENT };
-	// the slots [n_root, n) as they are before the pass
+	MPA_COOP_FOR(C, i, m) tail[i] = Pair64{ (uint64_t)k0, MPA_ABSENT };
+	C::sync();
+	// the slots [n_root, n) as they are before the pass (items are ascending in pos: the first one at or behind n_root)
 	int64_t first_tail = 0;
-	while (first_tail < m && items[first_tail].pos < n_root) ++first_tail;
-	for (int64_t i = first_tail; i < m; ++i) tail[items[i].pos - n_root] = items[i].e;
+	{
+		int64_t lo = 0, hi = m;
+		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (items[mid].pos < n_root) lo = mid + 1; else hi = mid; }
+		first_tail = lo;
+	}
+	MPA_COOP_FOR(C, i, m - first_tail) tail[items[first_tail + i].pos - n_root] = items[first_tail + i].e;
+	C::sync();
 	{
 		uint32_t at = 0;
-		for (int d = 0; d < 256; ++d) cursor[d] = at, at += cnt[d], limit[d] = at;
+		for (int d = 0; d < 256; ++d) { const uint32_t c = cnt[d]; cursor[d] = at, at += c, limit[d] = at; }
 	}
 	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
 	for (int64_t i = 0; i < first_tail; ++i) {
@@ -180,55 +222,61 @@ MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, 
 		} while (d != k);
 		tail[cursor[k]++] = carried;
 	}
+	C::sync();
 }
 
 MPA_HD inline int64_t view_pos(const ChainView &v, int64_t i) { return v.pos ? (int64_t)v.pos[i] : i; }
 
 // Returns the number of chain ends written to out[] (the non-roots, in the reference's order), or -1 if the preconditions do
 // not hold (the caller then builds and sorts the full list).
-MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, const ExtractScratch &S, Pair64 *out)
+template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainParams &p, const ChainView &v, const ExtractScratch &S, Pair64 *out)
 {
 	const int64_t n = v.n_total;
 	if (p.min_cnt <= 1 || p.min_sc > p.kmer || n <= 64 || p.kmer < 0 || p.kmer > 255) return -1;
 	SparseItem *items = S.items, *moved = S.moved, *merged = S.merged;
-	int64_t n_items = 0, n_moved = 0, n_merged = 0;
+	int64_t n_moved = 0, n_merged = 0;
+	// the non-roots, ascending in position (f > kmer always holds for a chained anchor; belt and braces)
 	int32_t max_f = 0;
-	for (int64_t i = 0; i < v.m; ++i)
-		if (v.pred[i] >= 0) {
-			if (v.f[i] <= p.kmer) return -1;               // (f > kmer always holds for a chained anchor; belt and braces)
-			if (v.f[i] > max_f) max_f = v.f[i];
-			items[n_items++] = SparseItem{ view_pos(v, i), Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } };
-		}
-	if (max_f < 256) { replay_low_digit(n, p.kmer, items, n_items, out); return n_items; }
+	bool odd = false;
+	const int64_t n_items = coop_compact<C>(v.m,
+		[&](int64_t i) { const bool c = v.pred[i] >= 0; if (c) { if (v.f[i] <= p.kmer) odd = true; if (v.f[i] > max_f) max_f = v.f[i]; } return c; },
+		[&](int64_t i, int64_t k) { items[k] = SparseItem{ view_pos(v, i), Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } }; });
+	max_f = C::reduce_max(max_f);
+	if (C::any(odd)) return -1;
+	if (max_f < 256) { replay_low_digit<C>(n, p.kmer, items, n_items, out, S.hist); return n_items; }
 	if (max_f >= 65536) return -1;
 	// ---- two digit levels.  Level 1 (shift 8): bucket 0 = all scores below 256 (the roots among them) is the region
 	// [0, c0); walking it moves the high scores found there into the heads of their buckets behind c0, and what they
 	// displace from there -- low scores -- into the holes they leave.
-	uint32_t cnt8[256];
-	for (int d = 0; d < 256; ++d) cnt8[d] = 0;
+	uint32_t *cnt8 = S.hist, *cursor = S.hist + 256, *limit = S.hist + 512, *start = S.hist + 768, *cnt_hi = S.hist + 1024;
+	MPA_COOP_FOR(C, d, 256) cnt8[d] = 0;
+	C::sync();
 	int64_t m_hi = 0;
-	for (int64_t i = 0; i < n_items; ++i) if (items[i].e.x >= 256) ++cnt8[items[i].e.x >> 8 & 0xff], ++m_hi;
+	MPA_COOP_FOR(C, i, n_items) if (items[i].e.x >= 256) { C::count(&cnt8[items[i].e.x >> 8 & 0xff]); }
+	C::sync();
+	for (int d = 1; d < 256; ++d) m_hi += cnt8[d];         // (scores below 256 are not counted: bucket 0 stays 0)
 	const int64_t c0 = n - m_hi;
 	Pair64 *tail8 = S.tail8;
-	for (int64_t i = 0; i < m_hi; ++i) tail8[i] = Pair64{ (uint64_t)p.kmer, MPA_ABSENT };
+	MPA_COOP_FOR(C, i, m_hi) tail8[i] = Pair64{ (uint64_t)p.kmer, MPA_ABSENT };
+	C::sync();
 	{	// slots [c0, n) as they are: every view element there, roots included (their identity never matters)
-		int64_t i;
-		if (!v.pos) i = c0 < v.m ? c0 : v.m;
+		int64_t i0;
+		if (!v.pos) i0 = c0 < v.m ? c0 : v.m;
 		else {                                               // first view element at position >= c0
 			const int64_t want = c0 < INT32_MAX ? c0 : INT32_MAX;
 			int64_t lo = 0, hi = v.m;
 			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)v.pos[mid] < want) lo = mid + 1; else hi = mid; }
-			i = lo;
+			i0 = lo;
 		}
-		for (; i < v.m; ++i) tail8[view_pos(v, i) - c0] = Pair64{ (uint64_t)(int64_t)v.f[i], v.pred[i] >= 0 ? (uint64_t)i : MPA_ABSENT };
+		MPA_COOP_FOR(C, k, v.m - i0) { const int64_t i = i0 + k; tail8[view_pos(v, i) - c0] = Pair64{ (uint64_t)(int64_t)v.f[i], v.pred[i] >= 0 ? (uint64_t)i : MPA_ABSENT }; }
+		C::sync();
 	}
-	uint32_t cursor[256], limit[256], start[256];
 	{
 		uint32_t at = 0;
-		for (int d = 0; d < 256; ++d) start[d] = cursor[d] = at, at += d ? cnt8[d] : 0, limit[d] = at;
+		for (int d = 0; d < 256; ++d) { const uint32_t c = d ? cnt8[d] : 0u; start[d] = at, cursor[d] = at, at += c, limit[d] = at; }
 	}
 	for (int64_t q = 0; q < n_items; ++q) {
-		const SparseItem &it = items[q];
+		const SparseItem it = items[q];
 		if (it.pos >= c0) break;
 		if (it.e.x < 256) continue;                        // a low score inside region 0 stays where it is
 		Pair64 carried = it.e;
@@ -264,8 +312,11 @@ MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainParams &p, const Chain
 		}
 		while (b < n_moved) merged[n_merged++] = moved[b++];
 	}
+	C::sync();
+	for (int d = 0; d < 256; ++d) cnt_hi[d] = d ? cnt8[d] : 0u;   // (the level-2 passes below reuse the first 768 words of S.hist)
+	C::sync();
 	int64_t n_out = 0;
-	if (c0 > 64) { replay_low_digit(c0, p.kmer, merged, n_merged, out); n_out = n_merged; }
+	if (c0 > 64) { replay_low_digit<C>(c0, p.kmer, merged, n_merged, out, S.hist); n_out = n_merged; }
 	else {                                                  // a short bucket is insertion-sorted: stable
 		for (int64_t i = 1; i < n_merged; ++i) {
 			const SparseItem x = merged[i];
@@ -277,11 +328,12 @@ MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainParams &p, const Chain
 	}
 	// ---- level 2 inside the other buckets (all of it is present): digit pass or insertion sort, as the reference recurses
 	for (int d = 1; d < 256; ++d) {
-		Pair64 *b = tail8 + start[d], *e = b + cnt8[d];
-		if (cnt8[d] > 64) { uint32_t c2[256]; pairs_digit_level(b, e, 0, c2); }
-		else if (cnt8[d] > 1) pairs_insertion(b, e);
+		Pair64 *b = tail8 + start[d], *e = b + cnt_hi[d];
+		if (cnt_hi[d] > 64) pairs_digit_level(b, e, 0, S.hist);
+		else if (cnt_hi[d] > 1) pairs_insertion(b, e);
 		for (Pair64 *x = b; x != e; ++x) out[n_out++] = *x;
 	}
+	C::sync();
 	return n_out;
 }
 
@@ -297,8 +349,8 @@ MPA_HD inline bool chain_ends_sparse_possible(const ChainParams &p, const ChainV
 // map.c:186-192, whose chains are dissolved again by the sort that follows it): no chain list, no layout, and no sort either
 // -- the view is in ascending anchor order, so marking the kept anchors and reading the view through gives them sorted.
 // Returns 0, or 1 when the full list of chain ends is needed and S.ends_cap is too small for it (nothing written).
-MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, const ExtractScratch &S, uint64_t *a_out, int64_t *n_a_out, uint64_t *u, int64_t *n_u_out,
-                                     bool set_only)
+template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, const ExtractScratch &S, uint64_t *a_out, int64_t *n_a_out, uint64_t *u, int64_t *n_u_out,
+                                                       bool set_only)
 {
 	int64_t n_u = 0, n_order = 0;
 	*n_a_out = 0, *n_u_out = 0;
@@ -306,7 +358,7 @@ MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, c
 	const int32_t *f = v.f, *pred = v.pred;
 	int32_t *mark = S.mark, *order = S.order;
 	Pair64 *ends = S.ends;
-	int64_t n_ends = sorted_chain_ends_sparse(p, v, S, ends);
+	int64_t n_ends = sorted_chain_ends_sparse<C>(p, v, S, ends);
 	if (n_ends < 0) {
 		// the full list: absent anchors are roots (score kmer); they can only be left out when min_cnt rejects them anyway
 		if (v.n_total > S.ends_cap) return 1;
@@ -318,10 +370,13 @@ MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, c
 				++vi;
 			} else if (p.kmer >= p.min_sc) ends[n_ends++] = Pair64{ (uint64_t)(int64_t)p.kmer, MPA_ABSENT };
 		}
-		sort_pairs_by_x_core(ends, ends + n_ends, S.stack);
+		C::sync();
+		sort_pairs_by_x_core(ends, ends + n_ends, S.stack, S.hist);
+		C::sync();
 	}
 	if (n_ends == 0) return 0;
-	for (int64_t i = 0; i < v.m; ++i) mark[i] = 0;
+	MPA_COOP_FOR(C, i, v.m) mark[i] = 0;
+	C::sync();
 	// anchor indices of the kept chains, each chain from its END backwards
 	for (int64_t k = n_ends - 1; k >= 0; --k) {
 		if (ends[k].y == MPA_ABSENT) continue;
@@ -352,15 +407,16 @@ MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, c
 		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)cnt;
 		else n_order = before;                              // rejected chains keep their anchors claimed
 	}
+	C::sync();
 	if (n_u == 0) return 0;
 	if (set_only) {
 		// (mark: 1 = claimed; the anchors of the kept chains are exactly those in `order`)
 		uint8_t *kept = S.kept;
-		for (int64_t i = 0; i < v.m; ++i) kept[i] = 0;
-		for (int64_t i = 0; i < n_order; ++i) kept[order[i]] = 1;
-		int64_t k = 0;
-		for (int64_t i = 0; i < v.m; ++i) if (kept[i]) a_out[k++] = v.a[i];
-		*n_a_out = k;
+		MPA_COOP_FOR(C, i, v.m) kept[i] = 0;
+		C::sync();
+		MPA_COOP_FOR(C, i, n_order) kept[order[i]] = 1;
+		C::sync();
+		*n_a_out = coop_compact<C>(v.m, [&](int64_t i) { return kept[i] != 0; }, [&](int64_t i, int64_t k) { a_out[k] = v.a[i]; });
 		return 0;
 	}
 	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
@@ -375,7 +431,9 @@ MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, c
 			k += cnt;
 		}
 	}
-	sort_pairs_by_x_core(first, first + n_u, S.stack);
+	C::sync();
+	sort_pairs_by_x_core(first, first + n_u, S.stack, S.hist);
+	C::sync();
 	int64_t k = 0;
 	for (int64_t c = 0; c < n_u; ++c) {
 		const uint32_t which = (uint32_t)first[c].y;
@@ -384,7 +442,9 @@ MPA_HD inline int chain_extract_core(const ChainParams &p, const ChainView &v, c
 		for (int64_t j = 0; j < cnt; ++j) a_out[k + j] = packed[from + j];
 		k += cnt;
 	}
+	C::sync();
 	for (int64_t c = 0; c < n_u; ++c) u[c] = u_sorted[c];
+	C::sync();
 	*n_a_out = k, *n_u_out = n_u;
 	return 0;
 }

@@ -11,6 +11,7 @@
 // roofline record).  The seeding-stage drivers (dev_prechain_forward, dev_refine_scan; kernels in seed_exec.hip) live
 // here too.  There is no CPU fallback here by design.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <algorithm>
 #include <functional>
 #include <mutex>
@@ -117,13 +118,22 @@ namespace mpa {
 // that gives the process a CPU quota (16 cores per GPU on the boxes this was measured on) spinning waiters eat the very cores
 // the host stages need.  An event created with hipEventBlockingSync makes the runtime block on the signal instead.
 // MPA_SPIN_WAIT=1 restores the spinning wait.
+// Measured (round 3): even the "blocking" hipEventSynchronize costs a waiting thread about half a core, so the wait polls the
+// event and SLEEPS in between (MPA_WAIT_US, default 100 us per nap after a short burst of immediate polls; 0 = the runtime's
+// blocking wait).
 static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 {
 	static const bool spin = [] { const char *e = getenv("MPA_SPIN_WAIT"); return e && atoi(e) != 0; }();
+	static const int nap_us = [] { const char *e = getenv("MPA_WAIT_US"); return e ? atoi(e) : 100; }();
 	if (spin || !ctx->wait_ev) return hipStreamSynchronize(s);
 	hipError_t e = hipEventRecord(ctx->wait_ev, s);
 	if (e != hipSuccess) return e;
-	return hipEventSynchronize(ctx->wait_ev);
+	if (nap_us <= 0) return hipEventSynchronize(ctx->wait_ev);
+	for (int polls = 0;; ++polls) {
+		e = hipEventQuery(ctx->wait_ev);
+		if (e != hipErrorNotReady) return e;
+		if (polls >= 8) { struct timespec ts = { 0, (long)nap_us * 1000L }; nanosleep(&ts, nullptr); }
+	}
 }
 
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)

@@ -79,7 +79,8 @@ void sort_pairs_by_x(Pair64 *beg, Pair64 *end)
 	static thread_local std::vector<SortRange> stack;
 	const size_t need = (size_t)(end - beg) / 64 + 4;
 	if (stack.size() < need) stack.resize(need);
-	sort_pairs_by_x_core(beg, end, stack.data());
+	uint32_t hist[768];
+	sort_pairs_by_x_core(beg, end, stack.data(), hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,17 +320,18 @@ static void chain_extract_impl(const ChainParams &p, const ChainView &v, std::ve
 	auto grow = [](auto &vec, size_t n) { if (vec.size() < n) vec.resize(n + n / 4 + 16); };
 	grow(mark, m), grow(order, m), grow(ends, std::max(ends_cap, m)), grow(tail8, m), grow(first, m), grow(items, m), grow(moved, m), grow(merged, m);
 	grow(kept, m), grow(packed, m), grow(u_sorted, m), grow(stack, std::max(ends_cap, m) / 64 + 4);
+	uint32_t hist[1280];
 	const ExtractScratch S{ mark.data(), order.data(), ends.data(), (int64_t)std::max(ends_cap, m), items.data(), moved.data(), merged.data(), tail8.data(), first.data(),
-	                        kept.data(), packed.data(), u_sorted.data(), stack.data() };
+	                        kept.data(), packed.data(), u_sorted.data(), stack.data(), hist };
 	static thread_local std::vector<uint64_t> a_buf, u_buf;  // (grow-only: a resize of the outputs would zero m words per call)
 	grow(a_buf, m), grow(u_buf, m);
 	int64_t n_a = 0, n_u = 0;
-	int rc = chain_extract_core(p, v, S, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
+	int rc = chain_extract_core<CoopSerial>(p, v, S, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
 	if (rc != 0) {                                          // (a sparse view whose preconditions failed after all: the full list)
 		grow(ends, (size_t)v.n_total), grow(stack, (size_t)v.n_total / 64 + 4);
 		ExtractScratch S2 = S;
 		S2.ends = ends.data(), S2.ends_cap = v.n_total, S2.stack = stack.data();
-		rc = chain_extract_core(p, v, S2, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
+		rc = chain_extract_core<CoopSerial>(p, v, S2, a_buf.data(), &n_a, u_buf.data(), &n_u, set_only);
 	}
 	a_out.assign(a_buf.begin(), a_buf.begin() + n_a), u.assign(u_buf.begin(), u_buf.begin() + n_u);
 }

@@ -260,22 +260,42 @@ struct ExtractArgs {
 	int32_t set_only;
 };
 
+// the team of chain_core.h on the device: the 64 lanes of one wavefront
+struct CoopWave {
+	static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
+	static __device__ __forceinline__ int width() { return 64; }
+	// lanes of one wave share their L1: ordering their global / LDS accesses needs no cache action, only completion + a barrier
+	static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+	static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+	static __device__ __forceinline__ int rank(uint64_t m) { return __popcll(m & ((1ull << lane()) - 1ull)); }
+	static __device__ __forceinline__ int popc(uint64_t m) { return __popcll(m); }
+	static __device__ __forceinline__ int32_t reduce_max(int32_t v)
+	{
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { const int32_t w = __shfl_xor(v, o); v = w > v ? w : v; }
+		return v;
+	}
+	static __device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0; }
+	static __device__ __forceinline__ void count(uint32_t *slot) { atomicAdd(slot, 1u); }
+};
+
 __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)
 {
+	__shared__ uint32_t hist[1280];
 	const int32_t q = blockIdx.x;
-	if (q >= n_prob || threadIdx.x != 0) return;
+	if (q >= n_prob) return;
 	const int64_t off = x.first[q];
 	const int64_t m = x.cnt ? x.cnt[q] : x.first[q + 1] - off;
-	x.n_a[q] = 0, x.n_u[q] = 0;
-	if (m <= 0) return;
+	if (m <= 0) { if (threadIdx.x == 0) x.n_a[q] = 0, x.n_u[q] = 0; return; }
 	const int64_t n_total = x.ntot_first ? x.ntot_first[q + 1] - x.ntot_first[q] : m;
 	const ChainView v{ n_total, m, x.v_pos ? x.v_pos + off : nullptr, x.v_f + off, x.v_pred + off, x.v_a + off };
 	const int64_t eoff = off + 64 * (int64_t)q;
 	const ExtractScratch S{ x.mark + off, x.order + off, x.ends + eoff, m + 64, x.items + off, x.moved + off, x.merged + off, x.tail8 + off, x.firstp + off,
-	                        x.kept + off, x.packed + off, x.u_sorted + off, x.stack + (eoff / 64 + 5 * (int64_t)q) };
+	                        x.kept + off, x.packed + off, x.u_sorted + off, x.stack + (eoff / 64 + 5 * (int64_t)q), hist };
 	int64_t n_a = 0, n_u = 0;
-	const int rc = chain_extract_core(x.p, v, S, x.a_out + off, &n_a, x.u_out + off, &n_u, x.set_only != 0);
-	if (rc != 0) { x.status[q] = 1; return; }
+	const int rc = chain_extract_core<CoopWave>(x.p, v, S, x.a_out + off, &n_a, x.u_out + off, &n_u, x.set_only != 0);
+	if (threadIdx.x != 0) return;
+	if (rc != 0) { x.status[q] = 1; x.n_a[q] = 0, x.n_u[q] = 0; return; }
 	x.n_a[q] = n_a, x.n_u[q] = n_u;
 }
 
