@@ -70,6 +70,9 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD int32_t reduce_max(int32_t v) { return v; }
 	static MPA_HD bool any(bool p) { return p; }
 	static MPA_HD void count(uint32_t *slot) { ++*slot; }              // histogram increment (shared counters)
+	static MPA_HD void atomic_min(int32_t *slot, int32_t v) { if (v < *slot) *slot = v; }
+	static MPA_HD int64_t scan_excl(int64_t v, int64_t *total) { *total = v; return 0; }   // sum of v over the lanes below this one; the team's total
+	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_EXTRACT_PROF)
 };
 #define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
 
@@ -304,13 +307,21 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 	}
 	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
 	{
-		int64_t a = 0, b = 0;
-		while (a < n_items && items[a].pos < c0) {
-			if (items[a].e.x >= 256) { ++a; continue; }
-			while (b < n_moved && moved[b].pos < items[a].pos) merged[n_merged++] = moved[b++];
-			merged[n_merged++] = items[a++];
+		C::sync();
+		int64_t a_end;                                     // items [0, a_end) sit in region 0
+		{
+			int64_t lo = 0, hi = n_items;
+			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (items[mid].pos < c0) lo = mid + 1; else hi = mid; }
+			a_end = lo;
 		}
-		while (b < n_moved) merged[n_merged++] = moved[b++];
+		const int64_t n_low = coop_compact<C>(a_end, [&](int64_t i) { return items[i].e.x < 256; }, [&](int64_t i, int64_t k) { merged[k] = items[i]; });
+		// ... merged with the moved ones by position (both ascending, positions distinct): backwards, in place
+		int64_t i = n_low - 1, j = n_moved - 1, k = n_low + n_moved - 1;
+		while (j >= 0) {
+			if (i >= 0 && merged[i].pos > moved[j].pos) merged[k--] = merged[i--];
+			else merged[k--] = moved[j--];
+		}
+		n_merged = n_low + n_moved;
 	}
 	C::sync();
 	for (int d = 0; d < 256; ++d) cnt_hi[d] = d ? cnt8[d] : 0u;   // (the level-2 passes below reuse the first 768 words of S.hist)
@@ -331,10 +342,11 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		Pair64 *b = tail8 + start[d], *e = b + cnt_hi[d];
 		if (cnt_hi[d] > 64) pairs_digit_level(b, e, 0, S.hist);
 		else if (cnt_hi[d] > 1) pairs_insertion(b, e);
-		for (Pair64 *x = b; x != e; ++x) out[n_out++] = *x;
 	}
 	C::sync();
-	return n_out;
+	MPA_COOP_FOR(C, i, m_hi) out[n_out + i] = tail8[i];   // (buckets 1..255 lie back to back from tail8[0] on)
+	C::sync();
+	return n_out + m_hi;
 }
 
 // Can the view be extracted without the full list of chain ends (one entry per anchor of the problem, absent ones included)?
@@ -354,6 +366,7 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 {
 	int64_t n_u = 0, n_order = 0;
 	*n_a_out = 0, *n_u_out = 0;
+	C::mark_time(0);
 	const int32_t max_drop = p.is_spliced ? INT32_MAX : p.bw;
 	const int32_t *f = v.f, *pred = v.pred;
 	int32_t *mark = S.mark, *order = S.order;
@@ -374,40 +387,79 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 		sort_pairs_by_x_core(ends, ends + n_ends, S.stack, S.hist);
 		C::sync();
 	}
+	C::mark_time(1);
 	if (n_ends == 0) return 0;
-	MPA_COOP_FOR(C, i, v.m) mark[i] = 0;
-	C::sync();
-	// anchor indices of the kept chains, each chain from its END backwards
-	for (int64_t k = n_ends - 1; k >= 0; --k) {
-		if (ends[k].y == MPA_ABSENT) continue;
-		const int64_t tail = (int64_t)ends[k].y;
-		const int32_t tail_f = (int32_t)ends[k].x;
-		if (mark[tail] != 0) continue;
-		// An unclaimed anchor without predecessor is a one-anchor chain.  When min_cnt rejects those, the only trace it
-		// would leave is its own claim mark, which nothing reads any more: every anchor chained onto it scores above
-		// kmer == f[tail] and has therefore been visited already.
-		if (pred[tail] < 0 && p.min_cnt > 1) continue;
-		// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
-		int64_t cut = tail, walk = tail, stop = -1;
-		int32_t best_suffix = 0;
-		do {
-			mark[walk] = 2;
-			stop = walk = pred[walk];
-			const int32_t s = walk < 0 ? tail_f : tail_f - f[walk];
-			if (s > best_suffix) best_suffix = s, cut = walk;
-			else if (best_suffix - s > max_drop) break;
-		} while (walk >= 0 && mark[walk] == 0);
-		for (int64_t x = tail; x >= 0 && x != stop; x = pred[x]) mark[x] = 0;
-		// claim the anchors of the suffix
-		const int64_t before = n_order;
-		int64_t x = tail;
-		for (; x != cut; x = pred[x]) order[n_order++] = (int32_t)x, mark[x] = 1;
-		const int32_t sc = x < 0 ? tail_f : tail_f - f[x];
-		const int64_t cnt = n_order - before;
-		if (sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt) u[n_u++] = (uint64_t)sc << 32 | (uint64_t)cnt;
-		else n_order = before;                              // rejected chains keep their anchors claimed
+	// ---- the greedy extraction (chain.c:37-75): chain ends best first; a chain walks back until it meets a claimed anchor.
+	// Chains only ever touch anchors of their own predecessor TREE, so ends of different trees do not depend on each other:
+	// the team takes C::width() consecutive ends at a time, one per lane, and only lanes whose ends sit in the same tree take
+	// turns, in the order of the list (the lowest lane goes first).  With a team of one this is the sequential loop.
+	const bool team = C::width() > 1;
+	int32_t *root = (int32_t*)S.items, *owner = root + v.m;      // (the item lists of the sort replay are dead by now)
+	MPA_COOP_FOR(C, i, v.m) {
+		mark[i] = 0;
+		if (team) owner[i] = INT32_MAX, root[i] = pred[i] < 0 ? (int32_t)i : pred[i];
 	}
 	C::sync();
+	if (team) {                                               // the root of every anchor's tree, by pointer jumping
+		for (;;) {
+			bool changed = false;
+			MPA_COOP_FOR(C, i, v.m) { const int32_t r = root[i], rr = root[r]; if (rr != r) root[i] = rr, changed = true; }
+			C::sync();
+			if (!C::any(changed)) break;
+		}
+	}
+	C::mark_time(2);
+	for (int64_t kb = n_ends - 1; kb >= 0; kb -= C::width()) {
+		const int64_t k = kb - C::lane();
+		const bool have = k >= 0 && ends[k >= 0 ? k : 0].y != MPA_ABSENT;
+		const int64_t tail = have ? (int64_t)ends[k].y : 0;
+		const int32_t tail_f = have ? (int32_t)ends[k].x : 0;
+		const int32_t my_root = team && have ? root[tail] : 0;
+		bool pending = have, accepted = false;
+		int64_t cnt = 0;
+		int32_t sc = 0;
+		while (C::any(pending)) {
+			if (team) { if (pending) C::atomic_min(&owner[my_root], (int32_t)C::lane()); C::sync(); }
+			const bool win = pending && (!team || owner[my_root] == (int32_t)C::lane());
+			// An unclaimed anchor without predecessor is a one-anchor chain.  When min_cnt rejects those, the only trace it
+			// would leave is its own claim mark, which nothing reads any more: every anchor chained onto it scores above
+			// kmer == f[tail] and has therefore been visited already.
+			if (win && mark[tail] == 0 && !(pred[tail] < 0 && p.min_cnt > 1)) {
+				// where does the best-scoring suffix of this chain start?  walk back until a claimed anchor or the chain's root
+				int64_t cut = tail, walk = tail, stop = -1;
+				int32_t best_suffix = 0;
+				do {
+					mark[walk] = 2;
+					stop = walk = pred[walk];
+					const int32_t sfx = walk < 0 ? tail_f : tail_f - f[walk];
+					if (sfx > best_suffix) best_suffix = sfx, cut = walk;
+					else if (best_suffix - sfx > max_drop) break;
+				} while (walk >= 0 && mark[walk] == 0);
+				for (int64_t x = tail; x >= 0 && x != stop; x = pred[x]) mark[x] = 0;
+				// claim the anchors of the suffix (a rejected chain keeps them claimed)
+				int64_t x = tail;
+				for (; x != cut; x = pred[x]) mark[x] = 1, ++cnt;
+				sc = x < 0 ? tail_f : tail_f - f[x];
+				accepted = sc >= p.min_sc && cnt > 0 && cnt >= p.min_cnt;
+			}
+			C::sync();
+			if (team && win) owner[my_root] = INT32_MAX;
+			pending = pending && !win;
+			C::sync();
+		}
+		// the kept chains of this group in the order of the list (= lane order): u, and their anchors from the END backwards
+		const uint64_t acc = C::ballot(accepted);
+		int64_t tot = 0;
+		const int64_t off = C::scan_excl(accepted ? cnt : 0, &tot);
+		if (accepted) {
+			u[n_u + C::rank(acc)] = (uint64_t)sc << 32 | (uint64_t)cnt;
+			int64_t x = tail;
+			for (int64_t j = 0; j < cnt; ++j, x = pred[x]) order[n_order + off + j] = (int32_t)x;
+		}
+		n_u += C::popc(acc), n_order += tot;
+	}
+	C::sync();
+	C::mark_time(3);
 	if (n_u == 0) return 0;
 	if (set_only) {
 		// (mark: 1 = claimed; the anchors of the kept chains are exactly those in `order`)
@@ -417,6 +469,7 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 		MPA_COOP_FOR(C, i, n_order) kept[order[i]] = 1;
 		C::sync();
 		*n_a_out = coop_compact<C>(v.m, [&](int64_t i) { return kept[i] != 0; }, [&](int64_t i, int64_t k) { a_out[k] = v.a[i]; });
+		C::mark_time(4);
 		return 0;
 	}
 	// ---- lay the chains out in ascending anchor order, chains sorted by their first target position (chain.c:77-110)
@@ -446,6 +499,7 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 	for (int64_t c = 0; c < n_u; ++c) u[c] = u_sorted[c];
 	C::sync();
 	*n_a_out = k, *n_u_out = n_u;
+	C::mark_time(4);
 	return 0;
 }
 

@@ -633,7 +633,7 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	const size_t o_mf = carve(M * 4), o_mpred = carve(M * 4), o_mmark = carve(M * 4);
 	const size_t o_out_a = carve(M * 8), o_out_u = carve(M * 8), o_na = carve(NQ * 8 + 8), o_nu = carve(NQ * 8 + 8), o_offa = carve(NQ * 8 + 16), o_offu = carve(NQ * 8 + 16);
 	int rc;
-	if ((rc = B.x_all.ensure(at))) return rc;
+	if (at > B.x_all.cap && (rc = B.x_all.ensure(at + at / 3))) return rc;   // (generous: a re-allocation is a hipFree, which waits for the whole device)
 	char *X = B.x_all.as<char>();
 	HIP_TRY(hipMemsetAsync(X + o_status, 0, NQ * 4 + 16, s));
 	const unsigned nblk2 = (unsigned)((n2 + 255) / 256), nblkm = (unsigned)((m + 255) / 256);
@@ -648,8 +648,40 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	xa.kept = (uint8_t*)(X + o_kept), xa.packed = (uint64_t*)(X + o_packed), xa.u_sorted = (uint64_t*)(X + o_usorted), xa.stack = (SortRange*)(X + o_stack);
 	xa.a_out = (uint64_t*)(X + o_pre_a), xa.u_out = (uint64_t*)(X + o_pre_u), xa.n_a = (int64_t*)(X + o_pre_na), xa.n_u = (int64_t*)(X + o_pre_nu);
 	xa.status = (int32_t*)(X + o_status), xa.p = pre, xa.set_only = 1;
+	// MPA_EXTRACT_PROF=1 (debug): per-phase wall clock of the extraction kernel, averaged over the problems of the launch
+	static const bool prof = [] { const char *e = getenv("MPA_EXTRACT_PROF"); return e && atoi(e) != 0; }();
+	long long *d_prof = nullptr;
+	auto prof_begin = [&]() -> int {
+		if (!prof) return MPA_OK;
+		HIP_TRY(hipMalloc((void**)&d_prof, NQ * 64 + 64));
+		HIP_TRY(hipMemsetAsync(d_prof, 0, NQ * 64, s));
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &d_prof, sizeof(d_prof), 0, hipMemcpyHostToDevice, s));
+		return MPA_OK;
+	};
+	auto prof_end = [&](const char *what) -> int {
+		if (!prof) return MPA_OK;
+		std::vector<long long> h(NQ * 8);
+		HIP_TRY(hipMemcpyAsync(h.data(), d_prof, NQ * 64, hipMemcpyDeviceToHost, s));
+		HIP_TRY(wait_stream(ctx, s));
+		double sum[4] = { 0, 0, 0, 0 }, mx = 0;
+		int64_t cnt = 0;
+		for (size_t q = 0; q < NQ; ++q) {
+			if (!h[q * 8 + 4] || !h[q * 8]) continue;
+			for (int k = 0; k < 4; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]) * 1e-5;   // 100 MHz ticks -> ms
+			mx = std::max(mx, (double)(h[q * 8 + 4] - h[q * 8]) * 1e-5), ++cnt;
+		}
+		fprintf(stderr, "[mpa-extract-prof] %s: %lld problems; mean ms: sort replay %.2f, trees %.2f, extraction %.2f, output %.2f; slowest problem %.2f ms\n", what, (long long)cnt,
+		        sum[0] / std::max<int64_t>(cnt, 1), sum[1] / std::max<int64_t>(cnt, 1), sum[2] / std::max<int64_t>(cnt, 1), sum[3] / std::max<int64_t>(cnt, 1), mx);
+		long long *none = nullptr;
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &none, sizeof(none), 0, hipMemcpyHostToDevice, s));
+		HIP_TRY(wait_stream(ctx, s));
+		(void)hipFree(d_prof), d_prof = nullptr;
+		return MPA_OK;
+	};
+	if ((rc = prof_begin())) return rc;
 	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
 	HIP_TRY(hipGetLastError());
+	if ((rc = prof_end("pre-chain"))) return rc;
 	// the main chain over the survivors: forward pass ...
 	PreParams pm;
 	pm.max_dist_x = std::max(mainp.max_dist_x, mainp.bw), pm.max_dist_y = mainp.max_dist_y;
@@ -665,7 +697,9 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	xa.v_pos = nullptr, xa.v_f = (const int32_t*)(X + o_mf), xa.v_pred = (const int32_t*)(X + o_mpred), xa.v_a = (const uint64_t*)(X + o_pre_a);
 	xa.a_out = (uint64_t*)(X + o_out_a), xa.u_out = (uint64_t*)(X + o_out_u), xa.n_a = (int64_t*)(X + o_na), xa.n_u = (int64_t*)(X + o_nu);
 	xa.p = mainp, xa.set_only = 0;
+	if ((rc = prof_begin())) return rc;
 	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
+	if ((rc = prof_end("main chain"))) return rc;
 	hipLaunchKernelGGL(k_offsets2, dim3(1), dim3(256), 0, s, (const int64_t*)(X + o_na), (const int64_t*)(X + o_nu), n_query, (int64_t*)(X + o_offa), (int64_t*)(X + o_offu));
 	HIP_TRY(hipGetLastError());
 	// offsets + status down, then the chains themselves straight into pinned memory

@@ -260,6 +260,9 @@ struct ExtractArgs {
 	int32_t set_only;
 };
 
+// MPA_EXTRACT_PROF: wall-clock stamps of k_chain_extract's phases, 8 per problem (start, chain ends sorted, trees, extraction, end)
+__device__ long long *g_extract_prof = nullptr;
+
 // the team of chain_core.h on the device: the 64 lanes of one wavefront
 struct CoopWave {
 	static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
@@ -277,6 +280,16 @@ struct CoopWave {
 	}
 	static __device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0; }
 	static __device__ __forceinline__ void count(uint32_t *slot) { atomicAdd(slot, 1u); }
+	static __device__ __forceinline__ void atomic_min(int32_t *slot, int32_t v) { atomicMin(slot, v); }
+	static __device__ __forceinline__ int64_t scan_excl(int64_t v, int64_t *total)
+	{
+		int64_t inc = v;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const int64_t w = __shfl_up(inc, o); if (lane() >= o) inc += w; }
+		*total = __shfl(inc, 63);
+		return inc - v;
+	}
+	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
 };
 
 __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)

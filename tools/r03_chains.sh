@@ -15,9 +15,10 @@ run base "MPA_TIMING=1" ""
 grep "mpa-cpu" $OUT/base.err | tail -10
 python tools/timing_agg.py < $OUT/base.err > $OUT/timing_base.txt
 grep -E "seed:|A1|A\.|plan:" $OUT/timing_base.txt
+run prof "MPA_EXTRACT_PROF=1" "--no-cpu-baseline --steps 6 --warmup 2"
+grep "extract-prof" $OUT/prof.err | tail -6
 run hostchains "MPA_DEVICE_CHAINS=0" "--no-cpu-baseline"
 run seed3 "MPA_SEEDERS=3" "--no-cpu-baseline"
-run seed4 "MPA_SEEDERS=4" "--no-cpu-baseline"
 run seed4l6 "MPA_SEEDERS=4 MPA_DP_LANES=6" "--no-cpu-baseline"
 run trace "MPA_TRACE=1 MPA_SEEDERS=3" "--no-cpu-baseline"
 python tools/gantt.py $OUT/trace.err > $OUT/gantt.txt 2>&1; head -14 $OUT/gantt.txt
