@@ -164,6 +164,16 @@ def host_cpu_seconds():
     return r.ru_utime + r.ru_stime
 
 
+def cgroup_throttled():
+    """(periods throttled, seconds throttled) of this process's cgroup so far: a CPU quota below the visible cores freezes ALL
+    threads of the process whenever a 100 ms period's budget is spent"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)) / 1e6
+    except Exception:
+        return 0, 0.0
+
+
 def run_stream(mpa, mdist, wl, ctx, n_steps, n_threads, rank, world, device):
     """One job of n_steps mini-batches (batch k of the job = distinct batch k mod n_distinct), shared by all ranks: every rank's
     mpa_map_batches_claim() stream pulls the next unclaimed batch whenever its pipeline has room (miniprot_amd/dist.py), the
@@ -183,12 +193,15 @@ def measure(mpa, mdist, wl, ctx, steps, warmup, n_threads, rank, world, device, 
     ctx.dp_stats(total=True, reset=True)
     sync()
     cpu0 = host_cpu_seconds()
+    thr0 = cgroup_throttled()
     t1 = time.time()
     texts = run_stream(mpa, mdist, wl, ctx, steps, n_threads, rank, world, device)
     sync()
     elapsed = time.time() - t1
     st = ctx.dp_stats(total=True)
     st["host_cpu_s"] = host_cpu_seconds() - cpu0              # user + system CPU time of THIS rank's process (all its threads) inside the timed region
+    thr1 = cgroup_throttled()
+    st["throttled_periods"], st["throttled_s"] = thr1[0] - thr0[0], thr1[1] - thr0[1]
     return elapsed, texts, st
 
 
@@ -353,7 +366,9 @@ def main():
                    "host_threads_per_rank": n_threads, "host_cpus_visible": ncpu, "host_cpu_quota": ncpu_eff,
                    # CPU seconds (user + system, getrusage) all ranks' processes spent inside the timed region, per step and as a share of
                    # the host: what one GPU's pipeline costs the host it shares with the other ranks
-                   "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9)}
+                   "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9),
+                   # (rank 0's cgroup: 100 ms scheduler periods in which the quota ran out, and thread-seconds spent frozen because of it)
+                   "host_throttled": {"periods": st.get("throttled_periods"), "thread_seconds": st.get("throttled_s")}}
         ctx.close()
         wl.idx.close()
         barrier()
@@ -384,7 +399,7 @@ def main():
                           "batching": "stream of mini-batches (mpa_map_batches)", "host_threads_per_rank": r["host_threads_per_rank"]},
                "elapsed_s": r["elapsed_s"], "aligned_residues": r["aligned_residues"], "input_residues_per_s": r["input_residues_per_s"],
                "paf_identical": r["paf_identical"], "identity": r["identity"], "md5_first_pass": r["md5_first_pass"], "steps_all_gpus": r["steps_all_gpus"],
-               "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"],
+               "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"], "host_throttled": r["host_throttled"],
                "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
         out.update(extra)
         print(json.dumps(out))

@@ -38,7 +38,9 @@ struct DevBuf {
 		if (bytes <= cap) return MPA_OK;
 		if (p) (void)hipFree(p);
 		p = nullptr, cap = 0;
-		size_t want = bytes + (bytes >> 3) + 4096;
+		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
+		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
+		size_t want = bytes + bytes / 3 + 4096;
 		hipError_t e = hipMalloc(&p, want);
 		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
@@ -63,7 +65,7 @@ struct HostPinned {
 		if (bytes <= cap) return MPA_OK;
 		if (p) (void)hipHostFree(p);
 		p = nullptr, cap = 0;
-		const size_t want = bytes + (bytes >> 2) + 4096;
+		const size_t want = bytes + bytes / 2 + 4096;           // (re-pinning host memory is slow: grow in big steps)
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return MPA_ERR_HIP; }
 		cap = want;
 		return MPA_OK;
@@ -82,7 +84,7 @@ struct SeedBufs {
 	HostPinned h_meta, h_back;                                             // ... their staging (up) and qfirst2 / flags / cfirst (down)
 	DevBuf x_all;                                                          // device chaining: views, extraction scratch, survivors, main-chain state, chains (carved up per call)
 	HostPinned h_U, h_A, h_xoff;                                           // ... the chains of every query (down)
-	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first;                // chain forward pass (k_chain_fwd)
+	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first, c_long;        // chain forward pass (k_chain_fwd, k_chain_fwd_wave: list of long runs + its counter)
 	HostPinned hc_a, hc_f, hc_pred;
 };
 
@@ -333,7 +335,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
 	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
-	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first,
+	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
 	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1],
 	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all }) b->release();
 	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_U, &B.h_A, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
@@ -631,6 +633,8 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	             o_kept = carve(M), o_packed = carve(M * 8), o_usorted = carve(M * 8), o_stack = carve((M / 64 + 6 * NQ + 16) * sizeof(SortRange));
 	const size_t o_pre_a = carve(M * 8), o_pre_u = carve(M * 8), o_pre_na = carve(NQ * 8 + 8), o_pre_nu = carve(NQ * 8 + 8), o_status = carve(NQ * 4 + 16);
 	const size_t o_mf = carve(M * 4), o_mpred = carve(M * 4), o_mmark = carve(M * 4);
+	const int32_t kSerialRun = 48;                          // longer runs of the main chain get a wavefront each (k_chain_fwd_wave)
+	const size_t long_cap = M / (size_t)(kSerialRun + 1) + 16, o_long = carve(long_cap * sizeof(LongRun)), o_nlong = carve(64);
 	const size_t o_out_a = carve(M * 8), o_out_u = carve(M * 8), o_na = carve(NQ * 8 + 8), o_nu = carve(NQ * 8 + 8), o_offa = carve(NQ * 8 + 16), o_offu = carve(NQ * 8 + 16);
 	int rc;
 	if (at > B.x_all.cap && (rc = B.x_all.ensure(at + at / 3))) return rc;   // (generous: a re-allocation is a hipFree, which waits for the whole device)
@@ -689,8 +693,11 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	pm.bw = mainp.bw, pm.max_skip = mainp.max_skip, pm.max_iter = mainp.max_iter, pm.kmer = mainp.kmer, pm.bbit = mainp.bbit;
 	pm.is_spliced = mainp.is_spliced, pm.coef_log = mainp.coef_log, pm.max_dblock = pm.max_dist_x >> mainp.bbit;
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblkm), dim3(256), 0, s, m, pm.kmer, (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark), (uint32_t*)(X + o_mark));
+	HIP_TRY(hipMemsetAsync(X + o_nlong, 0, 64, s));
 	hipLaunchKernelGGL(k_chain_fwd, dim3(nblkm), dim3(256), 0, s, (const uint64_t*)(X + o_pre_a), m, B.cfirst.as<int64_t>(), (const int64_t*)(X + o_pre_na), n_query, pm,
-	                   (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark));
+	                   (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark), kSerialRun, (LongRun*)(X + o_long), (unsigned int*)(X + o_nlong), (unsigned int)long_cap);
+	hipLaunchKernelGGL(k_chain_fwd_wave, dim3((unsigned)std::min<size_t>(long_cap, 65536)), dim3(64), 0, s, (const uint64_t*)(X + o_pre_a), (const LongRun*)(X + o_long),
+	                   (const unsigned int*)(X + o_nlong), (unsigned int)long_cap, pm, (int32_t*)(X + o_mf), (int32_t*)(X + o_mpred), (int32_t*)(X + o_mmark));
 	HIP_TRY(hipGetLastError());
 	// ... and extraction: dense views over the survivors
 	xa.cnt = (const int64_t*)(X + o_pre_na), xa.ntot_first = nullptr;
@@ -999,12 +1006,21 @@ int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &cp, int32_t n_prob, con
 	int rc;
 	if ((rc = B.c_a.ensure((size_t)n * 8)) || (rc = B.c_f.ensure((size_t)n * 4)) || (rc = B.c_pred.ensure((size_t)n * 4)) || (rc = B.c_mark.ensure((size_t)n * 4)) ||
 	    (rc = B.c_flag.ensure((size_t)n * 4)) || (rc = B.c_first.ensure(((size_t)n_prob + 1) * 8))) return rc;
+	// runs longer than this get a wavefront each (k_chain_fwd_wave); MPA_CHAIN_SERIAL_RUN overrides (tests: 4 = almost every run)
+	const int32_t serial_run = [] { const char *e = getenv("MPA_CHAIN_SERIAL_RUN"); return e ? std::max(1, atoi(e)) : 48; }();
+	const size_t long_cap = (size_t)n / (size_t)(serial_run + 1) + 16;
+	if ((rc = B.c_long.ensure(64 + long_cap * sizeof(LongRun)))) return rc;
+	unsigned int *d_nlong = B.c_long.as<unsigned int>();
+	LongRun *d_long = (LongRun*)(B.c_long.as<char>() + 64);
+	HIP_TRY(hipMemsetAsync(d_nlong, 0, 64, s));
 	HIP_TRY(hipMemcpyAsync(B.c_a.p, io.a, (size_t)n * 8, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(B.c_first.p, first, ((size_t)n_prob + 1) * 8, hipMemcpyHostToDevice, s));
 	const unsigned nblk = (unsigned)((n + 255) / 256);
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(), B.c_mark.as<int32_t>(), B.c_flag.as<uint32_t>());
 	hipLaunchKernelGGL(k_chain_fwd, dim3(nblk), dim3(256), 0, s, B.c_a.as<uint64_t>(), n, B.c_first.as<int64_t>(), (const int64_t*)nullptr, n_prob, pp, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(),
-	                   B.c_mark.as<int32_t>());
+	                   B.c_mark.as<int32_t>(), serial_run, d_long, d_nlong, (unsigned int)long_cap);
+	hipLaunchKernelGGL(k_chain_fwd_wave, dim3((unsigned)std::min<size_t>(long_cap, 65536)), dim3(64), 0, s, B.c_a.as<uint64_t>(), (const LongRun*)d_long, (const unsigned int*)d_nlong,
+	                   (unsigned int)long_cap, pp, B.c_f.as<int32_t>(), B.c_pred.as<int32_t>(), B.c_mark.as<int32_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(io.f, B.c_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(io.pred, B.c_pred.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

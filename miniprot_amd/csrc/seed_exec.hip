@@ -174,9 +174,13 @@ __device__ __forceinline__ int32_t d_link_score_a(uint64_t cur, uint64_t prev, c
 	return sc;
 }
 
-// cnt != nullptr: problem q holds cnt[q] anchors from first[q] on (the slots up to first[q + 1] are unused)
+// cnt != nullptr: problem q holds cnt[q] anchors from first[q] on (the slots up to first[q + 1] are unused).
+// long_runs != nullptr: a run of more than max_serial anchors is not walked here but handed to k_chain_fwd_wave (a wavefront
+// per run): one thread walking a gene locus of a few hundred anchors, window by window, is what the kernel used to wait for.
+struct LongRun { int64_t s, e, q0; };
 __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n, const int64_t *first, const int64_t *cnt, int32_t n_prob, PreParams p,
-                                                   int32_t *f, int32_t *pred, int32_t *mark)
+                                                   int32_t *f, int32_t *pred, int32_t *mark, int32_t max_serial = 0x7fffffff, LongRun *long_runs = nullptr,
+                                                   unsigned int *n_long = nullptr, unsigned int long_cap = 0)
 {
 	MPA_SHORT_KERNEL();
 	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -193,6 +197,11 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const uint64_t *a, int64_t n,
 	{
 		uint64_t prev = xs;
 		while (e < q1) { const uint64_t x = a[e] >> 32; if (x - prev > max_dx) break; prev = x, ++e; }
+	}
+	if (long_runs && e - s > (int64_t)max_serial) {
+		const unsigned int at = atomicAdd(n_long, 1u);
+		if (at < long_cap) { long_runs[at] = LongRun{ s, e, q0 }; return; }
+		// (the list is full -- it is sized for the worst case, so this cannot happen -- walk the run here after all)
 	}
 	int64_t win = s, hot = -1;
 	int32_t hot_f = 0;
@@ -346,6 +355,84 @@ __global__ __launch_bounds__(256) void k_chain_pack(const int64_t *first, const 
 	const int64_t off = first[q], na = n_a[q], nu = n_u[q], da = o_a[q], du = o_u[q];
 	for (int64_t i = threadIdx.x; i < na; i += 256) a_dst[da + i] = a_src[off + i];
 	for (int64_t i = threadIdx.x; i < nu; i += 256) u_dst[du + i] = u_src[off + i];
+}
+
+// The forward pass of mp_chain (chain.c:181-209) over ONE run, by one wavefront: the candidates j = i-1, i-2, ... of anchor i are
+// scored 64 at a time, one per lane.  What the reference does sequentially over j is recovered exactly:
+//   * "sc > best" with a running best is an exclusive prefix maximum over the lanes (seeded with the best so far): strict
+//     improvement, the nearest candidate wins ties -- as in the loop;
+//   * t[p[j]] = i marks set by candidates visited EARLIER can only land on candidates visited LATER (p[j] < j), so every
+//     compatible lane writes its mark first, and after a wave-level fence each lane reads its own;
+//   * the max_skip counter (++ on a marked non-improving candidate, -- on an improving one, clamped at 0, stop when it exceeds
+//     max_skip) is replayed by scalar code over the two ballots; candidates behind the stop are dropped.  Marks written by
+//     dropped lanes carry the value i and are never read again (the next anchor compares with i + 1).
+__global__ __launch_bounds__(64) void k_chain_fwd_wave(const uint64_t *a, const LongRun *runs, const unsigned int *n_runs, unsigned int cap, PreParams p,
+                                                       int32_t *f, int32_t *pred, int32_t *mark)
+{
+	const unsigned int nr = *n_runs < cap ? *n_runs : cap;
+	const int lane = (int)(threadIdx.x & 63);
+	for (unsigned int r = blockIdx.x; r < nr; r += gridDim.x) {
+	const LongRun run = runs[r];
+	const int64_t q0 = run.q0;
+	const uint64_t max_dx = (uint64_t)(p.max_dist_x >> p.bbit);
+	int64_t win = run.s, hot = -1;
+	int32_t hot_f = 0;
+	for (int64_t i = run.s; i < run.e; ++i) {
+		const uint64_t ai = a[i];
+		const int32_t me = (int32_t)(i - q0);
+		int64_t best_j = -1;
+		int32_t best = p.kmer, skipped = 0;
+		while (win < i && (ai >> 32) - (a[win] >> 32) > max_dx) ++win;
+		if (hot >= 0 && hot >= win) {
+			const int32_t l = d_link_score_a(ai, a[hot], p);
+			const int32_t sc = l == D_INCOMPAT ? D_INCOMPAT : hot_f + l;
+			if (sc > best) best = sc, best_j = hot;
+		} else hot_f = 0, hot = -1;
+		if (i - win > p.max_iter) win = i - p.max_iter;
+		bool stopped = false;
+		for (int64_t jhi = i - 1; jhi >= win && !stopped; jhi -= 64) {
+			const int64_t j = jhi - lane;
+			const bool valid = j >= win;
+			int32_t sc = valid ? d_link_score_a(ai, a[j], p) : D_INCOMPAT;
+			const bool compat = sc != D_INCOMPAT;
+			int32_t pj = -1;
+			if (compat) {
+				sc += f[j];
+				pj = pred[j];
+				if (pj >= 0) mark[q0 + pj] = me;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			const bool marked = compat && mark[j] == me;
+			// exclusive prefix maximum of the compatible scores, in visiting order (lane 0 first)
+			int32_t pm = compat ? sc : INT32_MIN;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const int32_t w = __shfl_up(pm, o); if (lane >= o) pm = w > pm ? w : pm; }
+			int32_t before = __shfl_up(pm, 1);
+			if (lane == 0) before = INT32_MIN;
+			if (best > before) before = best;
+			const bool improve = compat && sc > before;
+			const unsigned long long I = __ballot(improve), M = __ballot(compat && !improve && marked);
+			// the skip counter over the candidates in order
+			unsigned long long ev = I | M, live = ~0ull;
+			while (ev) {
+				const int b = __ffsll((long long)ev) - 1;
+				ev &= ev - 1;
+				if ((I >> b) & 1ull) { if (skipped > 0) --skipped; }
+				else if (++skipped > p.max_skip) { stopped = true; live = b >= 63 ? ~0ull : ((2ull << b) - 1ull); break; }
+			}
+			const unsigned long long Iv = I & live;
+			if (Iv) {
+				const int last = 63 - __clzll((long long)Iv);
+				best = __shfl(sc, last), best_j = jhi - last;
+			}
+		}
+		if (lane == 0) f[i] = best, pred[i] = best_j < 0 ? -1 : (int32_t)(best_j - q0);
+		if (hot_f < best) hot_f = best, hot = i;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	}
 }
 
 __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int32_t *f, int32_t *pred, int32_t *mark, uint32_t *flag)

@@ -236,11 +236,15 @@ def test_device_refinement_scan_equals_host_scan():
     ctx.close()
 
 
-def test_device_chain_forward_equals_host_forward():
+@pytest.mark.parametrize("serial_run", ["48", "4"])
+def test_device_chain_forward_equals_host_forward(serial_run, monkeypatch):
     """k_chain_fwd (the forward pass of mp_chain for any chaining problem, one thread per independent run of anchors) against
     the host pass that tests/test_host_core.py pins to the oracle: block anchors (main chain: long windows, planted chains,
     dense repeats that exercise max_skip and max_iter) and base-resolution anchors (refinement chains, the exact-gap branch
     of comput_sc), many problems per launch, empty and one-anchor problems in between"""
+    # serial_run: runs longer than this are walked by a wavefront (k_chain_fwd_wave: 64 candidates at a time, the max_skip counter
+    # replayed over ballots) instead of one thread; 4 sends almost every run there
+    monkeypatch.setenv("MPA_CHAIN_SERIAL_RUN", serial_run)
     from test_host_core import _anchors, _long_chains
     L = mpa.lib()
     L.mpa_dbg_chain_forward.argtypes = [C.c_void_p] + [C.c_int32] * 5 + [C.c_float] + [C.c_int32] * 4 + [C.c_void_p] * 4
