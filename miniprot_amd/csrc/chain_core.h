@@ -73,6 +73,8 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD void atomic_min(int32_t *slot, int32_t v) { if (v < *slot) *slot = v; }
 	static MPA_HD int64_t scan_excl(int64_t v, int64_t *total) { *total = v; return 0; }   // sum of v over the lanes below this one; the team's total
 	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_EXTRACT_PROF)
+	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
+	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
 };
 #define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
 
@@ -174,6 +176,53 @@ MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *sta
 // [0, n_root); walking it only ever moves the non-roots found there (in ascending position) into the heads of their
 // buckets, displacing what sits there; everything after that happens inside the tail [n_root, n), which is small.
 //
+// The walk of the reference's cycle-leader pass over the FIRST bucket's region (ksort.h:132-142), seen from the elements that
+// do not belong there: src[0, n_src), in order.  Each is dropped on the head of its own bucket in `tail` (tail[cursor[d]++]),
+// and whatever it displaces is carried on the same way until an element of the first bucket (digit == stop) is displaced --
+// that one ends up in the hole the walk started from, which sink(i, element) is told about.
+// The team takes C::width() elements at a time: as long as every one of them displaces an element of the first bucket -- the
+// overwhelmingly common case: the tail is almost all roots -- the placements do not interact (elements of one digit take
+// consecutive slots in their order, digits have disjoint slots) and are done side by side; a group in which some displacement
+// carries on is replayed one element at a time.  With a team of one this is the sequential walk.
+// sink_par(i, element, have): called by every lane for ITS element of a group placed side by side; sink_uni(i, element): called
+// by all lanes alike for an element of a replayed group.
+template<class C, int SHIFT, class SinkPar, class SinkUni>
+MPA_HD inline void place_in_order(const SparseItem *src, int64_t n_src, Pair64 *tail, uint32_t *cursor, int stop, SinkPar sink_par, SinkUni sink_uni)
+{
+	for (int64_t base = 0; base < n_src; base += C::width()) {
+		const int64_t i = base + C::lane();
+		const bool have = i < n_src;
+		const Pair64 e = have ? src[i].e : Pair64{ 0, 0 };
+		const int d = (int)(e.x >> SHIFT & 0xff);
+		int rank = 0, same = 1;
+		C::digit_rank(d, have, &rank, &same);
+		const uint32_t slot = have ? cursor[d] + (uint32_t)rank : 0u;
+		const Pair64 old = have ? tail[slot] : Pair64{ 0, 0 };
+		const bool ends_here = (int)(old.x >> SHIFT & 0xff) == stop;
+		if (!C::any(have && !ends_here)) {
+			if (have) tail[slot] = e;
+			sink_par(i, old, have);
+			C::sync();
+			if (have && rank == same - 1) cursor[d] += (uint32_t)same;
+			C::sync();
+		} else {
+			const int64_t lim = base + C::width() < n_src ? base + C::width() : n_src;
+			for (int64_t g = base; g < lim; ++g) {               // (every lane replays the group: identical state, as in the sequential parts)
+				Pair64 carried = src[g].e;
+				int dd = (int)(carried.x >> SHIFT & 0xff);
+				do {
+					const Pair64 placed = carried;
+					carried = tail[cursor[dd]];
+					tail[cursor[dd]++] = placed;
+					dd = (int)(carried.x >> SHIFT & 0xff);
+				} while (dd != stop);
+				sink_uni(g, carried);
+			}
+			C::sync();
+		}
+	}
+}
+
 // The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest key
 // present) everywhere except at `items` (m of them, ascending pos).  Writes the m non-roots in their final order to out[0, m).
 template<class C> MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, int64_t m, Pair64 *out, uint32_t *hist)
@@ -201,16 +250,8 @@ template<class C> MPA_HD inline void replay_low_digit(int64_t n, int k0, const S
 		for (int d = 0; d < 256; ++d) { const uint32_t c = cnt[d]; cursor[d] = at, at += c, limit[d] = at; }
 	}
 	// walk of bucket k0 over [0, n_root): roots stay, every other element starts a displacement cycle
-	for (int64_t i = 0; i < first_tail; ++i) {
-		Pair64 carried = items[i].e;
-		int d = (int)(carried.x & 0xff);
-		do {
-			const Pair64 placed = carried;
-			carried = tail[cursor[d]];
-			tail[cursor[d]++] = placed;
-			d = (int)(carried.x & 0xff);
-		} while (d != k0);
-	}
+	C::sync();
+	place_in_order<C, 0>(items, first_tail, tail, cursor, k0, [](int64_t, const Pair64 &, bool) {}, [](int64_t, const Pair64 &) {});
 	// the remaining buckets, entirely inside the tail (same walk as pairs_digit_level)
 	for (int k = k0 + 1; k < 256;) {
 		if (cursor[k] == limit[k]) { ++k; continue; }
@@ -278,20 +319,25 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		uint32_t at = 0;
 		for (int d = 0; d < 256; ++d) { const uint32_t c = d ? cnt8[d] : 0u; start[d] = at, cursor[d] = at, at += c, limit[d] = at; }
 	}
-	for (int64_t q = 0; q < n_items; ++q) {
-		const SparseItem it = items[q];
-		if (it.pos >= c0) break;
-		if (it.e.x < 256) continue;                        // a low score inside region 0 stays where it is
-		Pair64 carried = it.e;
-		int d = (int)(carried.x >> 8 & 0xff);
-		do {
-			const Pair64 placed = carried;
-			carried = tail8[cursor[d]];
-			tail8[cursor[d]++] = placed;
-			d = (int)(carried.x >> 8 & 0xff);
-		} while (d != 0);
-		if (carried.y != MPA_ABSENT) moved[n_moved++] = SparseItem{ it.pos, carried };   // a chained anchor with a low score: it now sits in the hole
+	// the walk of region 0: its high scores, in order (a low score inside region 0 stays where it is); what a walk finally
+	// displaces is a low score: if it is a chained anchor, it now sits in the hole the walk started from
+	int64_t a_end;                                          // items [0, a_end) sit in region 0
+	{
+		int64_t lo = 0, hi = n_items;
+		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (items[mid].pos < c0) lo = mid + 1; else hi = mid; }
+		a_end = lo;
 	}
+	SparseItem *high = merged;                              // (the merged list is built after the walk)
+	const int64_t n_high = coop_compact<C>(a_end, [&](int64_t i) { return items[i].e.x >= 256; }, [&](int64_t i, int64_t k) { high[k] = items[i]; });
+	place_in_order<C, 8>(high, n_high, tail8, cursor, 0,
+		[&](int64_t i, const Pair64 &old, bool have) {
+			const bool keep = have && old.y != MPA_ABSENT;
+			const uint64_t mask = C::ballot(keep);
+			if (keep) moved[n_moved + C::rank(mask)] = SparseItem{ high[i].pos, old };
+			n_moved += C::popc(mask);
+		},
+		[&](int64_t i, const Pair64 &old) { if (old.y != MPA_ABSENT) moved[n_moved++] = SparseItem{ high[i].pos, old }; });
+	C::sync();
 	for (int k = 1; k < 256;) {                             // buckets 1..255 (same walk as pairs_digit_level)
 		if (cursor[k] == limit[k]) { ++k; continue; }
 		int d = (int)(tail8[cursor[k]].x >> 8 & 0xff);
@@ -308,12 +354,6 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
 	{
 		C::sync();
-		int64_t a_end;                                     // items [0, a_end) sit in region 0
-		{
-			int64_t lo = 0, hi = n_items;
-			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (items[mid].pos < c0) lo = mid + 1; else hi = mid; }
-			a_end = lo;
-		}
 		const int64_t n_low = coop_compact<C>(a_end, [&](int64_t i) { return items[i].e.x < 256; }, [&](int64_t i, int64_t k) { merged[k] = items[i]; });
 		// ... merged with the moved ones by position (both ascending, positions distinct): backwards, in place
 		int64_t i = n_low - 1, j = n_moved - 1, k = n_low + n_moved - 1;

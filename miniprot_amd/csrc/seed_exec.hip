@@ -298,6 +298,13 @@ struct CoopWave {
 		*total = __shfl(inc, 63);
 		return inc - v;
 	}
+	static __device__ __forceinline__ void digit_rank(int d, bool have, int *rank, int *cnt)
+	{
+		unsigned long long eq = __ballot(have);                  // lanes that take part and hold the same 8-bit digit: eight ballots
+#pragma unroll
+		for (int b = 0; b < 8; ++b) { const unsigned long long m = __ballot((d >> b) & 1); eq &= ((d >> b) & 1) ? m : ~m; }
+		*rank = __popcll(eq & ((1ull << lane()) - 1ull)), *cnt = __popcll(eq);
+	}
 	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
 };
 
