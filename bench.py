@@ -215,7 +215,7 @@ def roofline_record(st, elapsed, world):
         n, ms = st["launches_round"], st["ms_round"]
         ops = OPS_PER_CELL_EXT * st["cells_ext_round"] + OPS_PER_CELL_GLOB * st["cells_glob_round"]
         cells = st["cells_ext_round"] + st["cells_glob_round"]
-        note = "launch durations from HIP events on the launch stream; rounds of different batches in flight (MPA_DP_LANES) overlap on the GPU, so the sum of launch durations exceeds the wall time"
+        note = "launch durations from HIP events on the launch stream; the rounds of the batches in flight (MPA_DP_LANES) overlap on the GPU"
     elif st["launches_ext"] > 0 and st["ms_ext"] > 0:
         kernel = "k_ext_narrow + k_ext_wide<NW> + k_ext_wide_split (score-only extension sweep, > 80 % of all DP cells)"
         n, ms = st["launches_ext"], st["ms_ext"]
@@ -224,23 +224,32 @@ def roofline_record(st, elapsed, world):
     else:
         return None
     ach = ops / (ms * 1e-3)                                   # int16 ops/s while the kernel is running
-    hbm = st["alg_bytes_ext"] / (ms * 1e-3) / 1e9
+    # algorithmic HBM bytes of the launch: extension calls = packed window + protein + result; traceback calls add
+    # 2 bytes per cell written, the words read along the path and the CIGAR -- the share of the traceback calls that ride in the
+    # round kernel is taken by cells
+    glob_share = st["cells_glob_round"] / st["cells_glob"] if st.get("cells_glob") else 0.0
+    alg_bytes = st["alg_bytes_ext"] + st.get("alg_bytes_glob", 0) * glob_share
+    hbm = alg_bytes / (ms * 1e-3) / 1e9
     wall_ops = (OPS_PER_CELL_EXT * st["cells_ext"] + OPS_PER_CELL_GLOB * st["cells_glob"]) / elapsed
     traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if os.path.exists(pmc):
-        try:
-            d = json.load(open(pmc))
-            traffic = d["kernels"]["k_dp_round"]["hbm_bytes_per_launch"]
-            src = "profiles/r02_pmc_summary.json: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over config 3 scaled x0.1 -- NOT measured in this run and not this run's launch size"
-        except Exception:
-            pass
+    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_round.sh): a
+    # profile constant measured on this workload at this mini-batch size (round 3), NOT collected in this run
+    for name, what in (("r03_pmc_summary.json", "config 3 at full size, this mini-batch size"), ("r02_pmc_summary.json", "config 3 scaled x0.1: not this run's launch size")):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            try:
+                d = json.load(open(pmc))
+                traffic = d["kernels"]["k_dp_round"]["hbm_bytes_per_launch"]
+                src = "profiles/%s: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over %s" % (name, what)
+                break
+            except Exception:
+                pass
     return {"kernel": kernel, "bound": "valu-int16", "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
             "traffic": traffic, "traffic_source": src,
             "launches": n, "avg_launch_ms": ms / n, "cells_per_launch": cells / n, "ops_per_cell": {"score_only": OPS_PER_CELL_EXT, "traceback": OPS_PER_CELL_GLOB},
             "gcups_per_launch": cells / (ms * 1e-3) / 1e9,
-            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": st["alg_bytes_ext"] / n,
-                    "note": "algorithmic bytes of the extension calls (packed window + protein + result, SURVEY.md 8(d)) / launch time: the score-only DP is not HBM-bound"},
+            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes / n,
+                    "note": "algorithmic bytes of the launch's calls (SURVEY.md 8(d): extension = packed window + protein + result; traceback adds 2 B per cell, the path's words and the CIGAR) / launch time: not the binding roof"},
             "wall": {"achieved": wall_ops / 1e12, "frac": wall_ops / VALU_I16_PEAK / max(world, 1), "unit": "Tops/s",
                      "note": "all DP ops of the timed steps (32/cell score-only + 65/cell traceback) / elapsed wall time / GPUs: includes every host stage and idle gap"},
             "note": note}

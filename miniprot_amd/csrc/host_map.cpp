@@ -1402,7 +1402,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so four
 	// lanes fit next to the seeding streams; measured at config 3 (20 000 proteins in 10 batches, two planners, two seeders):
 	// 3 lanes 0.91 s, 4 lanes 0.865 s; with one planner and one seeder the host stages bound the stream (1.00 s, any lane count)
-	int n_lanes = 4;
+	// round 3 (both chaining rounds on the device, sleeping waits: the host stages no longer bound the stream): 5 lanes 93.5 ms per
+	// 4 000-protein step, 4 lanes 99.8, 6 lanes 100-112 (config 3, 20 steps)
+	int n_lanes = 5;
 	if (const char *e = getenv("MPA_DP_LANES")) n_lanes = atoi(e);
 	n_lanes = std::max(1, std::min(n_lanes, 8));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
