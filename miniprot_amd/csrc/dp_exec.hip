@@ -83,6 +83,7 @@ struct SeedBufs {
 	DevBuf s_meta, s_cur, s_cur2, s_kept, s_base, s_out, s_flag, dkey;      // k_seed_sift: segments + per-query tables, list cursors, per-segment results, dense keys
 	HostPinned h_meta, h_back;                                             // ... their staging (up) and qfirst2 / flags / cfirst (down)
 	DevBuf x_all;                                                          // device chaining: views, extraction scratch, survivors, main-chain state, chains (carved up per call)
+	DevBuf rx_all, rx_keys;                                                // device refinement: pairing tables, pair keys (two buffers), chain state (carved up per call)
 	HostPinned h_U, h_A, h_xoff;                                           // ... the chains of every query (down)
 	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first, c_long;        // chain forward pass (k_chain_fwd, k_chain_fwd_wave: list of long runs + its counter)
 	HostPinned hc_a, hc_f, hc_pred;
@@ -337,7 +338,7 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
 	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
 	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1],
-	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all }) b->release();
+	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys }) b->release();
 	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_U, &B.h_A, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
@@ -1105,6 +1106,195 @@ int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_
 	out.hits.resize((size_t)n_hits);
 	std::vector<int64_t> at(out.first.begin(), out.first.end() - 1);
 	for (unsigned long long k = 0; k < n_hits; ++k) out.hits[(size_t)at[h[k].x]++] = (uint64_t)h[k].z << 32 | h[k].y;
+	return MPA_OK;
+}
+} // namespace mpa
+
+namespace mpa {
+// mp_refine_reg (map.c:32-96) for all windows of a mini-batch on the device: see the kernels in seed_exec.hip ("Refinement
+// pairing on the device") and k_chain_fwd / k_chain_fwd_wave / k_chain_extract.  MPA_ERR_UNSUPPORTED: outside the kernels' range
+// (the caller refines on the host).
+int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t max_ava, const ChainParams &cp, int32_t n_query, const RefineGroupsHost &G,
+                      int64_t n_win, const RefineWindow *wins, RefineChains &out)
+{
+	out.u_first.assign((size_t)n_win + 1, 0), out.a_first.assign((size_t)n_win + 1, 0);
+	out.U = out.A = nullptr;
+	if (n_win == 0) return MPA_OK;
+	if (kmer < 1 || kmer > 7 || min_aa_len > (REFINE_HALO - 3 * kmer) / 3 + kmer || cp.bbit != 0) { set_error("device refinement: parameters outside the kernels' range"); return MPA_ERR_UNSUPPORTED; }
+	if (n_win >= (1 << 20)) { set_error("device refinement: more than 2^20 windows in a batch"); return MPA_ERR_UNSUPPORTED; }
+	int64_t max_groups = 0;
+	for (int32_t q = 0; q < n_query; ++q) max_groups = std::max(max_groups, G.qg_first[(size_t)q + 1] - G.qg_first[(size_t)q]);
+	int hs_log2 = 10;
+	while ((1LL << hs_log2) < 2 * max_groups) ++hs_log2;
+	if (hs_log2 > 12) { set_error("device refinement: query too long for the LDS k-mer map"); return MPA_ERR_UNSUPPORTED; }
+	for (uint32_t p : G.qpos) if (p >= (1u << 22)) { set_error("device refinement: a query longer than 2^22 residues"); return MPA_ERR_UNSUPPORTED; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
+	SeedBufs &B = ctx->seed;
+	if (!ctx->seed_stream) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
+	}
+	hipStream_t s = ctx->seed_stream;
+	const double t0 = now_ms();
+	// ---- one pinned block up: windows | chunks | wg_first | qg_first | gword | gfirst | gcount | qpos
+	int64_t n_pos = 0, n_chunk = 0, wg_total = 0;
+	for (int64_t k = 0; k < n_win; ++k) {
+		if (wins[k].len >= (1 << 22)) { set_error("device refinement: a window longer than 2^22 bases"); return MPA_ERR_UNSUPPORTED; }
+		n_pos += wins[k].len, n_chunk += (wins[k].len + REFINE_CHUNK - 1) / REFINE_CHUNK;
+	}
+	if (n_chunk == 0) return MPA_OK;
+	const unsigned long long cap = (unsigned long long)(n_pos / 64 + (1 << 20));
+	const size_t n_group = G.gword.size(), n_qpos = G.qpos.size(), NW = (size_t)n_win, NQ = (size_t)n_query;
+	auto al64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+	const size_t o_win = 0, o_chunk = al64(NW * sizeof(RefineWindowDev)), o_wg = o_chunk + al64((size_t)n_chunk * sizeof(RefineChunk)), o_qg = o_wg + al64((NW + 1) * 8),
+	             o_gw = o_qg + al64((NQ + 1) * 8), o_gf = o_gw + al64(n_group * 4 + 4), o_gc = o_gf + al64(n_group * 4 + 4), o_qp = o_gc + al64(n_group * 4 + 4),
+	             up_bytes = o_qp + al64(n_qpos * 4 + 4);
+	int rc;
+	if ((rc = B.h_meta.ensure(up_bytes + 64)) || (rc = B.r_win.ensure(up_bytes)) || (rc = B.r_hits.ensure((size_t)cap * 16)) || (rc = B.r_count.ensure(16)) ||
+	    (rc = B.h_back.ensure(256))) return rc;
+	char *hm = B.h_meta.as<char>();
+	{
+		RefineWindowDev *dw = (RefineWindowDev*)(hm + o_win);
+		RefineChunk *ch = (RefineChunk*)(hm + o_chunk);
+		int64_t *wg = (int64_t*)(hm + o_wg);
+		int64_t c = 0;
+		for (int64_t k = 0; k < n_win; ++k) {
+			dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
+			for (int32_t st = 0; st < wins[k].len; st += REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
+			wg[k] = wg_total;
+			wg_total += G.qg_first[(size_t)wins[k].qid + 1] - G.qg_first[(size_t)wins[k].qid];
+		}
+		wg[n_win] = wg_total;
+		memcpy(hm + o_qg, G.qg_first.data(), (NQ + 1) * 8);
+		if (n_group) memcpy(hm + o_gw, G.gword.data(), n_group * 4), memcpy(hm + o_gf, G.gfirst.data(), n_group * 4), memcpy(hm + o_gc, G.gcount.data(), n_group * 4);
+		if (n_qpos) memcpy(hm + o_qp, G.qpos.data(), n_qpos * 4);
+	}
+	// device tables: per (window, group) hit counts and per-window pair counts, zeroed
+	size_t at = 0;
+	auto carve = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t o_wcnt = carve(((size_t)wg_total + 1) * 4), o_wpairs = carve((NW + 2) * 4), o_first = carve((NW + 2) * 8);
+	const size_t zero_bytes = at;
+	if ((rc = B.rx_all.ensure(at))) return rc;
+	HIP_TRY(hipMemcpyAsync(B.r_win.p, hm, up_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(B.r_count.p, 0, 16, s));
+	HIP_TRY(hipMemsetAsync(B.rx_all.p, 0, zero_bytes, s));
+	RefineTab rt;
+	for (int c = 0; c < 64; ++c) rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
+	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, nullptr, mi->l_seq };
+	const char *dm = B.r_win.as<char>();
+	RefineGroups gr{ (const int64_t*)(dm + o_qg), (const uint32_t*)(dm + o_gw), (const uint32_t*)(dm + o_gf), (const uint32_t*)(dm + o_gc), (const uint32_t*)(dm + o_qp) };
+	const int64_t *d_wg = (const int64_t*)(dm + o_wg);
+	char *R = B.rx_all.as<char>();
+	uint32_t *d_wcnt = (uint32_t*)(R + o_wcnt), *d_wpairs = (uint32_t*)(R + o_wpairs);
+	int64_t *d_first = (int64_t*)(R + o_first);
+	const size_t lds = ((size_t)8 << hs_log2) + REFINE_CHUNK + 2 * REFINE_HALO;
+	HIP_TRY(ensure_dynamic_lds((const void*)k_refine_scan_map, ctx->device, lds > 48 * 1024 ? lds : 48 * 1024));
+	hipLaunchKernelGGL(k_refine_scan_map, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk), gr, d_wg, rt,
+	                   kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt);
+	HIP_TRY(hipGetLastError());
+	unsigned long long *h_n = B.h_back.as<unsigned long long>();
+	HIP_TRY(hipMemcpyAsync(h_n, B.r_count.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(wait_stream(ctx, s));
+	const int64_t n_hits = (int64_t)*h_n;
+	if ((unsigned long long)n_hits > cap) { set_error("device refinement: more hits than the buffer holds"); return MPA_ERR_UNSUPPORTED; }
+	timing_note("    refine: scan (wait)", now_ms() - t0);
+	if (n_hits == 0) return MPA_OK;
+	// ---- pairs: count, offsets, emit, sort, decode
+	const double t1 = now_ms();
+	if ((rc = B.r_chunk.ensure((size_t)n_hits * 4 + 16)) || (rc = B.r_words.ensure((size_t)n_hits * 8 + 16))) return rc;   // pairs per hit, and where they go
+	uint32_t *d_pc = B.r_chunk.as<uint32_t>();
+	uint64_t *d_po = B.r_words.as<uint64_t>();
+	const unsigned nbh = (unsigned)((n_hits + 255) / 256);
+	hipLaunchKernelGGL(k_refine_pair_count, dim3(nbh), dim3(256), 0, s, B.r_hits.as<uint4>(), n_hits, d_wg, d_wcnt, gr.gcount, max_ava, d_pc, d_wpairs);
+	HIP_TRY(hipGetLastError());
+	{
+		size_t tb = 0, tb2 = 0;
+		auto in = rocprim::make_transform_iterator((const uint32_t*)d_pc, U32ToU64());
+		auto inw = rocprim::make_transform_iterator((const uint32_t*)d_wpairs, U32ToU64());
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, in, d_po, (uint64_t)0, (size_t)n_hits, rocprim::plus<uint64_t>(), s));
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, inw, (uint64_t*)d_first, (uint64_t)0, NW + 1, rocprim::plus<uint64_t>(), s));
+		if ((rc = B.tmp.ensure(std::max(tb, tb2) + 256))) return rc;
+		HIP_TRY(rocprim::exclusive_scan(B.tmp.p, tb, in, d_po, (uint64_t)0, (size_t)n_hits, rocprim::plus<uint64_t>(), s));
+		HIP_TRY(rocprim::exclusive_scan(B.tmp.p, tb2, inw, (uint64_t*)d_first, (uint64_t)0, NW + 1, rocprim::plus<uint64_t>(), s));
+	}
+	int64_t *h_np = (int64_t*)(h_n + 1);
+	HIP_TRY(hipMemcpyAsync(h_np, d_first + n_win, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(wait_stream(ctx, s));
+	const int64_t np = *h_np;
+	if (np == 0) return MPA_OK;
+	if ((rc = B.rx_keys.ensure((size_t)np * 24 + 64))) return rc;
+	uint64_t *keys0 = B.rx_keys.as<uint64_t>(), *keys1 = keys0 + np, *d_a = keys1 + np;
+	hipLaunchKernelGGL(k_refine_pair_emit, dim3(nbh), dim3(256), 0, s, B.r_hits.as<uint4>(), n_hits, (const uint32_t*)d_pc, (const uint64_t*)d_po, gr, keys0);
+	HIP_TRY(hipGetLastError());
+	{
+		int wbits = 1;
+		while ((1LL << wbits) < n_win) ++wbits;
+		size_t tb = 0;
+		HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, keys0, keys1, (size_t)np, 0u, (unsigned)(44 + wbits), s));
+		if ((rc = B.tmp.ensure(tb + 256))) return rc;
+		HIP_TRY(rocprim::radix_sort_keys(B.tmp.p, tb, keys0, keys1, (size_t)np, 0u, (unsigned)(44 + wbits), s));
+	}
+	const unsigned nbp = (unsigned)((np + 255) / 256);
+	hipLaunchKernelGGL(k_refine_pair_decode, dim3(nbp), dim3(256), 0, s, (const uint64_t*)keys1, np, d_a);
+	HIP_TRY(hipGetLastError());
+	// ---- the chains of every window: forward pass (base resolution), extraction, pack
+	PreParams pm;
+	pm.max_dist_x = std::max(cp.max_dist_x, cp.bw), pm.max_dist_y = cp.max_dist_y;
+	if (pm.max_dist_y < cp.bw && !cp.is_spliced) pm.max_dist_y = cp.bw;
+	pm.bw = cp.bw, pm.max_skip = cp.max_skip, pm.max_iter = cp.max_iter, pm.kmer = cp.kmer, pm.bbit = cp.bbit;
+	pm.is_spliced = cp.is_spliced, pm.coef_log = cp.coef_log, pm.max_dblock = pm.max_dist_x >> cp.bbit;
+	const size_t M = (size_t)np;
+	size_t xat = 0;
+	auto xcarve = [&](size_t bytes) { const size_t o = xat; xat += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t x_mark = xcarve(M * 4), x_order = xcarve(M * 4), x_ends = xcarve((M + 64 * NW + 64) * sizeof(Pair64)), x_tail8 = xcarve(M * sizeof(Pair64)), x_firstp = xcarve(M * sizeof(Pair64)),
+	             x_items = xcarve(M * sizeof(SparseItem)), x_moved = xcarve(M * sizeof(SparseItem)), x_merged = xcarve(M * sizeof(SparseItem)), x_kept = xcarve(M), x_packed = xcarve(M * 8),
+	             x_usorted = xcarve(M * 8), x_stack = xcarve((M / 64 + 6 * NW + 16) * sizeof(SortRange)), x_status = xcarve(NW * 4 + 16), x_f = xcarve(M * 4), x_pred = xcarve(M * 4),
+	             x_fm = xcarve(M * 4), x_outa = xcarve(M * 8), x_outu = xcarve(M * 8), x_na = xcarve(NW * 8 + 8), x_nu = xcarve(NW * 8 + 8), x_offa = xcarve(NW * 8 + 16), x_offu = xcarve(NW * 8 + 16);
+	const int32_t kSerialRun = 48;
+	const size_t long_cap = M / (size_t)(kSerialRun + 1) + 16, x_long = xcarve(long_cap * sizeof(LongRun)), x_nlong = xcarve(64);
+	if (xat > B.x_all.cap && (rc = B.x_all.ensure(xat + xat / 3))) return rc;
+	char *X = B.x_all.as<char>();
+	HIP_TRY(hipMemsetAsync(X + x_status, 0, NW * 4 + 16, s));
+	HIP_TRY(hipMemsetAsync(X + x_nlong, 0, 64, s));
+	hipLaunchKernelGGL(k_seed_fill, dim3(nbp), dim3(256), 0, s, np, pm.kmer, (int32_t*)(X + x_f), (int32_t*)(X + x_pred), (int32_t*)(X + x_fm), (uint32_t*)(X + x_mark));
+	hipLaunchKernelGGL(k_chain_fwd, dim3(nbp), dim3(256), 0, s, (const uint64_t*)d_a, np, (const int64_t*)d_first, (const int64_t*)nullptr, (int32_t)n_win, pm, (int32_t*)(X + x_f), (int32_t*)(X + x_pred),
+	                   (int32_t*)(X + x_fm), kSerialRun, (LongRun*)(X + x_long), (unsigned int*)(X + x_nlong), (unsigned int)long_cap);
+	hipLaunchKernelGGL(k_chain_fwd_wave, dim3((unsigned)std::min<size_t>(long_cap, 65536)), dim3(64), 0, s, (const uint64_t*)d_a, (const LongRun*)(X + x_long), (const unsigned int*)(X + x_nlong),
+	                   (unsigned int)long_cap, pm, (int32_t*)(X + x_f), (int32_t*)(X + x_pred), (int32_t*)(X + x_fm));
+	HIP_TRY(hipGetLastError());
+	ExtractArgs xa;
+	xa.first = d_first, xa.cnt = nullptr, xa.ntot_first = nullptr;
+	xa.v_pos = nullptr, xa.v_f = (const int32_t*)(X + x_f), xa.v_pred = (const int32_t*)(X + x_pred), xa.v_a = (const uint64_t*)d_a;
+	xa.mark = (int32_t*)(X + x_mark), xa.order = (int32_t*)(X + x_order), xa.ends = (Pair64*)(X + x_ends), xa.tail8 = (Pair64*)(X + x_tail8), xa.firstp = (Pair64*)(X + x_firstp);
+	xa.items = (SparseItem*)(X + x_items), xa.moved = (SparseItem*)(X + x_moved), xa.merged = (SparseItem*)(X + x_merged);
+	xa.kept = (uint8_t*)(X + x_kept), xa.packed = (uint64_t*)(X + x_packed), xa.u_sorted = (uint64_t*)(X + x_usorted), xa.stack = (SortRange*)(X + x_stack);
+	xa.a_out = (uint64_t*)(X + x_outa), xa.u_out = (uint64_t*)(X + x_outu), xa.n_a = (int64_t*)(X + x_na), xa.n_u = (int64_t*)(X + x_nu);
+	xa.status = (int32_t*)(X + x_status), xa.p = cp, xa.set_only = 0;
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_win), dim3(64), 0, s, xa, (int32_t)n_win);
+	hipLaunchKernelGGL(k_offsets2, dim3(1), dim3(256), 0, s, (const int64_t*)(X + x_na), (const int64_t*)(X + x_nu), (int32_t)n_win, (int64_t*)(X + x_offa), (int64_t*)(X + x_offu));
+	HIP_TRY(hipGetLastError());
+	const size_t offb = (NW + 1) * 8;
+	if ((rc = B.h_xoff.ensure(2 * offb + NW * 4 + 64))) return rc;
+	int64_t *h_offa = B.h_xoff.as<int64_t>(), *h_offu = h_offa + (NW + 1);
+	int32_t *h_status = (int32_t*)(h_offu + (NW + 1));
+	HIP_TRY(hipMemcpyAsync(h_offa, X + x_offa, offb, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_offu, X + x_offu, offb, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_status, X + x_status, NW * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(wait_stream(ctx, s));
+	for (size_t w = 0; w < NW; ++w) if (h_status[w]) { set_error("device refinement: a chain extraction needs the host"); return MPA_ERR_UNSUPPORTED; }   // (dense views never do)
+	const int64_t tot_a = h_offa[n_win], tot_u = h_offu[n_win];
+	if ((rc = B.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = B.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
+	if (tot_a > 0 || tot_u > 0) {
+		hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)n_win), dim3(256), 0, s, (const int64_t*)d_first, (const int64_t*)(X + x_na), (const int64_t*)(X + x_nu), (const int64_t*)(X + x_offa),
+		                   (const int64_t*)(X + x_offu), (const uint64_t*)(X + x_outa), (const uint64_t*)(X + x_outu), B.h_A.as<uint64_t>(), B.h_U.as<uint64_t>());
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(wait_stream(ctx, s));
+	}
+	out.a_first.assign(h_offa, h_offa + n_win + 1), out.u_first.assign(h_offu, h_offu + n_win + 1);
+	out.A = B.h_A.as<uint64_t>(), out.U = B.h_U.as<uint64_t>();
+	timing_note("    refine: pairs + chains (wait)", now_ms() - t1);
 	return MPA_OK;
 }
 } // namespace mpa

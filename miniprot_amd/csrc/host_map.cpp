@@ -290,23 +290,30 @@ static inline ChainParams refine_chain_params(const mpa_mapopt_t &opt)
 	                    opt.chn_coef_log, !(opt.flag & MPA_MF_NO_SPLICE), opt.kmer2, 0 };
 }
 
+static void refine_region_from_chains(const mpa_idx_s *mi, const mpa_mapopt_t &opt, Region &r, int32_t extl, const uint64_t *u, int64_t n_u, const uint64_t *a);
 // The refinement chain of a region over those anchors and what mp_refine_reg() makes of it (map.c:81-111).  f/pred != nullptr:
 // the forward pass of the chain ran on the device (dev_chain_forward).
 static void refine_region_chain(const mpa_idx_s *mi, const mpa_mapopt_t &opt, Region &r, int32_t extl, std::vector<uint64_t> &a,
                                 const int32_t *f = nullptr, const int32_t *pred = nullptr)
 {
-	const int32_t kmer = opt.kmer2;
-	const int64_t as = r.vs > extl ? r.vs - extl : 0;
 	const ChainParams cp = refine_chain_params(opt);
 	std::vector<uint64_t> u;
 	{ AccTimer tm(12); if (f) chain_anchors_after_forward(cp, f, pred, a, u); else chain_anchors(cp, a, u); }
-	if (u.empty()) { r.cnt = 0, r.off = -1, r.a.clear(); return; }
+	refine_region_from_chains(mi, opt, r, extl, u.data(), (int64_t)u.size(), a.data());
+}
+
+// ... what mp_refine_reg() makes of the window's chains (map.c:89-111): u[n_u] = score << 32 | anchors per chain, a = the chains' anchors
+static void refine_region_from_chains(const mpa_idx_s *mi, const mpa_mapopt_t &opt, Region &r, int32_t extl, const uint64_t *u, int64_t n_u, const uint64_t *a)
+{
+	const int32_t kmer = opt.kmer2;
+	const int64_t as = r.vs > extl ? r.vs - extl : 0;
+	if (n_u == 0) { r.cnt = 0, r.off = -1, r.a.clear(); return; }
 	// the first chain with the highest score
 	size_t best = 0, skip = 0;
-	for (size_t i = 1; i < u.size(); ++i) if ((int32_t)(u[best] >> 32) < (int32_t)(u[i] >> 32)) best = i;
+	for (size_t i = 1; i < (size_t)n_u; ++i) if ((int32_t)(u[best] >> 32) < (int32_t)(u[i] >> 32)) best = i;
 	for (size_t i = 0; i < best; ++i) skip += (uint32_t)u[i];
 	const size_t n_a = (uint32_t)u[best];
-	r.a.assign(a.begin() + skip, a.begin() + skip + n_a);
+	r.a.assign(a + skip, a + skip + n_a);
 	r.chn_sc = (int32_t)(u[best] >> 32);
 	r.cnt = (int32_t)n_a, r.off = 0;
 	r.qs = (int32_t)(uint32_t)r.a[0] - (kmer - 1);
@@ -630,8 +637,9 @@ static void stage_refine_pairs(mpa_batch_s *b, QueryState &qs, const RefineHits 
 
 // pairs_ready: stage_refine_pairs() has run; fwd != nullptr: the forward passes of the refinement chains come from the device,
 // fwd_first[w] = offset of refinement window w (= qs.win0 + region) in fwd->f / fwd->pred
+// rc != nullptr: the whole refinement ran on the device (dev_refine_chains): the chains of refinement window w = qs.win0 + region
 static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh, bool pairs_ready = false, const ChainIO *fwd = nullptr,
-                                 const int64_t *fwd_first = nullptr)
+                                 const int64_t *fwd_first = nullptr, const RefineChains *rc = nullptr)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
@@ -640,7 +648,14 @@ static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHit
 	{
 		AccTimer tm(5);
 		std::vector<Region> kept;
-		if (pairs_ready) {
+		if (rc) {
+			for (size_t i = 0; i < regs.size(); ++i) {
+				const size_t w = (size_t)qs.win0 + i;
+				g_acc[13] += 1000000LL;
+				refine_region_from_chains(mi, opt, regs[i], (int32_t)(ext[i] >> 32), rc->U + rc->u_first[w], rc->u_first[w + 1] - rc->u_first[w], rc->A + rc->a_first[w]);
+				if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
+			}
+		} else if (pairs_ready) {
 			for (size_t i = 0; i < regs.size(); ++i) {
 				const int64_t w = qs.win0 + (int64_t)i;
 				if (fwd) refine_region_chain(mi, opt, regs[i], (int32_t)(ext[i] >> 32), qs.ref_pairs[i], fwd->f + fwd_first[w], fwd->pred + fwd_first[w]);
@@ -963,6 +978,40 @@ static void query_words(const char *aa, int32_t l_aa, int32_t k, std::vector<uin
 	}
 }
 
+// The query side of the device refinement: the query's k-mers (packed word, index of the last residue) grouped by word -- in
+// ascending hash order, positions ascending inside a group, as the pairing of map.c:53-79 meets them in the sorted list.
+struct QueryGroups { std::vector<uint32_t> gword, gcount, qpos; };
+static void query_groups(const char *aa, int32_t l_aa, int32_t k, QueryGroups &out)
+{
+	const uint8_t *aa13 = tab_aa13();
+	const uint32_t mask = (1U << 4 * k) - 1;
+	static thread_local std::vector<uint64_t> hk;           // hash << 32 | position
+	static thread_local std::vector<uint32_t> wd;           // word of the k-mer ending at position i (by position)
+	hk.clear(), wd.assign((size_t)l_aa, 0);
+	uint32_t x = 0;
+	for (int32_t i = 0, run = 0; i < l_aa; ++i) {
+		const uint32_t c = aa13[(uint8_t)aa[i]];
+		if (c >= 14) { run = 0, x = 0; continue; }
+		x = (x << 4 | c) & mask;
+		if (++run >= k) hk.push_back((uint64_t)hash32_mask(x, mask) << 32 | (uint32_t)i), wd[(size_t)i] = x;
+	}
+	sort_u64(hk.data(), hk.data() + hk.size());
+	out.gword.clear(), out.gcount.clear(), out.qpos.clear();
+	for (size_t i = 0; i < hk.size(); ++i) {
+		if (i == 0 || hk[i] >> 32 != hk[i - 1] >> 32) out.gword.push_back(wd[(size_t)(uint32_t)hk[i]]), out.gcount.push_back(0);
+		++out.gcount.back();
+		out.qpos.push_back((uint32_t)hk[i]);
+	}
+}
+
+// MPA_GPU_REFINE_CHAINS (default 1): with the device refinement engaged, pairing, pair sort and the refinement chains run on the
+// device too (dev_refine_chains); 0 = scan on the device, pairing and chaining on the host (rounds 1-2)
+static bool gpu_refine_chains_mode()
+{
+	const char *e = getenv("MPA_GPU_REFINE_CHAINS");
+	return e ? atoi(e) != 0 : true;
+}
+
 // MPA_GPU_CHAIN=1: the forward passes of the main chain and of the refinement chains on the device (k_chain_fwd); default: on
 // the host.  Measured at config 3 (3 Gbp x 20 000 proteins, three DP lanes, 64 host threads): 0.96-1.01 s with the host passes,
 // 1.09-1.11 s with the device passes -- the pass itself is 24-28 ms per 2 000-protein batch next to three DP rounds in flight
@@ -1036,7 +1085,8 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	const double t_a = now_ms();
 	// the refinement scan of all windows on the device, if the batch is worth the round trip
 	RefineHits rh;
-	bool on_device = false;
+	RefineChains rchains;
+	bool on_device = false, chains_on_device = false;
 	const int mode = gpu_refine_mode();
 	if (rctx && mode != 0 && b->opt.kmer2 <= 6) {
 		static thread_local std::vector<RefineWindow> wins;
@@ -1054,7 +1104,35 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 				n_bases += ae - as;
 			}
 		}
-		if (!wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
+		if (!wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases) && gpu_refine_chains_mode() && !dev_chain && b->opt.kmer2 <= 6) {
+			// the whole refinement on the device: groups of every query (in parallel), then scan + pairing + sort + chains
+			static thread_local std::vector<QueryGroups> per;
+			static thread_local RefineGroupsHost G;
+			per.resize((size_t)n_q);
+			QueryGroups *perp = per.data();
+			parallel_for(b->n_threads, n_q, [&, perp](int64_t i) { query_groups(b->qs[i].seq, b->qs[i].qlen, b->opt.kmer2, perp[i]); });
+			G.qg_first.assign((size_t)n_q + 1, 0);
+			size_t n_kmer = 0;
+			for (int64_t i = 0; i < n_q; ++i) G.qg_first[(size_t)i + 1] = G.qg_first[(size_t)i] + (int64_t)per[(size_t)i].gword.size(), n_kmer += per[(size_t)i].qpos.size();
+			G.gword.resize((size_t)G.qg_first[(size_t)n_q]), G.gcount.resize(G.gword.size()), G.gfirst.resize(G.gword.size()), G.qpos.resize(n_kmer);
+			{
+				size_t at = 0;
+				for (int64_t i = 0; i < n_q; ++i) {
+					const QueryGroups &p = per[(size_t)i];
+					const size_t g0 = (size_t)G.qg_first[(size_t)i];
+					size_t k0 = at;
+					for (size_t g = 0; g < p.gword.size(); ++g) G.gword[g0 + g] = p.gword[g], G.gcount[g0 + g] = p.gcount[g], G.gfirst[g0 + g] = (uint32_t)k0, k0 += p.gcount[g];
+					if (!p.qpos.empty()) memcpy(&G.qpos[at], p.qpos.data(), p.qpos.size() * 4);
+					at += p.qpos.size();
+				}
+			}
+			const double t1 = now_ms();
+			const int rc = dev_refine_chains(rctx, const_cast<mpa_idx_s*>(b->mi), b->opt.kmer2, b->mi->opt.min_aa_len, b->opt.max_ava, refine_chain_params(b->opt), (int32_t)n_q, G,
+			                                 (int64_t)wins.size(), wins.data(), rchains);
+			timing_note("  refinement on the GPU (scan + pairs + chains)", now_ms() - t1);
+			chains_on_device = rc == MPA_OK;                   // anything else: the scan alone below, or the host
+		}
+		if (!chains_on_device && !wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
 			std::vector<uint32_t> w;
 			qw_first.assign((size_t)n_q + 1, 0), qwords.clear();
 			for (int64_t i = 0; i < n_q; ++i) {
@@ -1098,8 +1176,9 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	const ChainIO *riop = ref_fwd ? &rio : nullptr;
 	const int64_t *rfp = rfirst.data();
 	const bool pairs_ready = dev_chain;
-	parallel_for(b->n_threads, n_q, [&, rhp, riop, rfp, pairs_ready](int64_t i) {
-		stage_refine_to_plan(b, b->qs[i], rhp, pairs_ready, riop, rfp);
+	const RefineChains *rcp = chains_on_device ? &rchains : nullptr;
+	parallel_for(b->n_threads, n_q, [&, rhp, riop, rfp, pairs_ready, rcp](int64_t i) {
+		stage_refine_to_plan(b, b->qs[i], rhp, pairs_ready, riop, rfp, rcp);
 		AccTimer tm(7);
 		plan_round1(b, b->qs[i]);
 	});

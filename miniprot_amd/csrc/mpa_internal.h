@@ -104,6 +104,19 @@ struct RefineWindow { int64_t as; int32_t qid, vid, len; };    // strand-local w
 struct RefineHits { std::vector<int64_t> first; std::vector<uint64_t> hits; };
 int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t n_query, const int64_t *qw_first, const uint32_t *qwords,
                     int64_t n_win, const RefineWindow *wins, RefineHits &out);
+// The whole refinement of a mini-batch on the device (mp_refine_reg, map.c:32-96): window scan, pairing of equal k-mers, the sort
+// of every window's pairs, the forward pass and the extraction of its chain.  The query side comes as GROUPS (the distinct k-mers
+// of every query: packed word, and the query positions that carry it).  out: the chains of every window as mp_chain() returns them.
+struct RefineGroupsHost {
+	std::vector<int64_t> qg_first;           // [n_query + 1]
+	std::vector<uint32_t> gword, gfirst, gcount, qpos;
+};
+struct RefineChains {
+	std::vector<int64_t> u_first, a_first;   // [n_win + 1]
+	const uint64_t *U = nullptr, *A = nullptr;   // pinned buffers of the context, valid until its next call
+};
+int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_len, int32_t max_ava, const ChainParams &cp, int32_t n_query, const RefineGroupsHost &groups,
+                      int64_t n_win, const RefineWindow *wins, RefineChains &out);
 // forward pass of mp_chain (chain.c:181-209) for a batch of problems on the device; see dp_exec.hip
 struct ChainIO { uint64_t *a = nullptr; int32_t *f = nullptr, *pred = nullptr; };   // pinned buffers of the context, valid until its next chain call
 int dev_chain_buffers(mpa_ctx_t *ctx, int64_t n, ChainIO &io);

@@ -979,6 +979,128 @@ __global__ __launch_bounds__(256) void k_refine_scan(DevGenome g, const RefineWi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Refinement pairing on the device (mp_refine_reg, map.c:53-79): the window positions and the query positions that carry the
+// same k-mer, all pairs per k-mer unless there are too many.
+//   k_refine_scan_map   the refinement scan again, but the query's DISTINCT k-mers ("groups") sit in an LDS map word -> group, and
+//                       every hit also counts itself in wcnt[window][group]: n1 of map.c:66 needs no sort
+//   k_refine_pair_count n2 = the group's query positions; the pairs of a hit are n2 if n1 * n2 <= max_ava (32-bit product, as the
+//                       reference computes it), else none
+//   (exclusive scan)    where each hit's pairs go
+//   k_refine_pair_emit  window << 44 | window position << 22 | query position -- one radix sort of these keys is the reference's
+//                       sort of every window's pair list (map.c:80), and the window boundaries fall out of per-window counts
+//   k_refine_pair_decode  position << 32 | query position: the anchors mp_chain() takes (bbit = 0)
+// ------------------------------------------------------------------------------------------------
+struct RefineGroups {
+	const int64_t *qg_first;     // [n_query + 1] first group of every query
+	const uint32_t *gword;       // [n_group] the packed k-mer word of the group
+	const uint32_t *gfirst;      // [n_group] its first entry in qpos
+	const uint32_t *gcount;      // [n_group] how many query positions carry it
+	const uint32_t *qpos;        // query positions (index of the k-mer's last residue), group by group, ascending inside a group
+};
+
+__global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const RefineWindowDev *wins, const RefineChunk *chunks, RefineGroups gr, const int64_t *wg_first, RefineTab rt,
+                                                         int32_t kmer, int32_t min_aa_len, int32_t hs_log2, uint4 *hits, unsigned long long *n_hits, unsigned long long cap, uint32_t *wcnt)
+{
+	MPA_SHORT_KERNEL();
+	extern __shared__ uint32_t lds_refine[];
+	const int32_t HS = 1 << hs_log2;
+	uint32_t *tkey = lds_refine, *tval = tkey + HS;               // open addressing: word -> group (0xffffffff = empty)
+	uint8_t *base = (uint8_t*)(tval + HS);                          // [REFINE_CHUNK + 2 * REFINE_HALO] nt4 codes, 15 = outside the window
+	__shared__ uint8_t tab[64];
+	const RefineChunk ch = chunks[blockIdx.x];
+	const RefineWindowDev w = wins[ch.win];
+	const int cid = w.vid >> 1, rev = w.vid & 1;
+	const int64_t off = g.ctg_off[cid], clen = g.ctg_len[cid];
+	if (threadIdx.x < 64) tab[threadIdx.x] = rt.t[threadIdx.x];
+	for (int k = threadIdx.x; k < HS; k += 256) tkey[k] = 0xffffffffu;
+	for (int k = threadIdx.x; k < REFINE_CHUNK + 2 * REFINE_HALO; k += 256) {
+		const int64_t p = (int64_t)ch.start - REFINE_HALO + k;
+		base[k] = (p < 0 || p >= w.len) ? 15 : (uint8_t)strand_base(g.seq, off, clen, rev, w.as + p);
+	}
+	__syncthreads();
+	const int64_t G0 = gr.qg_first[w.qid], G1 = gr.qg_first[w.qid + 1];
+	for (int64_t k = G0 + threadIdx.x; k < G1; k += 256) {
+		const uint32_t word = gr.gword[k];
+		uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);
+		for (;;) {
+			const uint32_t old = atomicCAS(&tkey[slot], 0xffffffffu, word);
+			if (old == 0xffffffffu) { tval[slot] = (uint32_t)(k - G0); break; }     // (the groups' words are distinct)
+			slot = (slot + 1) & (HS - 1);
+		}
+	}
+	__syncthreads();
+	const uint32_t mask = (1u << (4 * kmer)) - 1;
+	auto codon_at = [&](int e) -> uint32_t {
+		const uint32_t b0 = base[e - 2], b1 = base[e - 1], b2 = base[e];
+		if ((b0 | b1 | b2) > 3) return 0xffu;
+		return tab[b0 << 4 | b1 << 2 | b2];
+	};
+	const int64_t wc0 = wg_first[ch.win];
+	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
+		const int32_t pos = ch.start + t * 256 + (int32_t)threadIdx.x;
+		if (pos >= w.len) continue;
+		const int e = pos - ch.start + REFINE_HALO;
+		uint32_t word = 0;
+		bool ok = true;
+		for (int c = kmer - 1; c >= 0; --c) {
+			const uint32_t r = codon_at(e - 3 * c);
+			if (r == 0xffu) { ok = false; break; }
+			word = word << 4 | r;
+		}
+		if (!ok) continue;
+		word &= mask;
+		uint32_t grp = 0xffffffffu;
+		for (uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);; slot = (slot + 1) & (HS - 1)) {
+			const uint32_t v = tkey[slot];
+			if (v == word) { grp = tval[slot]; break; }
+			if (v == 0xffffffffu) break;
+		}
+		if (grp == 0xffffffffu) continue;
+		int32_t n = kmer;
+		for (int q = e - 3 * kmer; n < min_aa_len && q >= 2 && codon_at(q) != 0xffu; q -= 3) ++n;
+		for (int q = e + 3; n < min_aa_len && q < REFINE_CHUNK + 2 * REFINE_HALO && codon_at(q) != 0xffu; q += 3) ++n;
+		if (n < min_aa_len) continue;
+		const unsigned long long at = atomicAdd(n_hits, 1ULL);
+		if (at < cap) hits[at] = make_uint4((uint32_t)ch.win, (uint32_t)pos, (uint32_t)(G0 + grp), grp);
+		atomicAdd(&wcnt[wc0 + grp], 1u);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_refine_pair_count(const uint4 *hits, int64_t n_hits, const int64_t *wg_first, const uint32_t *wcnt, const uint32_t *gcount, int32_t max_ava,
+                                                           uint32_t *pc, uint32_t *wpairs)
+{
+	MPA_SHORT_KERNEL();
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_hits) return;
+	const uint4 h = hits[i];
+	const int32_t n1 = (int32_t)wcnt[wg_first[h.x] + h.w], n2 = (int32_t)gcount[h.z];
+	const uint32_t c = (n2 > 0 && (int32_t)((uint32_t)n1 * (uint32_t)n2) <= max_ava) ? (uint32_t)n2 : 0u;   // (the reference's 32-bit product, wrap-around and all)
+	pc[i] = c;
+	if (c) atomicAdd(&wpairs[h.x], c);
+}
+
+__global__ __launch_bounds__(256) void k_refine_pair_emit(const uint4 *hits, int64_t n_hits, const uint32_t *pc, const uint64_t *po, RefineGroups gr, uint64_t *keys)
+{
+	MPA_SHORT_KERNEL();
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_hits) return;
+	const uint32_t c = pc[i];
+	if (!c) return;
+	const uint4 h = hits[i];
+	const uint64_t hi = (uint64_t)h.x << 44 | (uint64_t)h.y << 22;
+	const uint32_t *qp = gr.qpos + gr.gfirst[h.z];
+	uint64_t *dst = keys + po[i];
+	for (uint32_t j = 0; j < c; ++j) dst[j] = hi | qp[j];
+}
+
+__global__ __launch_bounds__(256) void k_refine_pair_decode(const uint64_t *keys, int64_t n, uint64_t *a)
+{
+	MPA_SHORT_KERNEL();
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { const uint64_t k = keys[i]; a[i] = ((k >> 22) & 0x3fffffULL) << 32 | (k & 0x3fffffULL); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Index build on the device (mp_idx_build: build_worker + build_bidx, index.c:52-136; mp_sketch_nt4 + mp_sketch_clean_orf,
 // sketch.c:40-100): every selected k-mer of every reading frame of both strands of every contig as (bucket << 32 | global
 // block id); sorted and de-duplicated these keys ARE the index -- kb[] is their low words (inside a bucket ascending global
