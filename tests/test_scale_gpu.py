@@ -63,7 +63,7 @@ def test_genome_scale_batch_with_default_thresholds(ctx, tmp_path, monkeypatch, 
     batches = [mpa.Queries(prots[a:b], names[a:b]) for a, b in ((0, 3000), (3000, 3300))]
     ours = b"".join(mpa.map_batches(ctx, idx, mo, batches, min(64, NCPU)))
     notes = capfd.readouterr().err
-    assert "seeding on the GPU" in notes and "refinement scan on the GPU" in notes, "the device stages did not switch on by themselves"
+    assert "seeding on the GPU" in notes and ("refinement on the GPU" in notes or "refinement scan on the GPU" in notes), "the device stages did not switch on by themselves"
     ref = _reference(tmp_path, idx, prots, names, ["-I", "-u"])
     assert ours == ref, _first_difference(ours, ref)
     assert ours.count(b"\n") >= 3300
