@@ -639,9 +639,8 @@ __global__ __launch_bounds__(256) void k_seed_gather_kept(const SeedJobDev *jobs
 // hitting the same block: degenerate low-complexity input -- is flagged and seeded on the host.
 // ------------------------------------------------------------------------------------------------
 #define SIFT_THREADS 256
-#define SIFT_CAP 2048                                     /* anchors per LDS buffer (8 KB) */
 #define SIFT_CARRY_MAX 1024                               /* anchors that may wait for the next range */
-#define SIFT_TARGET 1280u                                 /* anchors a range is sized for */
+// SIFT_CAP (template parameter CAP): anchors per LDS buffer -- 2048 (8 KB) or 4096 (16 KB); a range is sized for 5/8 of it
 struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t cur_off; }; // blocks [lo, hi) of query qid; cur_off: the segment's own cursors (one per list of the query)
 
 __device__ __forceinline__ uint32_t sift_wave_sum(uint32_t v)
@@ -679,11 +678,13 @@ __device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0
 
 // skey/sval: staging, indexed like the unfiltered anchors (a segment writes its kept anchors from qfirst[q] + rank base on: the
 // kept ones can never outnumber the anchors below them); seg_kept[seg] / seg_base[seg]: how many and from where.
-__global__ __launch_bounds__(SIFT_THREADS) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const uint32_t *kb,
+template<int SIFT_CAP>
+__global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const uint32_t *kb,
                                                             uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
                                                             int64_t *seg_base, int32_t *qflag)
 {
 	MPA_SHORT_KERNEL();
+	constexpr uint32_t SIFT_TARGET = (uint32_t)SIFT_CAP * 5u / 8u;      // anchors a range is sized for
 	__shared__ uint32_t keys[SIFT_CAP];
 	__shared__ uint32_t scr[4];
 	__shared__ uint32_t wtot[4];
