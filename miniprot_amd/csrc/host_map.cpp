@@ -1458,6 +1458,26 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 
 // Several mini-batches as a three-stage software pipeline: [seed..plan of batch k+1] | [DP rounds of batch k on the GPU]
 // | [flatten + format batch k-1].  Each stage is one host thread driving its own worker-pool lane.
+// the results of consecutive slices of a batch (slice s starts at query q0[s]) as the result of the whole batch; frees the parts
+static mpa_result_t *merge_results(const std::vector<mpa_result_t*> &parts, const std::vector<int32_t> &q0, int32_t n_seq)
+{
+	mpa_result_s *res = new mpa_result_s();
+	res->n_seq = n_seq;
+	res->hit_off.assign((size_t)n_seq + 1, 0);
+	for (size_t s = 0; s < parts.size(); ++s) {
+		mpa_result_s *p = parts[s];
+		if (!p) continue;
+		const int64_t h0 = (int64_t)res->hits.size(), c0 = (int64_t)res->cigars.size(), f0 = (int64_t)res->feats.size();
+		for (int32_t i = 0; i < p->n_seq; ++i) res->hit_off[(size_t)q0[s] + i] = h0 + p->hit_off[i];
+		for (mpa_hit_t h : p->hits) { h.qid += q0[s], h.cigar_off += c0, h.feat_off += f0; res->hits.push_back(h); }
+		res->cigars.insert(res->cigars.end(), p->cigars.begin(), p->cigars.end());
+		res->feats.insert(res->feats.end(), p->feats.begin(), p->feats.end());
+		delete p;
+	}
+	res->hit_off[(size_t)n_seq] = (int64_t)res->hits.size();
+	return res;
+}
+
 // claim != nullptr: the job's batches are handed out by the caller -- claim(user) returns the index (into batches[]) of the next
 // batch this call should map, or -1 when the job has none left -- so that several callers (one process per GPU) can share one
 // job and each takes work as fast as it gets through it (the kt_for work stealing of map.c:264-271, between processes).
@@ -1470,12 +1490,29 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
 	g_trace_t0 = now_ms();
-	struct Slot { mpa_batch_t *b = nullptr; int32_t g = 0; bool seeded = false, begun = false, dp_done = false; };   // g: index into batches[]
-	std::vector<Slot> slot((size_t)n_batches);
+	// What moves through the pipeline is a UNIT: a whole mini-batch, or -- for the first and the last mini-batches of the stream -- a
+	// quarter of one.  A stream of K batches takes (K - 1) steps plus the time ONE batch needs to get through all stages (seeding,
+	// planning, three DP rounds: ~0.6 s at config 3); while the pipeline fills and drains most of the GPU idles.  The DP rounds of a
+	// quarter batch last as long as those of a whole one (a round is as long as its longest window), but its seeding and planning
+	// take a quarter of the time and the quarters run side by side on the lanes, so the first DP round starts ~0.25 s earlier and
+	// the last one ends ~0.25 s earlier.  Results and text of a split batch are merged back: the caller sees whole batches
+	// (MPA_EDGE_SPLIT = parts, default 4; 0/1 = off).
+	const int edge_parts = [] { const char *e = getenv("MPA_EDGE_SPLIT"); const int v = e ? atoi(e) : 4; return v < 2 ? 1 : v > 8 ? 8 : v; }();
+	const int edge_batches = 2;                           // how many batches at either end are split
+	struct Slot {
+		mpa_batch_t *b = nullptr;
+		int32_t g = 0, j = 0;                             // index into batches[]; ordinal of the batch among those this call maps
+		int32_t part = 0, n_parts = 1, q0 = 0;            // which part of the batch, and its first query
+		mpa_qbatch_t q{};                                 // the unit's queries (a slice of batches[g])
+		bool seeded = false, begun = false, dp_done = false;
+	};
+	std::vector<Slot> slot((size_t)n_batches * (size_t)edge_parts);
 	std::mutex mu, claim_mu;
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK, next_seed = 0, next_plan = 0;
-	int32_t n_total = n_batches;                          // batches this call maps: shrinks to the number claimed when the job runs out (guarded by mu)
+	int32_t n_total = (int32_t)slot.size();               // units this call maps: shrinks to the number created when the job runs out (guarded by mu)
+	int32_t n_created = 0, n_claimed = 0, next_own = 0;   // units created so far; batches taken; (without a claim function) the next batch
+	bool exhausted = false;
 	if (n_mapped) *n_mapped = 0;
 	std::string err;
 	// DP lanes = batches in their DP rounds at the same time.  A round is one k_dp_round launch (one hardware queue), so four
@@ -1495,7 +1532,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// nothing from more than ~32 threads, so two batches are planned side by side with half the threads each
 	// (MPA_PLANNERS, default 2).  The seeder's own streams and buffers, one set per batch that can be between seeding and
 	// the end of planning: the result of batch k is consumed while batches k+1 .. are on the device.
-	int n_plan = 2;
+	// (round 3: with the whole refinement on the device a planner mostly waits for it -- three of them, a third of the threads each)
+	int n_plan = 3;
 	if (const char *e = getenv("MPA_PLANNERS")) n_plan = atoi(e);
 	n_plan = std::max(1, std::min(n_plan, 6));
 	// Seeders: the device-seeding stage of a batch is mostly waiting for its kernels, which share the GPU with the DP rounds in
@@ -1527,12 +1565,25 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			int32_t k;
 			{	// (claims are serialised among the seeders, outside the pipeline's own lock: a claim may be a round trip to another process)
 				std::lock_guard<std::mutex> cl(claim_mu);
-				{ std::lock_guard<std::mutex> g(mu); if (next_seed >= n_total || rc_all != MPA_OK) return; }
-				const int32_t want = claim ? claim(claim_user) : 0;
+				bool need_batch;
+				{ std::lock_guard<std::mutex> g(mu); if (rc_all != MPA_OK || (next_seed >= n_created && exhausted)) return; need_batch = next_seed >= n_created; }
+				if (need_batch) {                                     // no unit waiting: the next batch of the job, cut into its units
+					const int32_t want = claim ? claim(claim_user) : (next_own < n_batches ? next_own++ : -1);
+					std::lock_guard<std::mutex> g(mu);
+					if (want < 0 || want >= n_batches) { exhausted = true, n_total = n_created; cv.notify_all(); return; }   // the job has no batch left
+					const mpa_qbatch_t &bq = batches[want];
+					const bool edge = n_claimed < edge_batches || want >= n_batches - edge_batches;
+					const int parts = edge && bq.n_seq >= 64 * edge_parts ? edge_parts : 1;
+					for (int p = 0; p < parts; ++p) {
+						Slot &u = slot[(size_t)n_created + p];
+						const int32_t a0 = (int32_t)((int64_t)bq.n_seq * p / parts), a1 = (int32_t)((int64_t)bq.n_seq * (p + 1) / parts);
+						u.g = want, u.j = n_claimed, u.part = p, u.n_parts = parts, u.q0 = a0;
+						u.q = mpa_qbatch_t{ a1 - a0, bq.seqs, bq.q_off + a0 };
+					}
+					n_created += parts, ++n_claimed;
+				}
 				std::lock_guard<std::mutex> g(mu);
-				if (claim && (want < 0 || want >= n_batches)) { n_total = next_seed; cv.notify_all(); return; }   // the job has no batch left
-				k = next_seed++;                                      // (a free seeder takes the next batch in input order)
-				slot[k].g = claim ? want : k;
+				k = next_seed++;                                      // (a free seeder takes the next unit in input order)
 			}
 			{	// its result lives in a seeding context until the batch is planned: wait for the batch that had this context before
 				std::unique_lock<std::mutex> g(mu);
@@ -1540,7 +1591,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK) return;
 			}
 			trace(kSeedName[sd], k, "begin");
-			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &batches[slot[k].g], n_threads);
+			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &slot[k].q, n_threads);
 			trace(kSeedName[sd], k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1577,16 +1628,37 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		tl_pool_lane = 1, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "output: worker pool";
 		CpuSpan cs("output: stage thread (flatten + format)");
-		for (int32_t k = 0; k < n_batches; ++k) {
+		std::vector<mpa_result_t*> parts;                     // the finished parts of the batch that is being assembled
+		std::vector<int32_t> part_q0;
+		std::string part_text;
+		for (int32_t k = 0; k < (int32_t)slot.size(); ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
 				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].dp_done; });
 				if (k >= n_total || !slot[k].dp_done) return;
 			}
 			trace("finish", k, "begin");
-			results[k] = mpa_batch_finish(slot[k].b);
+			const Slot &u = slot[k];
+			mpa_result_t *r = mpa_batch_finish(slot[k].b);
 			slot[k].b = nullptr;
-			if (names) text_len[k] = mpa_format_output(mi, opt, &batches[slot[k].g], names[slot[k].g], results[k], id_io, &text[k]);
+			char *t = nullptr;
+			int64_t tl = 0;
+			if (names) tl = mpa_format_output(mi, opt, &u.q, names[u.g] + u.q0, r, id_io, &t);   // (units finish in input order: the hit ids run on)
+			if (u.n_parts == 1) { results[u.j] = r; if (names) text[u.j] = t, text_len[u.j] = tl; }
+			else {
+				parts.push_back(r), part_q0.push_back(u.q0);
+				if (names) { part_text.append(t, (size_t)tl); free(t); }
+				if (u.part == u.n_parts - 1) {                    // the batch is complete: one result, one text
+					results[u.j] = merge_results(parts, part_q0, batches[u.g].n_seq);
+					parts.clear(), part_q0.clear();
+					if (names) {
+						text[u.j] = (char*)malloc(part_text.size() + 1);
+						memcpy(text[u.j], part_text.data(), part_text.size());
+						text[u.j][part_text.size()] = 0, text_len[u.j] = (int64_t)part_text.size();
+						part_text.clear();
+					}
+				}
+			}
 			trace("finish", k, "end");
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("output stage: ") + e.what()); } });
@@ -1610,7 +1682,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			}
 			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
 			trace(lane_name[d], k, "begin");
-			const int rc = run_dp_rounds(cd, mi, &batches[slot[k].g], slot[k].b);
+			const int rc = run_dp_rounds(cd, mi, &slot[k].q, slot[k].b);
 			trace(lane_name[d], k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1629,8 +1701,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	ctx_absorb_sibling_stats(ctx);
 	cpu_report_and_reset("mpa_map_batches", now_ms() - g_trace_t0);
 	if (rc_all == MPA_OK) {
-		if (n_mapped) *n_mapped = n_total;
-		if (order) for (int32_t k = 0; k < n_total; ++k) order[k] = slot[k].g;
+		if (n_mapped) *n_mapped = n_claimed;
+		if (order) for (int32_t k = 0; k < n_total; ++k) order[slot[k].j] = slot[k].g;
 	}
 	if (rc_all != MPA_OK) {
 		for (Slot &sl : slot) delete sl.b;
