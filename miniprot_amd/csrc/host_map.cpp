@@ -167,6 +167,7 @@ static void trace(const char *stage, int32_t batch, const char *what)
 
 static thread_local int tl_pool_lane = 0;
 static thread_local int tl_thread_div = 1;          // pipeline stages with light host work take a fraction of the threads
+static thread_local int tl_unit_parts = 1;          // the unit being seeded / planned is one of this many parts of a mini-batch (the device-stage thresholds are per batch)
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 {
 	std::function<void(int64_t)> f = fn;
@@ -920,7 +921,7 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	static thread_local std::vector<SeedJob> jobs;
 	qfirst.assign((size_t)q->n_seq + 1, 0), jfirst.assign((size_t)q->n_seq + 1, 0);
 	for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
-	if (mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) return b;
+	if (mode < 0 && qfirst[q->n_seq] * tl_unit_parts < kDeviceSeedingMinAnchors) return b;
 	if (jobs.size() < jfirst[q->n_seq]) jobs.resize(jfirst[q->n_seq]);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
 	// (pointers, not the thread_local vectors: the workers have their own, empty, instances of those)
@@ -1104,7 +1105,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 				n_bases += ae - as;
 			}
 		}
-		if (!wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases) && gpu_refine_chains_mode() && !dev_chain && b->opt.kmer2 <= 6) {
+		if (!wins.empty() && (mode == 1 || n_bases * tl_unit_parts >= kDeviceRefineMinBases) && gpu_refine_chains_mode() && !dev_chain && b->opt.kmer2 <= 6) {
 			// the whole refinement on the device: groups of every query (in parallel), then scan + pairing + sort + chains
 			static thread_local std::vector<QueryGroups> per;
 			static thread_local RefineGroupsHost G;
@@ -1132,7 +1133,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 			timing_note("  refinement on the GPU (scan + pairs + chains)", now_ms() - t1);
 			chains_on_device = rc == MPA_OK;                   // anything else: the scan alone below, or the host
 		}
-		if (!chains_on_device && !wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
+		if (!chains_on_device && !wins.empty() && (mode == 1 || n_bases * tl_unit_parts >= kDeviceRefineMinBases)) {
 			std::vector<uint32_t> w;
 			qw_first.assign((size_t)n_q + 1, 0), qwords.clear();
 			for (int64_t i = 0; i < n_q; ++i) {
@@ -1497,8 +1498,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// take a quarter of the time and the quarters run side by side on the lanes, so the first DP round starts ~0.25 s earlier and
 	// the last one ends ~0.25 s earlier.  Results and text of a split batch are merged back: the caller sees whole batches
 	// (MPA_EDGE_SPLIT = parts, default 4; 0/1 = off).
+	// Measured (config 3, 20 steps): splitting the FIRST batches costs more than it gains -- a lane's grow-only device pools are sized
+	// by the first unit it sees, and re-growing them for the whole batches that follow stalls the device (MPA_EDGE_SPLIT_HEAD=1
+	// splits them anyway); the LAST batches meet pools that are already large.
 	const int edge_parts = [] { const char *e = getenv("MPA_EDGE_SPLIT"); const int v = e ? atoi(e) : 4; return v < 2 ? 1 : v > 8 ? 8 : v; }();
+	const bool edge_head = [] { const char *e = getenv("MPA_EDGE_SPLIT_HEAD"); return e && atoi(e) != 0; }();
 	const int edge_batches = 2;                           // how many batches at either end are split
+	const int edge_min = [] { const char *e = getenv("MPA_EDGE_SPLIT_MIN"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();   // a part has at least this many queries (the tests lower it)
 	struct Slot {
 		mpa_batch_t *b = nullptr;
 		int32_t g = 0, j = 0;                             // index into batches[]; ordinal of the batch among those this call maps
@@ -1572,8 +1578,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 					std::lock_guard<std::mutex> g(mu);
 					if (want < 0 || want >= n_batches) { exhausted = true, n_total = n_created; cv.notify_all(); return; }   // the job has no batch left
 					const mpa_qbatch_t &bq = batches[want];
-					const bool edge = n_claimed < edge_batches || want >= n_batches - edge_batches;
-					const int parts = edge && bq.n_seq >= 64 * edge_parts ? edge_parts : 1;
+					const bool edge = (edge_head && n_claimed < edge_batches) || (want >= n_batches - edge_batches && n_batches > 2 * edge_batches);
+					const int parts = edge && bq.n_seq >= edge_min * edge_parts ? edge_parts : 1;
 					for (int p = 0; p < parts; ++p) {
 						Slot &u = slot[(size_t)n_created + p];
 						const int32_t a0 = (int32_t)((int64_t)bq.n_seq * p / parts), a1 = (int32_t)((int64_t)bq.n_seq * (p + 1) / parts);
@@ -1591,6 +1597,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK) return;
 			}
 			trace(kSeedName[sd], k, "begin");
+			tl_unit_parts = slot[k].n_parts;
 			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &slot[k].q, n_threads);
 			trace(kSeedName[sd], k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
@@ -1615,6 +1622,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK || k >= n_total) return;       // (k >= n_total: the job ran out before this slot was claimed)
 			}
 			trace(kPlanName[pl], k, "begin");
+			tl_unit_parts = slot[k].n_parts;
 			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
 			trace(kPlanName[pl], k, "end");
 			std::lock_guard<std::mutex> g(mu);

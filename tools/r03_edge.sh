@@ -9,12 +9,12 @@ run() {
   ( env $2 timeout 600 python bench.py --no-extra --workload-cache $WL --steps 20 --warmup 5 $3 ) > $OUT/$1.json 2> $OUT/$1.err
   python tools/bench_line.py "$1 [$2 $3]" $OUT/$1.json
 }
-run split4 "" ""
+run tail4 "" ""
 run nosplit "MPA_EDGE_SPLIT=1" "--no-cpu-baseline"
-run split4b "" "--no-cpu-baseline"
+run tail4b "" "--no-cpu-baseline"
 run nosplitb "MPA_EDGE_SPLIT=1" "--no-cpu-baseline"
-run split8 "MPA_EDGE_SPLIT=8" "--no-cpu-baseline"
-run split4hostref "MPA_GPU_REFINE_CHAINS=0" "--no-cpu-baseline"
+run tail2 "MPA_EDGE_SPLIT=2" "--no-cpu-baseline"
+run tail4c "" "--no-cpu-baseline"
 run trace "MPA_TRACE=1" "--no-cpu-baseline"
 python tools/gantt.py $OUT/trace.err > $OUT/gantt.txt 2>&1; head -16 $OUT/gantt.txt
 rm -f $OUT/*.err
