@@ -1497,11 +1497,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// quarter batch last as long as those of a whole one (a round is as long as its longest window), but its seeding and planning
 	// take a quarter of the time and the quarters run side by side on the lanes, so the first DP round starts ~0.25 s earlier and
 	// the last one ends ~0.25 s earlier.  Results and text of a split batch are merged back: the caller sees whole batches
-	// (MPA_EDGE_SPLIT = parts, default 4; 0/1 = off).
-	// Measured (config 3, 20 steps): splitting the FIRST batches costs more than it gains -- a lane's grow-only device pools are sized
-	// by the first unit it sees, and re-growing them for the whole batches that follow stalls the device (MPA_EDGE_SPLIT_HEAD=1
-	// splits them anyway); the LAST batches meet pools that are already large.
-	const int edge_parts = [] { const char *e = getenv("MPA_EDGE_SPLIT"); const int v = e ? atoi(e) : 4; return v < 2 ? 1 : v > 8 ? 8 : v; }();
+	// (MPA_EDGE_SPLIT = parts; default 1 = off, see below).
+	// Measured (config 3, 5 warm-up + 20 timed steps, profiles/r03_experiments.txt): OFF by default.  The device pools of a lane or a
+	// seeding context are grow-only and sized by the first units it sees; a context that met only quarter batches in the warm-up
+	// stream re-grows every pool when its first whole batch arrives in the timed one (hipFree waits for the whole device): 6.9-10.9 M
+	// residues/s against 17.7 M without the split.  In a long stream the pools settle and the split does what it is meant to; it is
+	// kept as an opt-in (and tested for identity), MPA_EDGE_SPLIT_HEAD=1 splits the first batches as well.
+	const int edge_parts = [] { const char *e = getenv("MPA_EDGE_SPLIT"); const int v = e ? atoi(e) : 1; return v < 2 ? 1 : v > 8 ? 8 : v; }();
 	const bool edge_head = [] { const char *e = getenv("MPA_EDGE_SPLIT_HEAD"); return e && atoi(e) != 0; }();
 	const int edge_batches = 2;                           // how many batches at either end are split
 	const int edge_min = [] { const char *e = getenv("MPA_EDGE_SPLIT_MIN"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();   // a part has at least this many queries (the tests lower it)
