@@ -4,8 +4,9 @@ where the guide gives one): HBM bytes per launch, LDS bank-conflict rate, VALU b
     python tools/pmc_report.py pmc_all.json > pmc_summary.json"""
 import json, re, sys
 d = json.load(open(sys.argv[1]))
-out = {"source": "rocprofv3 --pmc <block> --kernel-trace, one pass per counter block (tools/pmc_round.sh); workload: config 3 scaled x0.1 "
-                 "(300 Mbp x 2 000 proteins, -I -u), 3 blocking steps, MPA_DP_LANES=1",
+import os
+out = {"source": "rocprofv3 --pmc <block> --kernel-trace, one pass per counter block (tools/pmc_round.sh); workload: "
+                 + os.environ.get("PMC_WORKLOAD_NOTE", "config 3 scaled x0.1 (300 Mbp x 2 000 proteins, -I -u), 3 blocking steps, MPA_DP_LANES=1"),
        "corrections": "FETCH_SIZE x2 (gfx950 rocprofv3 tallies 128-B requests as 64 B, guide section HBM), KB units; WRITE_SIZE uncorrected; SQ_*_CYCLES in quad-cycles", "kernels": {}}
 def short(n):
     m = re.search(r"(k_[a-z0-9_]+)(ILi(\d+))?", n)
