@@ -180,6 +180,10 @@ typedef struct {
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
 /* sums over every mpa_dp_run() of this context since the last reset */
 void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset);
+/* Extension calls of 257..1024 columns are swept by two or four workgroups that hand column-block boundaries to each other
+ * through HBM.  Should a hand-off not arrive within seconds (a stalled hardware queue), mpa_dp_run() repeats the round with
+ * those calls on the one-wave path -- same results, no error.  How often that happened on this context: */
+int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx);
 
 /* ---- boundary #1: batched mp_map() ------------------------------------------------------------------------ */
 /* mp_feat_t / mp_extra_t / mp_reg1_t (miniprot.h:108-145) flattened for a C ABI */

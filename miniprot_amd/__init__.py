@@ -113,6 +113,9 @@ def lib():
                                  C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         L.mpa_dp_last_stats.argtypes = [C.c_void_p, C.POINTER(DpStats)]
         L.mpa_dp_total_stats.argtypes = [C.c_void_p, C.POINTER(DpStats), C.c_int]
+        if hasattr(L, "mpa_dp_handoff_retries"):                      # (absent from older builds loaded through MPA_LIB_PATH)
+            L.mpa_dp_handoff_retries.argtypes = [C.c_void_p]
+            L.mpa_dp_handoff_retries.restype = C.c_int64
         L.mpa_free.argtypes = [C.c_void_p]
         for name, res, args in [
             ("mpa_batch_begin", C.c_void_p, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int]),
@@ -177,6 +180,10 @@ class Context:
         else:
             lib().mpa_dp_last_stats(self.h, C.byref(st))
         return {k: getattr(st, k) for k, _ in DpStats._fields_}
+
+    def handoff_retries(self):
+        """DP rounds repeated because a workgroup hand-off of a split extension call timed out (mpa_dp_handoff_retries)."""
+        return int(lib().mpa_dp_handoff_retries(self.h))
 
     def __del__(self):
         try:

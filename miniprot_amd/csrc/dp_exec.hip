@@ -46,6 +46,15 @@ struct DevBuf {
 		cap = want;
 		return MPA_OK;
 	}
+	// exactly `bytes` (no slack) unless already that large: ctx_pools_equalize
+	int grow_to(size_t bytes) {
+		if (bytes <= cap) return MPA_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr, cap = 0;
+		if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return MPA_ERR_HIP; }
+		cap = bytes;
+		return MPA_OK;
+	}
 	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }
 	template<typename T> T *as() { return (T*)p; }
 };
@@ -68,6 +77,14 @@ struct HostPinned {
 		const size_t want = bytes + bytes / 2 + 4096;           // (re-pinning host memory is slow: grow in big steps)
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return MPA_ERR_HIP; }
 		cap = want;
+		return MPA_OK;
+	}
+	int grow_to(size_t bytes) {
+		if (bytes <= cap) return MPA_OK;
+		if (p) (void)hipHostFree(p);
+		p = nullptr, cap = 0;
+		if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return MPA_ERR_HIP; }
+		cap = bytes;
 		return MPA_OK;
 	}
 	void release() { if (p) (void)hipHostFree(p); p = nullptr, cap = 0; }
@@ -112,6 +129,8 @@ struct mpa_ctx_s {
 	hipEvent_t wait_ev = nullptr;             // blocking-sync event: a host thread that waits for the device SLEEPS (wait_stream)
 	int side_off = 0;                         // first side stream a round uses (lets the DP lanes of a stream of batches sit on different hardware queues)
 	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
+	bool no_split = false;                    // this mpa_dp_run() repeats a round whose workgroup hand-off timed out: 512/1024-column calls go to k_ext_huge
+	int64_t handoff_retries = 0;              // how often that has happened on this context (mpa_dp_handoff_retries)
 };
 
 namespace mpa {
@@ -374,6 +393,40 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 	return ctx->siblings[k - 1];
 }
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off) { ctx->side_off = off; }
+
+// Every grow-only pool of a context, in a fixed order (the same pool of two contexts has the same position).
+template<class FD, class FH> static void for_each_pool(mpa_ctx_s *c, FD fd, FH fh)
+{
+	SeedBufs &z = c->seed;
+	DevBuf *dev[] = { &c->tasks, &c->waves, &c->chunks, &c->qseq, &c->rec, &c->prof, &c->tb, &c->cig, &c->ncig, &c->score, &c->extout, &c->bnd, &c->list,
+	                  &c->rowkey, &c->cigd, &c->cigoff, &c->hkey, &c->xg, &c->units,
+	                  &z.jobs, &z.key[0], &z.key[1], &z.val[0], &z.val[1], &z.f, &z.pred, &z.mark, &z.flag, &z.idx, &z.tmp, &z.qfirst, &z.cfirst, &z.o_pos, &z.o_f,
+	                  &z.o_pred, &z.o_a, &z.r_win, &z.r_chunk, &z.r_qfirst, &z.r_words, &z.r_hits, &z.r_count, &z.pf_w, &z.pf_dst, &z.pf_rem, &z.pf_jfirst,
+	                  &z.pf_qfirst2, &z.pf_err, &z.val64[0], &z.val64[1], &z.s_meta, &z.s_cur, &z.s_cur2, &z.s_kept, &z.s_base, &z.s_out, &z.s_flag, &z.dkey,
+	                  &z.x_all, &z.rx_all, &z.rx_keys, &z.c_a, &z.c_f, &z.c_pred, &z.c_mark, &z.c_flag, &z.c_first, &z.c_long };
+	HostPinned *host[] = { &c->h_up, &c->h_down, &c->h_pool, &z.h_jobs, &z.h_pos, &z.h_f, &z.h_pred, &z.h_a, &z.h_rhits, &z.h_meta, &z.h_back, &z.h_U, &z.h_A,
+	                       &z.h_xoff, &z.hc_a, &z.hc_f, &z.hc_pred };
+	int k = 0;
+	for (DevBuf *b : dev) fd(b, k++);
+	k = 0;
+	for (HostPinned *b : host) fh(b, k++);
+}
+// The contexts of one pipeline stage (the DP lanes; the seeding/planning contexts) take turns on the batches of a stream, so
+// what one of them needed the others will need: bring every pool of every context up to the largest of its kind in the group.
+// Called between streams, when nothing of the caller's is in flight -- a pool that grows while kernels run costs a hipFree,
+// which waits for the whole device (a context that met only the short edge batches of one stream would otherwise re-grow
+// everything in the middle of the next).  A failed allocation is not an error here: the pool grows on demand later.
+void ctx_pools_equalize(mpa_ctx_t *const *list, int n)
+{
+	if (n < 2) return;
+	std::vector<size_t> hw_dev, hw_host;
+	for (int i = 0; i < n; ++i)
+		for_each_pool(list[i], [&](DevBuf *b, int k) { if ((int)hw_dev.size() <= k) hw_dev.resize(k + 1, 0); hw_dev[k] = std::max(hw_dev[k], b->cap); },
+		              [&](HostPinned *b, int k) { if ((int)hw_host.size() <= k) hw_host.resize(k + 1, 0); hw_host[k] = std::max(hw_host[k], b->cap); });
+	(void)hipSetDevice(list[0]->device);
+	for (int i = 0; i < n; ++i)
+		for_each_pool(list[i], [&](DevBuf *b, int k) { (void)b->grow_to(hw_dev[k]); }, [&](HostPinned *b, int k) { (void)b->grow_to(hw_host[k]); });
+}
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
 	for (mpa_ctx_s *sb : ctx->siblings) {
@@ -1315,6 +1368,7 @@ void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset)
 	if (reset) ctx->total = mpa_dp_stats_t();
 }
 
+#define MPA_RETRY_NO_SPLIT (-100)   /* internal: repeat the round without split extension calls */
 static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
                int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
 {
@@ -1357,7 +1411,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.out_idx = (int32_t)k;
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
-			const int cls = ext_class_of(t.ncol);                  // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
+			int cls = ext_class_of(t.ncol);                        // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
+			if (ctx->no_split && cls >= 5) cls = -1;               // repeated round: no inter-workgroup hand-off (see mpa_dp_run)
 			// The packed kernels run their gap scan on h + j*ge with saturating adds, which is only the reference's value while
 			// nothing can reach the int16 limits; calls that could (more than ~2900 columns with BLOSUM62, hence always of the
 			// "huge" class) are swept by k_ext_huge, whose int32 arithmetic clamps every operation like the reference does.
@@ -1814,8 +1869,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		if (l.is_ext) ms_ext_sum += ms;
 	}
 
-	if (*(const int32_t*)(hdn + dn_err)) {                                // a boundary hand-off that never arrived (bounded spin in the kernel)
-		set_error("k_ext_wide_split: a column-block hand-off between workgroups timed out"); return MPA_ERR_HIP;
+	// a boundary hand-off that never arrived (bounded spin in the kernel): the producer workgroup was running (it drew its
+	// ticket first) but made no progress for seconds -- a stalled hardware queue under oversubscription.  Nothing of this round
+	// has been handed to the caller yet: mpa_dp_run() repeats it with those calls on the one-wave path (k_ext_huge, same bits).
+	static const bool test_fail = [] { const char *e = getenv("MPA_TEST_HANDOFF_FAIL"); return e && atoi(e) != 0; }();
+	if (*(const int32_t*)(hdn + dn_err) || (test_fail && n_split && !ctx->no_split)) {
+		set_error("k_ext_wide_split: a column-block hand-off between workgroups timed out"); return MPA_RETRY_NO_SPLIT;
 	}
 	timing_note("  dp: upload+kernels (wall)", now_ms() - t_begin);
 	const double t_res = now_ms();
@@ -1902,7 +1961,18 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
                int64_t n, const mpa_dp_task_t *in, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool)
 {
-	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_dp_run_impl(ctx, mi, opt, q, n, in, rst, cigar_pool, n_pool); });
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] {
+		int rc = mpa_dp_run_impl(ctx, mi, opt, q, n, in, rst, cigar_pool, n_pool);
+		if (rc == MPA_RETRY_NO_SPLIT) {
+			ctx->no_split = true, ++ctx->handoff_retries;
+			rc = mpa_dp_run_impl(ctx, mi, opt, q, n, in, rst, cigar_pool, n_pool);
+			ctx->no_split = false;
+			if (rc == MPA_RETRY_NO_SPLIT) rc = MPA_ERR_HIP;
+		}
+		return rc;
+	});
 }
+
+int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx) { return ctx ? ctx->handoff_retries : 0; }
 
 } // extern "C"

@@ -151,6 +151,17 @@ template<int G> __device__ __forceinline__ int32_t shift1_i32(int32_t x, int32_t
 	return (int32_t)shift1<G>((uint32_t)x, (uint32_t)fill, lane);
 }
 
+// shift1 with a constant fill whose register is kept across calls: the DPP move leaves the lanes without a source untouched,
+// so a register that held `fill` everywhere once still holds it in exactly those lanes after any number of shifts -- no
+// "v_mov fill" per use (keep must start as fill and must only ever be written here)
+template<int G> __device__ __forceinline__ uint32_t shift1_keep(uint32_t &keep, uint32_t x, uint32_t fill, int lane)
+{
+	if (G == 16) { keep = dpp_mov<DPP_ROW_SHR(1), 0xf>(keep, x); return keep; }
+	keep = dpp_mov<DPP_WAVE_SHR1, 0xf>(keep, x);
+	if (G == 32) return lane == 32 ? fill : keep;
+	return keep;
+}
+
 template<int G> __device__ __forceinline__ int32_t group_max(int32_t v)
 {
 #pragma unroll
@@ -977,12 +988,59 @@ struct GlobArgs {
 
 #define SEG_BIG (1 << 20)
 
-// (x << 4 | 15 - k): the maximum over such keys is the best value and, among equal values, the smallest state index k --
-// the outcome of the reference's chain of strict '>' comparisons (nasw-sse.c:451-519) without ten compare/select pairs
-__device__ __forceinline__ int32_t st_key(int32_t x, int k) { return (int32_t)((uint32_t)x << 4) + (15 - k); }
+// (x << 16 | 15 - k): the maximum over such keys is the best value and, among equal values, the smallest state index k --
+// the outcome of the reference's chain of strict '>' comparisons (nasw-sse.c:451-519) without ten compare/select pairs.  x is
+// the LOW half of v (one v_lshl_or_b32, whatever the high half holds).
+__device__ __forceinline__ int32_t st_key(uint32_t v, int k) { return (int32_t)((v << 16) | (uint32_t)(15 - k)); }
 __device__ __forceinline__ int32_t imax3(int32_t a, int32_t b, int32_t c) { return imax(imax(a, b), c); }
 // (acc << 1) | (d < 0): collects "a > b" flags as the sign bits of b - a, one v_alignbit_b32 each
-__device__ __forceinline__ uint32_t push_neg(uint32_t acc, int32_t d) { return __builtin_amdgcn_alignbit(acc, (uint32_t)d, 31); }
+__device__ __forceinline__ uint32_t push_neg(uint32_t acc, uint32_t d) { return __builtin_amdgcn_alignbit(acc, d, 31); }
+// an int16-range value in both halves of a register
+__device__ __forceinline__ uint32_t spl(int32_t x) { return __builtin_amdgcn_perm((uint32_t)x, (uint32_t)x, 0x01000100u); }
+
+// The state a traceback lane carries from row to row.  Every member holds its int16 value in BOTH halves of the register
+// ("splat"): the reference computes these in saturating int16 (nasw-sse.c:444-542), and on a splat register one
+// v_pk_{add,sub}_i16 clamp IS that operation (an int32 lane needs a subtract and a clamp), the sign of the value is bit 31,
+// and signed int32 comparison of two splats orders them like the values.  Rows are processed in groups of three with the
+// slot of row i fixed at compile time (i mod 3), so nothing is moved between rows.
+struct GlobState { uint32_t H[3], Hs[3], D[3], A, B, C, dn[3], ac[3]; };
+__device__ __forceinline__ void glob_state_init(GlobState &s, const uint32_t q0, const uint32_t q1, const bool origin, const int32_t fs)
+{
+	for (int k = 0; k < 3; ++k) s.H[k] = s.Hs[k] = s.D[k] = NEGP, s.dn[k] = s.ac[k] = 0;
+	s.A = s.B = s.C = NEGP;
+	// rows 0 and 1 of the first column's left neighbour (the matrix's column -1): H(-1,-1) = 0, frameshifted starts
+	if (origin) s.Hs[2] = 0, s.Hs[0] = s.Hs[1] = splat16((int16_t)-fs);
+	s.dn[0] = __builtin_amdgcn_perm(q0, q0, 0x08010801u), s.dn[1] = __builtin_amdgcn_perm(q1, q1, 0x08010801u);
+	s.ac[0] = __builtin_amdgcn_perm(q0, q0, 0x09030903u), s.ac[1] = __builtin_amdgcn_perm(q1, q1, 0x09030903u);
+}
+// Row i (K = i mod 3) up to the choice among the states other than I: returns the key of the best of them, leaves the new D, A,
+// B, C in the state and the four "old value kept" differences (sign bit = direction bit) in dD..dC.  rcur = record of row i,
+// S = profile score of the row's amino acid in this lane's column (splat).
+template<int K>
+__device__ __forceinline__ int32_t glob_cands(GlobState &s, const uint32_t rcur, const uint32_t S, const uint32_t go, const uint32_t io, const uint32_t fs,
+                                              uint32_t &dD, uint32_t &dA, uint32_t &dB, uint32_t &dC)
+{
+	constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3, R3 = K;      // slots of rows i-1, i-2 and i-3 (the one row i overwrites)
+	s.dn[R3] = __builtin_amdgcn_perm(rcur, rcur, 0x08010801u);      // donor(i), acceptor(i): sign-extended bytes 1 and 3
+	s.ac[R3] = __builtin_amdgcn_perm(rcur, rcur, 0x09030903u);
+	const uint32_t gei = __builtin_amdgcn_perm(rcur, rcur, 0x0c020c02u);
+	const uint32_t H1 = s.H[R1], H2 = s.H[R2], H3 = s.H[R3], H1s = s.Hs[R1], H2s = s.Hs[R2], H3s = s.Hs[R3];
+	const uint32_t M = p_adds(H3s, S);
+	uint32_t u = p_subs(H3, go), tt;
+	dD = p_subs(u, s.D[R3]);                                          // direction bits: "old value wins" = sign of new - old
+	const uint32_t Dn = p_subs(p_max(u, s.D[R3]), gei);
+	s.D[R3] = Dn;
+	tt = p_subs(p_subs(H1, io), s.dn[R2]); dA = p_subs(tt, s.A);
+	s.A = p_max(tt, s.A); const uint32_t Av = p_subs(s.A, s.ac[R3]);
+	u = p_subs(H1s, io);
+	tt = p_subs(u, s.dn[R1]); dB = p_subs(tt, s.B);
+	s.B = p_max(tt, s.B); const uint32_t Bv = p_subs(s.B, s.ac[R2]);
+	tt = p_subs(u, s.dn[R3]); dC = p_subs(tt, s.C);
+	s.C = p_max(tt, s.C); const uint32_t Cv = p_subs(s.C, s.ac[R1]);
+	const uint32_t F6 = p_subs(H1, fs), F7 = p_subs(H2, fs), F8 = p_subs(H1s, fs), F9 = p_subs(H2s, fs);
+	return imax3(imax3(st_key(M, 0), st_key(Dn, 2), st_key(Av, 3)), imax3(st_key(Bv, 4), st_key(Cv, 5), st_key(F6, 6)),
+	             imax3(st_key(F7, 7), st_key(F8, 8), st_key(F9, 9)));
+}
 
 // MB: the matrix may span several 64-column blocks (block-major sweep).  EXT: score-only extension call swept with this
 // kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
@@ -1037,72 +1095,62 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		const int32_t cge = gc * ge, yoff = seg * SEG_BIG + cge;
 		const bool first_blk = !MB || blk == 0, last_blk = !MB || blk == nblk - 1;
 
-		int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
-		int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
-		if (first_blk && col == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
-		// donor/acceptor sliding windows
-		const uint32_t q0 = ring[0], q1 = ring[1];
-		int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
-		int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
-		uint32_t rcur = ring[2], rnext = ring[3];
+		GlobState gs;
+		glob_state_init(gs, ring[0], ring[1], first_blk && col == 0, fs);
+		const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs);
+		const char *profb = (const char*)myprof;                // + byte0(record) * G = this lane's score for the row's amino acid
+		uint32_t r[3];                                          // records of rows i, i+1 (and, once fetched, i+2) at slot row mod 3
+		r[2] = ring[2], r[0] = ring[3], r[1] = 0;
+		const bool carry_src = seg_start && gc >= slen;         // lanes that feed the carry scan
+		uint32_t keep_py = (uint32_t)NEG32, keep_h1 = (uint32_t)NEG16, keep_i1 = (uint32_t)NEG16, keep_hs = NEGP;   // !MB: see shift1_keep
+		int32_t hfin = NEG16;                                   // H of the last live row
 
 		const int32_t max_nl = wv.max_nl;                 // (a register copy: through the reference it is re-loaded, and waited for, every row)
-		for (int32_t i = 2; i < max_nl; ++i) {
+		auto row = [&](auto kc, const int32_t i) {
+			constexpr int K = decltype(kc)::value;
 			const bool rowlive = i < nl;
-			if ((i & 15) == 0) { if (loader) pf = rec[i + 16 + col]; }
-			else if ((i & 15) == 12) { if (loader) ring[((i + 4) & 31) + col] = pf; }
-			const uint32_t rnn = ring[(i + 2) & 31];                      // two rows ahead: LDS latency is off the critical path
-			const int32_t nas = (rcur & 0xff) >> 1, gei = (rcur >> 16) & 0xff;
-			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
-			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
-			const int32_t S = myprof[nas * G];
+			if ((i & 15) == 12) { if (loader) ring[((i + 4) & 31) + col] = pf, pf = rec[i + 20 + col]; }   // rows [i+4, i+20) published, the next 16 requested
+			r[(K + 2) % 3] = ring[(i + 2) & 31];                           // two rows ahead: LDS latency is off the critical path
+			const uint32_t rcur = r[K];
+			const char *sp = profb + (rcur & 0xff) * G;
+			const uint32_t S = prof2(sp, sp);
 			// boundary record of the block to the left
 			int4 bin = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
 			if (!first_blk && rowlive) bin = bnd[i];
 			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
 
-			int32_t w = 0, st = 0, h, tt, u;
 			// candidates other than I
-			const int32_t M = s_add(H3s, S);
-			u = s_sub(H3, go); const int32_t dD = u - D3;                   // direction bits: "old value wins" = sign of new - old
-			const int32_t Dn = s_sub(imax(u, D3), gei);
-			tt = s_sub(s_sub(H1, io), dm1); const int32_t dA = tt - A;
-			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
-			u = s_sub(H1s, io);
-			tt = s_sub(u, d0); const int32_t dB = tt - B;
-			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
-			tt = s_sub(u, dp1); const int32_t dC = tt - C;
-			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
-			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
-			const int32_t knon = imax3(imax3(st_key(M, 0), st_key(Dn, 2), st_key(Av, 3)), imax3(st_key(Bv, 4), st_key(Cv, 5), st_key(F6, 6)),
-			                            imax3(st_key(F7, 7), st_key(F8, 8), st_key(F9, 9)));
-			const int32_t nonI = knon >> 4;
+			uint32_t dD, dA, dB, dC;
+			const int32_t knon = glob_cands<K>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC);
+			const int32_t nonI = knon >> 16;
 			// first-pass I: the chain restarts at every lane start of the striped reference (segments of slen columns)
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
-			int32_t pex = shift1_i32<G>(py, NEG32, lane);
+			int32_t pex = MB ? shift1_i32<G>(py, NEG32, lane) : (int32_t)shift1_keep<G>(keep_py, (uint32_t)py, (uint32_t)NEG32, lane);
 			pex = imax(pex, bin.x);
 			const int32_t py_tot = imax(bin.x, __shfl(py, grp * G + G - 1));
 			const int32_t I1 = imax(pex - yoff - go, NEG16);
 			// ordered choice of the state, strict '>' keeps the earlier one (nasw-sse.c:451-519)
-			const int32_t kbest = imax(knon, st_key(I1, 1));
-			st = 15 - (kbest & 15);
-			const int32_t h1 = kbest >> 4;
+			const int32_t kbest = imax(knon, st_key((uint32_t)I1, 1));
+			const int32_t h1 = kbest >> 16;
 			// left neighbour's first-pass (h, I)
-			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
-			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
-			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
-			const int32_t dI = s_sub(hl, go) - il;
+			const int32_t hl_raw = MB ? shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane) : (int32_t)shift1_keep<G>(keep_h1, (uint32_t)h1, (uint32_t)NEG16, lane);
+			const int32_t il_raw = MB ? shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane) : (int32_t)shift1_keep<G>(keep_i1, (uint32_t)I1, (uint32_t)NEG16, lane);
+			// at a lane start of the striped reference both are -inf: (sat(-inf - go)) - (-inf) = 0
+			const int32_t dI = seg_start ? 0 : s_sub(hl_raw, go) - il_raw;
 			// carry of I across lane starts (the reference's lazy-F loop) as a second prefix max
 			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
-			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
+			const int32_t z = carry_src ? E + cge : NEG32;
 			int32_t pz = scan_max_i32<G>(z);
 			pz = imax(pz, bin.y);
 			const int32_t Gc = imax(pz - cge, NEG16);
-			h = imax(h1, Gc);
-			// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go
-			w = (int32_t)(push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), dI) << 4);
-			if (!EXT) { if (live && rowlive) tb[(int64_t)i * ncol + gc] = (uint16_t)(w | st); }
-			else {
+			const int32_t h = imax(h1, Gc);
+			if (!EXT) {
+				// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go; bits 3..0: the state
+				if (live && rowlive) {
+					const uint32_t w = push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), (uint32_t)dI);
+					tb[(int64_t)i * ncol + gc] = (uint16_t)((w << 4) | (uint32_t)(15 - (kbest & 15)));
+				}
+			} else {
 				// key of this block's row: best (H + end bonus) among the live columns, ties to the smallest column
 				const int32_t hb = h + (gc == t.al - 1 ? c.end_bonus : 0);
 				const uint32_t kk = reduce_max_u32(live ? ((uint32_t)(imax(hb, NEG16) + 32768) << 6) | (63u - (uint32_t)lane) : 0u);
@@ -1112,16 +1160,19 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			// boundary record for the block to the right
 			if (!last_blk && rowlive && col == G - 1 && tid >= 0)
 				bnd[i] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
-			if (!EXT && rowlive && i == nl - 1 && gc == t.al - 1 && tid >= 0) a.score[tid] = h;
-			// rotate
-			const int32_t hs = shift1_i32<G>(h, first_blk ? NEG16 : Hb, lane);
-			H3 = H2, H2 = H1, H1 = h;
-			H3s = H2s, H2s = H1s, H1s = hs;
-			D3 = D2, D2 = D1, D1 = Dn;
-			A = An, B = Bn, C = Cn;
-			if (i == 2 && first_blk && col == 0) H2s = NEG16, H3s = NEG16;
-			rcur = rnext, rnext = rnn;
+			if (!EXT) hfin = rowlive ? h : hfin;
+			// the new row into the slot of row i - 3
+			const uint32_t hsp = spl(h);
+			gs.H[K] = hsp;
+			gs.Hs[K] = MB ? shift1<G>(hsp, first_blk ? NEGP : splat16(Hb), lane) : shift1_keep<G>(keep_hs, hsp, NEGP, lane);
+			if (K == 2) { if (i == 2 && first_blk && col == 0) gs.Hs[0] = NEGP, gs.Hs[1] = NEGP; }
+		};
+		for (int32_t i = 2; i < max_nl; i += 3) {
+			row(std::integral_constant<int, 2>(), i);
+			if (i + 1 < max_nl) row(std::integral_constant<int, 0>(), i + 1);
+			if (i + 2 < max_nl) row(std::integral_constant<int, 1>(), i + 2);
 		}
+		if (!EXT && tid >= 0 && nl >= 3 && gc == t.al - 1) a.score[tid] = hfin;
 	}
 	if (!EXT && tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
 }
@@ -1248,16 +1299,16 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 	const int32_t cge = gc * ge, yoff = seg * SEG_BIG + cge;
 	const bool first_blk = w == 0;
 
-	int32_t H1 = NEG16, H2 = NEG16, H3 = NEG16, D1 = NEG16, D2 = NEG16, D3 = NEG16, A = NEG16, B = NEG16, C = NEG16;
-	int32_t H1s = NEG16, H2s = NEG16, H3s = NEG16;
-	if (first_blk && lane == 0) H3s = 0, H2s = (int16_t)-fs, H1s = (int16_t)-fs;
-	const uint32_t q0 = ring[0], q1 = ring[1];
-	int32_t dm1, d0 = (int8_t)(q0 >> 8), dp1 = (int8_t)(q1 >> 8);
-	int32_t am2, am1 = (int8_t)(q0 >> 24), a0 = (int8_t)(q1 >> 24);
+	GlobState gs;
+	glob_state_init(gs, ring[0], ring[1], first_blk && lane == 0, fs);
+	const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs);
+	const char *profb = (const char*)myprof;
 	uint32_t rcur = ring[2];
+	const bool carry_src = seg_start && gc >= slen;              // lanes that feed the carry scan
 
 	for (int k = 0; k < w; ++k) lds_barrier();                   // skew: wave w runs w rows behind wave 0
-	for (int32_t i = 2; i < nl; ++i) {
+	auto row = [&](auto kc, const int32_t i) {
+		constexpr int K = decltype(kc)::value;
 		const int32_t par = (i + w) & 1;
 		{
 			if (w == 0) {
@@ -1265,62 +1316,51 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 				else if ((i & 15) == 12) { if (loader) ring[((i + 20) & 63) + lane] = pf; }
 			}
 			const uint32_t rnext = ring[(i + 1) & 63];
-			const int32_t nas = (rcur & 0xff) >> 1, gei = (rcur >> 16) & 0xff;
-			dm1 = d0, d0 = dp1, dp1 = (int8_t)(rcur >> 8);
-			am2 = am1, am1 = a0, a0 = (int8_t)(rcur >> 24);
-			const int32_t S = myprof[nas * G];
+			const char *sp = profb + (rcur & 0xff) * G;
+			const uint32_t S = prof2(sp, sp);
 			int4 bin = make_int4(NEG32, NEG32, (int)NEGP, NEG16);
 			if (!first_blk) bin = xB[(par ^ 1) * NW + w - 1];
 			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
-			int32_t wd = 0, st = 0, h, tt, u;
-			const int32_t M = s_add(H3s, S);
-			u = s_sub(H3, go); const int32_t dD = u - D3;                   // direction bits: "old value wins" = sign of new - old
-			const int32_t Dn = s_sub(imax(u, D3), gei);
-			tt = s_sub(s_sub(H1, io), dm1); const int32_t dA = tt - A;
-			const int32_t An = imax(tt, A), Av = s_sub(An, a0);
-			u = s_sub(H1s, io);
-			tt = s_sub(u, d0); const int32_t dB = tt - B;
-			const int32_t Bn = imax(tt, B), Bv = s_sub(Bn, am2);
-			tt = s_sub(u, dp1); const int32_t dC = tt - C;
-			const int32_t Cn = imax(tt, C), Cv = s_sub(Cn, am1);
-			const int32_t F6 = s_sub(H1, fs), F7 = s_sub(H2, fs), F8 = s_sub(H1s, fs), F9 = s_sub(H2s, fs);
-			const int32_t knon = imax3(imax3(st_key(M, 0), st_key(Dn, 2), st_key(Av, 3)), imax3(st_key(Bv, 4), st_key(Cv, 5), st_key(F6, 6)),
-			                            imax3(st_key(F7, 7), st_key(F8, 8), st_key(F9, 9)));
-			const int32_t nonI = knon >> 4;
+			uint32_t dD, dA, dB, dC;
+			const int32_t knon = glob_cands<K>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC);
+			const int32_t nonI = knon >> 16;
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
 			int32_t pex = shift1_i32<G>(py, NEG32, lane);
 			pex = imax(pex, bin.x);
 			const int32_t py_tot = imax(bin.x, __shfl(py, 63));
 			const int32_t I1 = imax(pex - yoff - go, NEG16);
-			const int32_t kbest = imax(knon, st_key(I1, 1));
-			st = 15 - (kbest & 15);
-			const int32_t h1 = kbest >> 4;
+			const int32_t kbest = imax(knon, st_key((uint32_t)I1, 1));
+			const int32_t h1 = kbest >> 16;
 			const int32_t hl_raw = shift1_i32<G>(h1, first_blk ? NEG16 : h1b, lane);
 			const int32_t il_raw = shift1_i32<G>(I1, first_blk ? NEG16 : I1b, lane);
-			const int32_t hl = seg_start ? NEG16 : hl_raw, il = seg_start ? NEG16 : il_raw;
-			const int32_t dI = s_sub(hl, go) - il;
+			const int32_t dI = seg_start ? 0 : s_sub(hl_raw, go) - il_raw;   // (at a lane start both are -inf: the difference is 0)
 			const int32_t E = imax(s_sub(hl_raw, goe), s_sub(il_raw, ge));
-			const int32_t z = (seg_start && gc >= slen) ? E + cge : NEG32;
+			const int32_t z = carry_src ? E + cge : NEG32;
 			int32_t pz = scan_max_i32<G>(z);
 			pz = imax(pz, bin.y);
 			const int32_t Gc = imax(pz - cge, NEG16);
-			h = imax(h1, Gc);
-			// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go
-			wd = (int32_t)(push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), dI) << 4);
-			if (live) tb[(int64_t)i * ncol + gc] = (uint16_t)(wd | st);
+			const int32_t h = imax(h1, Gc);
+			// bits 9..4 of the direction word: Gc > h1 | C | B | A | D | il > hl - go; bits 3..0: the state
+			if (live) {
+				const uint32_t wd = push_neg(push_neg(push_neg(push_neg(push_neg((uint32_t)(h1 - Gc) >> 31, dC), dB), dA), dD), (uint32_t)dI);
+				tb[(int64_t)i * ncol + gc] = (uint16_t)((wd << 4) | (uint32_t)(15 - (kbest & 15)));
+			}
 			if (lane == 63) xB[par * NW + w] = make_int4(py_tot, pz, (int)pack16(h, h1), I1);
-			if (i == nl - 1 && gc == t.al - 1) a.score[tid] = h;
-			const int32_t hs = shift1_i32<G>(h, first_blk ? NEG16 : Hb, lane);
-			H3 = H2, H2 = H1, H1 = h;
-			H3s = H2s, H2s = H1s, H1s = hs;
-			D3 = D2, D2 = D1, D1 = Dn;
-			A = An, B = Bn, C = Cn;
-			if (i == 2 && first_blk && lane == 0) H2s = NEG16, H3s = NEG16;
+			const uint32_t hsp = spl(h);
+			gs.H[K] = hsp;
+			gs.Hs[K] = shift1<G>(hsp, first_blk ? NEGP : splat16(Hb), lane);
+			if (K == 2) { if (i == 2 && first_blk && lane == 0) gs.Hs[0] = NEGP, gs.Hs[1] = NEGP; }
 			rcur = rnext;
 		}
 		lds_barrier();
+	};
+	for (int32_t i = 2; i < nl; i += 3) {
+		row(std::integral_constant<int, 2>(), i);
+		if (i + 1 < nl) row(std::integral_constant<int, 0>(), i + 1);
+		if (i + 2 < nl) row(std::integral_constant<int, 1>(), i + 2);
 	}
 	for (int k = w; k < NW - 1; ++k) lds_barrier();
+	if (nl >= 3 && gc == t.al - 1) { const int k = (nl - 1) % 3; a.score[tid] = lo16(k == 0 ? gs.H[0] : k == 1 ? gs.H[1] : gs.H[2]); }
 	if (nl < 3 && wp.tg == 0) a.score[tid] = NEG16;
 }
 

@@ -1560,6 +1560,10 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	const int n_seed_ctx = n_plan + n_seed + seed_extra;
 	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
 	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
+	// the contexts of a stage take turns on the batches: what one of them had to allocate in an earlier stream the others get
+	// now, while nothing is in flight (see ctx_pools_equalize)
+	static const bool equalize = [] { const char *e = getenv("MPA_POOL_EQUALIZE"); return !e || atoi(e) != 0; }();
+	if (equalize) ctx_pools_equalize(lane_ctx.data(), n_lanes), ctx_pools_equalize(seed_ctx.data(), n_seed_ctx);
 	static const char *const kSeedName[4] = { "seed0", "seed1", "seed2", "seed3" };
 	static const char *const kPlanName[6] = { "plan0", "plan1", "plan2", "plan3", "plan4", "plan5" };
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };

@@ -94,6 +94,50 @@ def test_extension_wider_than_1024_columns(ctx, oracle_built):
     run_case(ctx, [make_task(rng, al=1300, p_indel=0.01, flank=2000) for _ in range(3)], P2, rng)
 
 
+def test_split_extension_calls_retry_and_load(oracle_built):
+    """257..1024-column extension calls are swept by 2 / 4 workgroups with a hand-off through HBM (k_ext_wide_split).
+    (a) A hand-off that times out makes mpa_dp_run() repeat the round with those calls on the one-wave path: forced here
+    (MPA_TEST_HANDOFF_FAIL is read once per process, so the forced failure runs in a child), results must not change.
+    (b) Four contexts sweeping such calls at the same time from four host threads (oversubscribed queues) agree with the oracle."""
+    import os, subprocess, sys, threading
+    code = ("import numpy as np, sys; sys.path.insert(0, 'tests'); import conftest, miniprot_amd as mpa, refbind\n"
+            "from dpgen import make_task; from dputil import build_workload, oracle_eval, dpopt_from_params, compare\n"
+            "rng = np.random.default_rng(21); P = refbind.DpParams(refbind.mapping_matrix(23))\n"
+            "pairs = [make_task(rng, al=al, p_indel=0.002, flank=600) for al in (300, 513, 700, 1000, 1024, 40, 90)]\n"
+            "contigs, queries, tasks, meta = build_workload(pairs, rng, modes=('left', 'right'), io=P.io)\n"
+            "ctx = mpa.Context(0); idx = mpa.Index.from_nt4(contigs); idx.to_device(ctx)\n"
+            "rst, cig = mpa.dp_run(ctx, idx, dpopt_from_params(P), queries, tasks)\n"
+            "bad, msg = compare(rst, cig, oracle_eval(pairs, meta, P), meta, pairs)\n"
+            "assert not bad, msg\n"
+            "print('retries', ctx.handoff_retries())\n")
+    env = dict(os.environ, MPA_TEST_HANDOFF_FAIL="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "retries 1" in out.stdout, out.stdout + out.stderr
+    # (b)
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    errs = []
+
+    def worker(seed):
+        try:
+            c = mpa.Context(0)
+            rng = np.random.default_rng(seed)
+            pairs = [make_task(rng, al=int(rng.choice([513, 600, 800, 1000, 1024])), p_indel=0.002, flank=int(rng.choice([200, 3000]))) for _ in range(10)]
+            pairs += [make_task(rng) for _ in range(60)]
+            for _ in range(2):
+                run_case(c, pairs, P, rng, modes=("left", "right"))
+            assert c.handoff_retries() == 0
+            c.close()
+        except BaseException as e:                                   # noqa: BLE001 (reported in the main thread)
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(100 + k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
 def test_extension_that_saturates_int16(ctx, oracle_built):
     """scores beyond 32767: the reference's int16 arithmetic saturates; k_ext_huge clamps every operation the same way"""
     rng = np.random.default_rng(17)
