@@ -180,6 +180,13 @@ typedef struct {
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
 /* sums over every mpa_dp_run() of this context since the last reset */
 void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset);
+/* The same batch interface for the 32-bit operator, ns_global_gs32b (nasw.h:131-132, nasw-sse.c:558-750): global score of
+ * every call and, for calls with MPA_F_CIGAR and no extension flag, its CIGAR; extension flags only select the reversed
+ * preparation (ns_prep_seq_left), lengths come back as given -- the 32-bit operator has no extension mode (nasw.h:112-114).
+ * Which behaviour of the reference this reproduces (its default x86 build of that function is broken): gs32_core.h. */
+int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, const mpa_qbatch_t *q,
+                 int64_t n, const mpa_dp_task_t *tasks, mpa_dp_rst_t *rst, uint32_t **cigar_pool, int64_t *n_pool);
+
 /* Extension calls of 257..1024 columns are swept by two or four workgroups that hand column-block boundaries to each other
  * through HBM.  Should a hand-off not arrive within seconds (a stalled hardware queue), mpa_dp_run() repeats the round with
  * those calls on the one-wave path -- same results, no error.  How often that happened on this context: */
@@ -283,6 +290,10 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
  * anchors; from the host stages (ctx == NULL) or from the device, which then runs both chaining rounds (k_chain_extract,
  * k_chain_fwd).  off_u / off_a [n_seq + 1], *out_u / *out_a (mpa_free).  Returns how many queries the device handed back to the
  * host, or a negative error code. */
+/* Test model of the 32-bit sweep: the host instance of the source k_gs32 is compiled from (gs32_core.h), one call, inputs as
+ * the device kernel gets them (per-row records, int16 profile [22][pw]); fills tb[nl][ncol] when not NULL, returns the score. */
+int32_t mpa_dbg_gs32_model(int32_t nl, int32_t al, const uint32_t *rec, const int16_t *prof, int32_t pw, int32_t go, int32_t ge, int32_t io, int32_t fs,
+                           uint16_t *tb, int32_t ncol);
 int64_t mpa_dbg_main_chains(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off_u, uint64_t **out_u,
                             int64_t *off_a, uint64_t **out_a);
 

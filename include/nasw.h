@@ -77,6 +77,11 @@ void ns_set_stop_sc(int32_t asize, int8_t *mat, int8_t score);
 /* ns: ASCII or 0..4 codes; as: ASCII.  ss: optional splice-score bytes, one per nucleotide (0xff = none). */
 void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r);
 void ns_global_gs16(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, ns_rst_t *r);
+/* the 32-bit operator (nasw.h:129,132): global score and CIGAR without int16 saturation; no extension mode, no end bonus
+ * (nasw.h:112-114).  One wavefront per call on the GPU (miniprot_amd/csrc/gs32_core.h says which build of the reference's
+ * function it reproduces bit for bit). */
+void ns_global_gs32(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, ns_rst_t *r);
+void ns_global_gs32b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r);
 
 /* append one operation to a malloc'd CIGAR (frameshift operators are never merged) */
 static inline uint32_t *ns_push_cigar(void *km, int32_t *n_cigar, int32_t *m_cigar, uint32_t *cigar, uint32_t op, int32_t len)

@@ -434,14 +434,17 @@ def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_tex
     return (out, results) if keep_results else out
 
 
-def dp_run(ctx, idx, dpopt, queries, tasks):
-    """Run a batch of DP calls on the GPU.  tasks: numpy array of DP_TASK.  Returns (results, cigar_pool)."""
+def dp_run(ctx, idx, dpopt, queries, tasks, wide32=False):
+    """Run a batch of DP calls on the GPU.  tasks: numpy array of DP_TASK.  Returns (results, cigar_pool).
+    wide32: the 32-bit operator (mpa_dp_run32 = ns_global_gs32b per call) instead of the int16 one."""
     tasks = np.ascontiguousarray(tasks, dtype=DP_TASK)
     rst = np.zeros(len(tasks), dtype=DP_RST)
     pool = C.POINTER(C.c_uint32)()
     n_pool = C.c_int64(0)
-    _check(lib().mpa_dp_run(ctx.h, idx.h, C.byref(dpopt), C.byref(queries.c), len(tasks), tasks.ctypes.data,
-                            rst.ctypes.data, C.byref(pool), C.byref(n_pool)))
+    fn = lib().mpa_dp_run32 if wide32 else lib().mpa_dp_run
+    fn.argtypes = lib().mpa_dp_run.argtypes
+    _check(fn(ctx.h, idx.h, C.byref(dpopt), C.byref(queries.c), len(tasks), tasks.ctypes.data,
+              rst.ctypes.data, C.byref(pool), C.byref(n_pool)))
     cig = np.ctypeslib.as_array(pool, (max(n_pool.value, 1),))[:n_pool.value].copy() if n_pool.value else np.zeros(0, np.uint32)
     lib().mpa_free(pool)
     return rst, cig

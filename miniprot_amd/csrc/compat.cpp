@@ -399,16 +399,26 @@ int32_t mp_map_file(const mp_idx_t *idx, const char *fn, const mp_mapopt_t *opt,
 	return 0;
 }
 
-// ---- ns_global_gs16b: one call of the batched operator ------------------------------------------------------
-void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r)
+// ---- ns_global_gs16b / ns_global_gs32b: one call of the batched operator (mpa_dp_run / mpa_dp_run32) ---------------
+} // extern "C"
+static void global_one(const bool wide32, const char *who, void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r)
 {
 	r->n_cigar = 0, r->nt_len = nl, r->aa_len = al, r->score = INT32_MIN;   // (NS_GEN_PREPARE sets the lengths before its early return, nasw-sse.c:236)
+	if (wide32 && nl == 0 && al > 0) {
+		// the 32-bit function has no early return: with no rows it reports its initial H (-2^30) and ns_backtrack's tail (nasw-sse.c:77)
+		r->score = -0x40000000;
+		if ((opt->flag & NS_F_CIGAR) && !(opt->flag & (NS_F_EXT_LEFT | NS_F_EXT_RIGHT)) && al > 1) {
+			if (r->m_cigar < 1 || !r->cigar) r->m_cigar = 1, r->cigar = (uint32_t*)(km && kmalloc ? kmalloc(km, sizeof(uint32_t)) : realloc(r->cigar, sizeof(uint32_t)));
+			r->cigar[0] = (uint32_t)(al - 1) << 4 | 1, r->n_cigar = 1;
+		}
+		return;
+	}
 	if (nl <= 0 || al <= 0) return;
 	if (opt->asize != 22 || (opt->nt4 && opt->nt4 != ns_tab_nt4) || (opt->aa20 && opt->aa20 != ns_tab_aa20) || (opt->codon && opt->codon != ns_tab_codon)) {
 		set_error("ns_opt_t must use the library's own tables (ns_tab_nt4 / ns_tab_aa20 / ns_tab_codon) and asize 22");
-		die("ns_global_gs16b");
+		die(who);
 	}
-	if (km && !kmalloc) { set_error("a kalloc arena was passed but the program provides no kmalloc(); pass km = NULL"); die("ns_global_gs16b"); }
+	if (km && !kmalloc) { set_error("a kalloc arena was passed but the program provides no kmalloc(); pass km = NULL"); die(who); }
 	// the caller's nucleotides as a one-contig genome (ASCII or 0..4 codes: the table maps both, nasw-tab.c:93-95)
 	std::vector<uint8_t> nt4((size_t)nl);
 	for (int32_t i = 0; i < nl; ++i) nt4[i] = ns_tab_nt4[(uint8_t)ns[i]];
@@ -430,6 +440,7 @@ void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32
 	memset(&t, 0, sizeof(t));
 	t.nt_off = 0, t.vid = 0, t.nl = nl, t.qid = 0, t.aa_off = 0, t.al = al, t.io = opt->io;
 	t.flag = is_ext ? (opt->flag & (NS_F_EXT_LEFT | NS_F_EXT_RIGHT)) : MPA_F_CIGAR;   // the global sweep always keeps its traceback
+	if (wide32 && !is_ext && !(opt->flag & NS_F_CIGAR)) t.flag = 0;                    // (the 32-bit sweep has a score-only mode: no traceback matrix)
 	const int64_t q_off[2] = { 0, al };
 	const mpa_qbatch_t q{ 1, as, q_off };
 	mpa_dp_rst_t out;
@@ -438,9 +449,9 @@ void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32
 	{
 		std::lock_guard<std::mutex> g(g_mu);
 		mpa_ctx_t *ctx = shared_ctx();
-		if (mpa_idx_to_device(ctx, mi) != MPA_OK || mpa_dp_run(ctx, mi, &dp, &q, 1, &t, &out, &pool, &n_pool) != MPA_OK) {
+		if (mpa_idx_to_device(ctx, mi) != MPA_OK || (wide32 ? mpa_dp_run32(ctx, mi, &dp, &q, 1, &t, &out, &pool, &n_pool) : mpa_dp_run(ctx, mi, &dp, &q, 1, &t, &out, &pool, &n_pool)) != MPA_OK) {
 			mpa_idx_destroy(mi);
-			die("ns_global_gs16b");
+			die(who);
 		}
 	}
 	mpa_idx_destroy(mi);
@@ -454,6 +465,24 @@ void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32
 		r->n_cigar = out.n_cigar;
 	}
 	mpa_free(pool);
+}
+
+extern "C" {
+void ns_global_gs16b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r)
+{
+	global_one(false, "ns_global_gs16b", km, ns, nl, as, al, opt, ss, r);
+}
+
+// nasw.h:129,132 (nasw-sse.c:558-750): the 32-bit operator -- no extension mode, no end bonus (nasw.h:112-114); what exactly
+// is reproduced (the reference's default x86 build of it is broken) is stated in gs32_core.h
+void ns_global_gs32b(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, const uint8_t *ss, ns_rst_t *r)
+{
+	global_one(true, "ns_global_gs32b", km, ns, nl, as, al, opt, ss, r);
+}
+
+void ns_global_gs32(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, ns_rst_t *r)
+{
+	global_one(true, "ns_global_gs32b", km, ns, nl, as, al, opt, nullptr, r);
 }
 
 void ns_global_gs16(void *km, const char *ns, int32_t nl, const char *as, int32_t al, const ns_opt_t *opt, ns_rst_t *r)

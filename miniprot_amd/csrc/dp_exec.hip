@@ -40,19 +40,14 @@ struct DevBuf {
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
-		size_t want = bytes + bytes / 3 + 4096;
+		// (tl_pool_scale: the stage thread is working on one of that many parts of a mini-batch -- the pool is sized for the whole
+		// batches the same context will meet later in the stream)
+		size_t want = bytes * (size_t)std::max(1, tl_pool_scale);
+		want += want / 3 + 4096;
 		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess && tl_pool_scale > 1) { (void)hipGetLastError(); want = bytes + bytes / 3 + 4096; e = hipMalloc(&p, want); }
 		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
-		return MPA_OK;
-	}
-	// exactly `bytes` (no slack) unless already that large: ctx_pools_equalize
-	int grow_to(size_t bytes) {
-		if (bytes <= cap) return MPA_OK;
-		if (p) (void)hipFree(p);
-		p = nullptr, cap = 0;
-		if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return MPA_ERR_HIP; }
-		cap = bytes;
 		return MPA_OK;
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }
@@ -74,17 +69,9 @@ struct HostPinned {
 		if (bytes <= cap) return MPA_OK;
 		if (p) (void)hipHostFree(p);
 		p = nullptr, cap = 0;
-		const size_t want = bytes + bytes / 2 + 4096;           // (re-pinning host memory is slow: grow in big steps)
+		const size_t want = bytes * (size_t)std::max(1, tl_pool_scale) * 3 / 2 + 4096;   // (re-pinning host memory is slow: grow in big steps)
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return MPA_ERR_HIP; }
 		cap = want;
-		return MPA_OK;
-	}
-	int grow_to(size_t bytes) {
-		if (bytes <= cap) return MPA_OK;
-		if (p) (void)hipHostFree(p);
-		p = nullptr, cap = 0;
-		if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return MPA_ERR_HIP; }
-		cap = bytes;
 		return MPA_OK;
 	}
 	void release() { if (p) (void)hipHostFree(p); p = nullptr, cap = 0; }
@@ -394,39 +381,6 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 }
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off) { ctx->side_off = off; }
 
-// Every grow-only pool of a context, in a fixed order (the same pool of two contexts has the same position).
-template<class FD, class FH> static void for_each_pool(mpa_ctx_s *c, FD fd, FH fh)
-{
-	SeedBufs &z = c->seed;
-	DevBuf *dev[] = { &c->tasks, &c->waves, &c->chunks, &c->qseq, &c->rec, &c->prof, &c->tb, &c->cig, &c->ncig, &c->score, &c->extout, &c->bnd, &c->list,
-	                  &c->rowkey, &c->cigd, &c->cigoff, &c->hkey, &c->xg, &c->units,
-	                  &z.jobs, &z.key[0], &z.key[1], &z.val[0], &z.val[1], &z.f, &z.pred, &z.mark, &z.flag, &z.idx, &z.tmp, &z.qfirst, &z.cfirst, &z.o_pos, &z.o_f,
-	                  &z.o_pred, &z.o_a, &z.r_win, &z.r_chunk, &z.r_qfirst, &z.r_words, &z.r_hits, &z.r_count, &z.pf_w, &z.pf_dst, &z.pf_rem, &z.pf_jfirst,
-	                  &z.pf_qfirst2, &z.pf_err, &z.val64[0], &z.val64[1], &z.s_meta, &z.s_cur, &z.s_cur2, &z.s_kept, &z.s_base, &z.s_out, &z.s_flag, &z.dkey,
-	                  &z.x_all, &z.rx_all, &z.rx_keys, &z.c_a, &z.c_f, &z.c_pred, &z.c_mark, &z.c_flag, &z.c_first, &z.c_long };
-	HostPinned *host[] = { &c->h_up, &c->h_down, &c->h_pool, &z.h_jobs, &z.h_pos, &z.h_f, &z.h_pred, &z.h_a, &z.h_rhits, &z.h_meta, &z.h_back, &z.h_U, &z.h_A,
-	                       &z.h_xoff, &z.hc_a, &z.hc_f, &z.hc_pred };
-	int k = 0;
-	for (DevBuf *b : dev) fd(b, k++);
-	k = 0;
-	for (HostPinned *b : host) fh(b, k++);
-}
-// The contexts of one pipeline stage (the DP lanes; the seeding/planning contexts) take turns on the batches of a stream, so
-// what one of them needed the others will need: bring every pool of every context up to the largest of its kind in the group.
-// Called between streams, when nothing of the caller's is in flight -- a pool that grows while kernels run costs a hipFree,
-// which waits for the whole device (a context that met only the short edge batches of one stream would otherwise re-grow
-// everything in the middle of the next).  A failed allocation is not an error here: the pool grows on demand later.
-void ctx_pools_equalize(mpa_ctx_t *const *list, int n)
-{
-	if (n < 2) return;
-	std::vector<size_t> hw_dev, hw_host;
-	for (int i = 0; i < n; ++i)
-		for_each_pool(list[i], [&](DevBuf *b, int k) { if ((int)hw_dev.size() <= k) hw_dev.resize(k + 1, 0); hw_dev[k] = std::max(hw_dev[k], b->cap); },
-		              [&](HostPinned *b, int k) { if ((int)hw_host.size() <= k) hw_host.resize(k + 1, 0); hw_host[k] = std::max(hw_host[k], b->cap); });
-	(void)hipSetDevice(list[0]->device);
-	for (int i = 0; i < n; ++i)
-		for_each_pool(list[i], [&](DevBuf *b, int k) { (void)b->grow_to(hw_dev[k]); }, [&](HostPinned *b, int k) { (void)b->grow_to(hw_host[k]); });
-}
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
 	for (mpa_ctx_s *sb : ctx->siblings) {
@@ -1976,3 +1930,5 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx) { return ctx ? ctx->handoff_retries : 0; }
 
 } // extern "C"
+
+#include "gs32_exec.hip"

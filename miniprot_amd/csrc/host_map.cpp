@@ -1560,10 +1560,6 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	const int n_seed_ctx = n_plan + n_seed + seed_extra;
 	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
 	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
-	// the contexts of a stage take turns on the batches: what one of them had to allocate in an earlier stream the others get
-	// now, while nothing is in flight (see ctx_pools_equalize)
-	static const bool equalize = [] { const char *e = getenv("MPA_POOL_EQUALIZE"); return !e || atoi(e) != 0; }();
-	if (equalize) ctx_pools_equalize(lane_ctx.data(), n_lanes), ctx_pools_equalize(seed_ctx.data(), n_seed_ctx);
 	static const char *const kSeedName[4] = { "seed0", "seed1", "seed2", "seed3" };
 	static const char *const kPlanName[6] = { "plan0", "plan1", "plan2", "plan3", "plan4", "plan5" };
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
@@ -1603,7 +1599,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK) return;
 			}
 			trace(kSeedName[sd], k, "begin");
-			tl_unit_parts = slot[k].n_parts;
+			tl_unit_parts = tl_pool_scale = slot[k].n_parts;
 			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &slot[k].q, n_threads);
 			trace(kSeedName[sd], k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
@@ -1628,7 +1624,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK || k >= n_total) return;       // (k >= n_total: the job ran out before this slot was claimed)
 			}
 			trace(kPlanName[pl], k, "begin");
-			tl_unit_parts = slot[k].n_parts;
+			tl_unit_parts = tl_pool_scale = slot[k].n_parts;
 			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
 			trace(kPlanName[pl], k, "end");
 			std::lock_guard<std::mutex> g(mu);
@@ -1696,6 +1692,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			}
 			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
 			trace(lane_name[d], k, "begin");
+			tl_pool_scale = slot[k].n_parts;
 			const int rc = run_dp_rounds(cd, mi, &slot[k].q, slot[k].b);
 			trace(lane_name[d], k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }

@@ -298,6 +298,15 @@ struct CoopWave {
 		*total = __shfl(inc, 63);
 		return inc - v;
 	}
+	static __device__ __forceinline__ int64_t scan_max_excl(int64_t v, int64_t *total)
+	{
+		int64_t inc = v;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const int64_t w = __shfl_up(inc, o); if (lane() >= o && w > inc) inc = w; }
+		*total = __shfl(inc, 63);
+		const int64_t below = __shfl_up(inc, 1);
+		return lane() ? below : INT64_MIN;
+	}
 	static __device__ __forceinline__ void digit_rank(int d, bool have, int *rank, int *cnt)
 	{
 		unsigned long long eq = __ballot(have);                  // lanes that take part and hold the same 8-bit digit: eight ballots

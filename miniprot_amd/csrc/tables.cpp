@@ -15,6 +15,8 @@
 #include "mpa_internal.h"
 
 namespace mpa {
+thread_local int tl_pool_scale = 1;
+
 
 const char *const kAA = "ARNDCQEGHILKMFPSTWYV*X";
 

@@ -394,3 +394,30 @@ void mpo_nasw(const uint8_t *nt, int32_t nl, const uint8_t *aa, int32_t al, cons
 	if (tb) { walk_back(tb, nl, al, ncol, r); free(tb); }
 	free(buf); free(prof); free(p.nas); free(p.aas); free(p.donor); free(p.acceptor);
 }
+
+/* ---- pieces of the above on their own, for the tests of the 32-bit sweep (tests/test_gs32_model.py) -------------------------
+ * mpo_prep_rec: the per-row inputs of one call packed the way the device's prep kernel hands them to the DP kernels (dp_device.h):
+ * byte0 2*nas[i], byte1 donor[i+1], byte2 ge -- or fs on a stop codon --, byte3 acceptor[i]; aas_out[al] = the aa20 codes of
+ * the protein in column order (reversed for a left extension). */
+void mpo_prep_rec(const uint8_t *nt, int32_t nl, const uint8_t *aa, int32_t al, const mpo_nasw_opt_t *o, const uint8_t *ss, uint32_t *rec, uint8_t *aas_out)
+{
+	const uint8_t *codon_tab = o->codon ? o->codon : mpo_codon_std();
+	prep_t p;
+	int32_t i;
+	p.nl = nl, p.al = al, p.slen = (al + 7) / 8, p.ncol = p.slen * 8;
+	p.nas = (uint8_t*)malloc(nl + 1); p.aas = (uint8_t*)malloc(al + 1);
+	p.donor = (int8_t*)malloc(nl + 2); p.acceptor = (int8_t*)malloc(nl + 2);
+	if (o->flag & MPO_F_EXT_LEFT) prep_reverse(&p, nt, aa, o, ss, codon_tab);
+	else prep_forward(&p, nt, aa, o, ss, codon_tab);
+	for (i = 0; i < nl; ++i)
+		rec[i] = (uint32_t)(p.nas[i] * 2) | (uint32_t)(uint8_t)p.donor[i + 1] << 8 | (uint32_t)((p.nas[i] == 20 ? o->fs : o->ge) & 0xff) << 16 | (uint32_t)(uint8_t)p.acceptor[i] << 24;
+	memcpy(aas_out, p.aas, al);
+	free(p.nas); free(p.aas); free(p.donor); free(p.acceptor);
+}
+
+/* ns_backtrack (nasw-sse.c:40-89) over a [nl][ncol] matrix of traceback words */
+void mpo_walk_back(const uint16_t *tb, int32_t nl, int32_t al, int32_t ncol, mpo_nasw_rst_t *r)
+{
+	r->n_cigar = 0, r->m_cigar = 0, r->cigar = 0;
+	walk_back(tb, nl, al, ncol, r);
+}

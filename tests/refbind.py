@@ -25,6 +25,25 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+REF41_SO = os.path.join(ORACLE_DIR, "_ref", "libnasw_sse41.so")   # the DP operator built with -msse4.1 (oracle/Makefile says why)
+_ref41 = None
+
+
+def have_ref41():
+    return os.path.exists(REF41_SO)
+
+
+def ref41():
+    global _ref41
+    if _ref41 is None:
+        _ref41 = C.CDLL(REF41_SO)
+        _ref41.ns_make_tables(1)
+        for fn in ("ns_global_gs16b", "ns_global_gs32b"):
+            getattr(_ref41, fn).argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(NsOpt), C.c_void_p, C.POINTER(NsRst)]
+            getattr(_ref41, fn).restype = None
+    return _ref41
+
+
 # ---------------------------------------------------------------- reference structs (nasw.h:62-80)
 class NsOpt(C.Structure):
     _fields_ = [("flag", C.c_int32), ("go", C.c_int32), ("ge", C.c_int32), ("io", C.c_int32), ("fs", C.c_int32),
@@ -149,6 +168,63 @@ def ref_nasw(nt, aa, P, flag, ss=None):
     if rst.n_cigar or rst.cigar:
         _libc.free(rst.cigar)
     return rst.nt_len, rst.aa_len, rst.score, cig
+
+
+def _ns_opt(lib, P, flag):
+    o = NsOpt()
+    o.flag, o.go, o.ge, o.io, o.fs, o.xdrop, o.end_bonus, o.asize = flag, P.go, P.ge, P.io, P.fs, P.xdrop, P.end_bonus, 22
+    for i in range(6):
+        o.sp[i] = P.sp[i]
+    o.sp_null_bonus, o.ie_coef = P.sp_null_bonus, P.ie_coef
+    o.sc = P.mat.ctypes.data
+    o.nt4 = C.addressof((C.c_uint8 * 256).in_dll(lib, "ns_tab_nt4"))
+    o.aa20 = C.addressof((C.c_uint8 * 256).in_dll(lib, "ns_tab_aa20"))
+    o.codon = C.addressof((C.c_uint8 * 64).in_dll(lib, "ns_tab_codon"))
+    return o
+
+
+def ref_gs32(nt, aa, P, flag, ss=None, fn="ns_global_gs32b", lib=None):
+    """The reference's 32-bit operator in its -msse4.1 build (or `fn` of `lib`).  Returns (nt_len, aa_len, score, cigar list)."""
+    r = lib or ref41()
+    o = _ns_opt(r, P, flag)
+    rst = NsRst()
+    ssp = None if ss is None else C.cast(C.c_char_p(bytes(ss)), C.c_void_p)
+    getattr(r, fn)(None, bytes(nt), len(nt), bytes(aa), len(aa), C.byref(o), ssp, C.byref(rst))
+    cig = [rst.cigar[i] for i in range(rst.n_cigar)]
+    if rst.n_cigar or rst.cigar:
+        _libc.free(rst.cigar)
+    return rst.nt_len, rst.aa_len, rst.score, cig
+
+
+def _mpo_opt(P, flag):
+    o = MpoOpt()
+    o.flag, o.go, o.ge, o.io, o.fs, o.xdrop, o.end_bonus = flag, P.go, P.ge, P.io, P.fs, P.xdrop, P.end_bonus
+    for i in range(6):
+        o.sp[i] = P.sp[i]
+    o.sp_null_bonus, o.ie_coef = P.sp_null_bonus, P.ie_coef
+    o.mat = P.mat.ctypes.data
+    o.codon = None
+    return o
+
+
+def ora_prep_rec(nt, aa, P, flag, ss=None):
+    """Per-row records of one call as the device's prep kernel packs them (dp_device.h) + the aa20 codes in column order."""
+    rec = np.zeros(max(len(nt), 1), dtype=np.uint32)
+    aas = np.zeros(max(len(aa), 1), dtype=np.uint8)
+    o = _mpo_opt(P, flag)
+    ssp = None if ss is None else C.cast(C.c_char_p(bytes(ss)), C.c_void_p)
+    ora().mpo_prep_rec(bytes(nt), len(nt), bytes(aa), len(aa), C.byref(o), ssp, C.c_void_p(rec.ctypes.data), C.c_void_p(aas.ctypes.data))
+    return rec[:len(nt)], aas[:len(aa)]
+
+
+def ora_walk_back(tb, nl, al, ncol):
+    rst = MpoRst()
+    tb = np.ascontiguousarray(tb, dtype=np.uint16)
+    ora().mpo_walk_back(C.c_void_p(tb.ctypes.data), nl, al, ncol, C.byref(rst))
+    cig = [rst.cigar[i] for i in range(rst.n_cigar)]
+    if rst.cigar:
+        _libc.free(rst.cigar)
+    return cig
 
 
 def ora_nasw(nt, aa, P, flag, ss=None):

@@ -199,6 +199,66 @@ def test_ns_global_gs16b_on_a_host_buffer():
 
 
 @pytest.mark.gpu
+def test_ns_global_gs32b_on_the_gpu(oracle_built):
+    """the 32-bit operator (nasw.h:129,132) on the device: every golden vector of the reference's -msse4.1 build (scores far
+    beyond int16, other penalties, splice tracks, reversed preparation, tiny windows) through ns_global_gs32b -- one wavefront
+    per call runs the source the CPU tests pin (gs32_core.h) -- and a batch of calls through mpa_dp_run32 against the same
+    reference build (or, without it on the box, against the host model the CPU tests pinned to it)."""
+    import golden
+    from gs32util import model_gs32, gs32_cases
+    L = mpa.lib()
+    L.ns_global_gs32b.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(refbind.NsOpt), C.c_void_p, C.POINTER(refbind.NsRst)]
+    L.ns_global_gs32b.restype = None
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    z = np.load(golden.path("gs32_vectors.npz"))
+    n = len(z["flag"])
+    nt_off, aa_off = np.concatenate([[0], np.cumsum(z["nt_len"])]), np.concatenate([[0], np.cumsum(z["aa_len"])])
+    cg_off, ss_off = np.concatenate([[0], np.cumsum(z["cig_len"])]), np.concatenate([[0], np.cumsum(z["ss_len"])])
+    for k in range(n):
+        nt, aa = bytes(z["nt"][nt_off[k]:nt_off[k + 1]]), bytes(z["aa"][aa_off[k]:aa_off[k + 1]])
+        ss = np.ascontiguousarray(z["ss"][ss_off[k]:ss_off[k + 1]]) if z["ss_len"][k] else None
+        o = refbind.NsOpt()
+        L.ns_opt_init(C.byref(o))
+        mat = np.ascontiguousarray(z["mat"][k], dtype=np.int8)
+        o.flag, o.sc = int(z["flag"][k]), mat.ctypes.data
+        o.go, o.ge, o.io, o.fs = (int(x) for x in z["par"][k][:4])
+        for i in range(6):
+            o.sp[i] = int(z["par"][k][4 + i])
+        r = refbind.NsRst()
+        L.ns_global_gs32b(None, nt, len(nt), aa, len(aa), C.byref(o), ss.ctypes.data if ss is not None else None, C.byref(r))
+        cig = [r.cigar[i] for i in range(r.n_cigar)]
+        if r.cigar:
+            libc.free(r.cigar)
+        want = (len(nt), len(aa), int(z["score"][k]), [int(x) for x in z["cig"][cg_off[k]:cg_off[k + 1]]])
+        assert (r.nt_len, r.aa_len, r.score, cig) == want, "vector %d (flag %d, nl %d, al %d)" % (k, o.flag, len(nt), len(aa))
+    # a batch through mpa_dp_run32: one set of parameters, intron-open penalty per call
+    from dputil import build_workload, dpopt_from_params
+    rng = np.random.default_rng(77)
+    mat = np.clip(refbind.mapping_matrix(23).astype(np.int32) * 11, -128, 127).astype(np.int8)
+    P = refbind.DpParams(mat)
+    from dpgen import make_task
+    pairs = [make_task(rng) for _ in range(40)] + [make_task(rng, al=int(rng.integers(500, 1200)), p_sub=0.02, p_indel=0.004, p_intron=0.01) for _ in range(6)]
+    contigs, queries, tasks, meta = build_workload(pairs, rng, modes=("cigar",), io=P.io)
+    ctx = mpa.Context(0)
+    idx = mpa.Index.from_nt4(contigs)
+    idx.to_device(ctx)
+    rst, pool = mpa.dp_run(ctx, idx, dpopt_from_params(P), queries, tasks, wide32=True)
+    n_big = 0
+    for t, (nt, aa) in enumerate(pairs):
+        if refbind.have_ref41():
+            want = refbind.ref_gs32(nt, aa, P, 1)
+        else:
+            sc, cg = model_gs32(nt, aa, P, 1)
+            want = (len(nt), len(aa), sc, cg)
+        got = (int(rst[t]["nt_len"]), int(rst[t]["aa_len"]), int(rst[t]["score"]), [int(x) for x in pool[rst[t]["cigar_off"]:rst[t]["cigar_off"] + rst[t]["n_cigar"]]])
+        assert got == want, "call %d (nl %d, al %d)" % (t, len(nt), len(aa))
+        n_big += want[2] > 32767
+    assert n_big >= 4
+    idx.close(), ctx.close()
+
+
+@pytest.mark.gpu
 def test_index_built_on_the_gpu_is_the_reference_file(tmp_path):
     """mpa_idx_build_kmers_device (scan kernel + one radix sort of all k-mer keys + unique) against the host build, which the
     CPU tests pin to `miniprot -d`: the .mpi of the awkward multi-contig genome (tiny, empty, N-rich, soft-masked contigs), with

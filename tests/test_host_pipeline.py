@@ -65,11 +65,13 @@ def test_error_paths_report_instead_of_guessing(tmp_path):
 
 def test_product_does_not_link_the_oracle():
     out = subprocess.run(["ldd", mpa.LIB_PATH], capture_output=True, text=True).stdout
-    assert "mporacle" not in out and "miniprot_ref" not in out
+    assert "mporacle" not in out and "miniprot_ref" not in out and "nasw_sse41" not in out
     syms = subprocess.run(["nm", "-D", mpa.LIB_PATH], capture_output=True, text=True).stdout
-    # (ns_global_gs16b / mp_map ARE exported since round 2 -- by miniprot_amd/csrc/compat.cpp, on top of the HIP path;
-    #  what must not be there is anything of the checker: the oracle's mpo_* or the reference's internals)
-    assert "mpo_" not in syms and "mp_chain" not in syms and "ns_global_gs32b" not in syms and "radix_sort_mp" not in syms
+    # (ns_global_gs16b / mp_map ARE exported since round 2, ns_global_gs32 / gs32b since round 3 -- by
+    #  miniprot_amd/csrc/compat.cpp, on top of the HIP path; what must not be there is anything of the checker: the oracle's
+    #  mpo_* or the reference's internals)
+    assert "mpo_" not in syms and "mp_chain" not in syms and "mp_sketch_prot" not in syms and "kt_for" not in syms and "radix_sort_mp" not in syms
+    assert "ns_global_gs32b" in syms and "ns_global_gs32\n" in syms + "\n"
 
 
 def test_mapopt_defaults_match_reference_layout():
