@@ -98,6 +98,21 @@ template<int G> __device__ __forceinline__ uint32_t scan_max_pk(uint32_t x)
 	return x;
 }
 
+// The same with the fill registers of the first three steps kept by the caller (all NEGP before the first call, never written
+// elsewhere): a DPP move leaves the lanes without a source untouched, so each register still holds NEGP exactly where its
+// step needs it and that step's "v_mov fill" goes away (VOP3P has no DPP operand on gfx9: move + v_pk_max is the shortest
+// step there is).  Three, not all six: registers are the scarcer resource in the kernel that inlines this (k_dp_round).
+template<int G> __device__ __forceinline__ uint32_t scan_max_pk_keep(uint32_t x, uint32_t (&k)[3])
+{
+	k[0] = dpp_mov<DPP_ROW_SHR(1), 0xf>(k[0], x), x = p_max(x, k[0]);
+	k[1] = dpp_mov<DPP_ROW_SHR(2), 0xf>(k[1], x), x = p_max(x, k[1]);
+	k[2] = dpp_mov<DPP_ROW_SHR(4), 0xf>(k[2], x), x = p_max(x, k[2]);
+	x = p_max(x, dpp_mov<DPP_ROW_SHR(8), 0xf>(NEGP, x));
+	if (G >= 32) x = p_max(x, dpp_mov<DPP_BCAST15, 0xa>(NEGP, x));
+	if (G == 64) x = p_max(x, dpp_mov<DPP_BCAST31, 0xc>(NEGP, x));
+	return x;
+}
+
 // wave-wide maximum of unsigned words, valid in lane 63.  VOP2 takes the DPP operand directly; a lane without a source (or in
 // a masked row) is not written, i.e. keeps its value -- no fill needed (cf. scan_max_i32).
 __device__ __forceinline__ uint32_t reduce_max_u32(uint32_t x)
@@ -433,6 +448,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP, Hbest = NEGP;
 #pragma unroll
 	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
+	uint32_t kscan[3] = { NEGP, NEGP, NEGP };                        // fill registers of the row's scan (scan_max_pk_keep)
 	// virtual column -1 as row 2 sees it (nasw-sse.c:256-258): H(-1,-1)=0, H(0,-1)=H(1,-1)=-fs
 	if (col == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
 	// donor[i-1], donor[i], donor[i+1] live in dn[R1], dn[R2]... : record r carries donor[r+1] and acceptor[r]
@@ -491,10 +507,11 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		constexpr int K = decltype(kc)::value;
 		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;   // ring slots of rows i-1, i-2, i-3
 		// ring maintenance, 16 rows at a time: fetch rows [i+16, i+32) when i%16==0, publish them when i%16==12
-		if ((i & 15) == 0) {                                               // (the first publish, at i=12, is the preloaded rows [16,32))
-			if (loader) pf = make_uint2(recbase[roff[0] + (uint32_t)i + 16 + col], recbase[roff[1] + (uint32_t)i + 16 + col]);
-		} else if ((i & 15) == 12) {
-			if (loader) lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
+		if ((i & 15) == 12) {                                              // rows [i+4, i+20) published (the first time: the preloaded rows [16,32)), the next 16 requested
+			if (loader) {
+				lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
+				pf = make_uint2(recbase[roff[0] + (uint32_t)i + 20 + col], recbase[roff[1] + (uint32_t)i + 20 + col]);
+			}
 		}
 		// next row's profile scores and the record of row i+2: issued first, consumed one row later
 		const uint32_t Snext = prof2(lds_prof + pbase0 + (rnext.x & 0xff), lds_prof + pbase1 + (rnext.y & 0xff));
@@ -518,7 +535,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));          // four frameshift moves
 		h = p_max(h, p_subs(t, fsP));
 		// horizontal gap chain as a prefix max of h + j*ge
-		const uint32_t y = scan_max_pk<G>(p_adds(h, jge));
+		const uint32_t y = scan_max_pk_keep<G>(p_adds(h, jge), kscan);
 		const uint32_t ex = shift1<G>(y, NEGP, lane);
 		h = p_max(h, p_subs(ex, gojge));
 		Hr[R3] = h, Hs[R3] = shift1<G>(h, NEGP, lane);
