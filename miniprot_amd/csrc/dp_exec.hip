@@ -17,8 +17,6 @@
 #include <mutex>
 #include <cstring>
 #include <cstdlib>
-#include <atomic>
-#include <mutex>
 #include <string>
 #include <vector>
 #include "mpa_internal.h"
@@ -33,40 +31,12 @@ namespace mpa {
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return MPA_ERR_HIP; } } while (0)
 
-// A pool that grows gives its old block up -- but hipFree() waits for the whole device, i.e. for the DP rounds and seeding kernels
-// of every other batch in flight, and the stage that grows stands still that long.  Inside a stream of batches the old block is
-// therefore only RETIRED (mpa_map_batches frees the retired blocks when the stream is over, nothing in flight); a failed
-// allocation frees them at once and tries again.  MPA_POOL_RETIRE=0: free on the spot, as before.
-static std::mutex g_retire_mu;
-static std::vector<std::pair<int, void*>> g_retired;       // (device, block)
-static std::atomic<int> g_retire_on{ 0 };                  // streams running (retiring is on while > 0)
-static void pools_drain_retired()
-{
-	std::vector<std::pair<int, void*>> v;
-	{ std::lock_guard<std::mutex> g(g_retire_mu); v.swap(g_retired); }
-	if (v.empty()) return;
-	int cur = 0;
-	(void)hipGetDevice(&cur);
-	for (auto &x : v) { (void)hipSetDevice(x.first); (void)hipFree(x.second); }
-	(void)hipSetDevice(cur);
-}
-void pools_stream_begin() { static const bool on = [] { const char *e = getenv("MPA_POOL_RETIRE"); return !e || atoi(e) != 0; }(); if (on) ++g_retire_on; }
-void pools_stream_end() { static const bool on = [] { const char *e = getenv("MPA_POOL_RETIRE"); return !e || atoi(e) != 0; }(); if (on && --g_retire_on == 0) pools_drain_retired(); }
-
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return MPA_OK;
-		const double t0 = now_ms();
-		if (p) {
-			if (g_retire_on.load() > 0) {
-				int dev = 0;
-				(void)hipGetDevice(&dev);
-				std::lock_guard<std::mutex> g(g_retire_mu);
-				g_retired.emplace_back(dev, p);
-			} else (void)hipFree(p);
-		}
+		if (p) (void)hipFree(p);
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
@@ -75,11 +45,9 @@ struct DevBuf {
 		size_t want = bytes * (size_t)std::max(1, tl_pool_scale);
 		want += want / 3 + 4096;
 		hipError_t e = hipMalloc(&p, want);
-		if (e != hipSuccess) { (void)hipGetLastError(); pools_drain_retired(); e = hipMalloc(&p, want); }
 		if (e != hipSuccess && tl_pool_scale > 1) { (void)hipGetLastError(); want = bytes + bytes / 3 + 4096; e = hipMalloc(&p, want); }
-		if (e != hipSuccess) { p = nullptr; set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
+		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
-		timing_note("    pool growth (device)", now_ms() - t0);
 		return MPA_OK;
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }

@@ -1491,7 +1491,6 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
 	g_trace_t0 = now_ms();
-	struct PoolStream { PoolStream() { pools_stream_begin(); } ~PoolStream() { pools_stream_end(); } } pool_stream;   // (growing pools retire their blocks until the stream is over)
 	// What moves through the pipeline is a UNIT: a whole mini-batch, or -- for the first and the last mini-batches of the stream -- a
 	// quarter of one.  A stream of K batches takes (K - 1) steps plus the time ONE batch needs to get through all stages (seeding,
 	// planning, three DP rounds: ~0.6 s at config 3); while the pipeline fills and drains most of the GPU idles.  The DP rounds of a

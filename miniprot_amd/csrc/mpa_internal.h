@@ -83,8 +83,6 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi);           // k-mer table of 
 void dev_free_index(mpa_idx_s *mi);
 mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);
-void pools_stream_begin();   // inside a stream of batches a device pool that grows retires its old block instead of hipFree()ing it (which waits for the device) ...
-void pools_stream_end();     // ... and the end of the stream frees the retired blocks
 extern thread_local int tl_pool_scale;   // > 1 while this thread works on one of that many parts of a mini-batch: device / pinned pools that have to grow are sized for the whole batch
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off);   // which of its side streams a DP round starts with
 
