@@ -36,6 +36,10 @@ struct DevBuf {
 	size_t cap = 0;
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return MPA_OK;
+		const double t0 = now_ms();
+		// (free, then allocate: measured -- round 3, call 18 -- a pool that keeps its old block until the stream is over and only
+		// hipMalloc()s pays 25 ms per growth instead of 6: the allocator hands the block just freed straight back, a fresh one is
+		// mapped)
 		if (p) (void)hipFree(p);
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
@@ -48,6 +52,7 @@ struct DevBuf {
 		if (e != hipSuccess && tl_pool_scale > 1) { (void)hipGetLastError(); want = bytes + bytes / 3 + 4096; e = hipMalloc(&p, want); }
 		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
+		timing_note("    pool growth (device)", now_ms() - t0);
 		return MPA_OK;
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }
