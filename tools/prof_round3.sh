@@ -3,7 +3,7 @@
 # near-lone), PMC passes at FULL config 3, the pipeline timeline, and the N = 2 code path on one GPU.   bash tools/prof_round3.sh [outdir]
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-OUT=${1:-gpurun_out/r03_final}
+OUT=${1:-gpurun_out/r03_final2}
 mkdir -p $OUT
 WL=/dev/shm/mpa_wl
 bash tools/hostinfo.sh > $OUT/hostinfo.txt 2>&1; head -3 $OUT/hostinfo.txt
@@ -35,7 +35,7 @@ find $OUT/pmc -name "*.db" -delete; find $OUT/pmc -type d -empty -delete
 python - <<'PY'
 import json,sys
 try:
-    d=json.load(open(sys.argv[1] if len(sys.argv)>1 else "gpurun_out/r03_final/pmc/pmc_summary.json"))
+    d=json.load(open(sys.argv[1] if len(sys.argv)>1 else "gpurun_out/r03_final2/pmc/pmc_summary.json"))
     k=d["kernels"].get("k_dp_round",{})
     print("PMC k_dp_round:", {x:k.get(x) for x in ("avg_us","hbm_bytes_per_launch","avg_resident_waves_per_simd","valu_issue_share_of_wave_cycles","lds_bank_conflict_rate")})
 except Exception as e: print("pmc summary:", repr(e)[:200])
