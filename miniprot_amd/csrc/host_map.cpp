@@ -1740,9 +1740,11 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				k = next_dp++;
 				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].begun; });
 				if (rc_all != MPA_OK || k >= n_total) return;
-				// (MPA_DP_MERGE) planned batches that are waiting for a lane ride along: their rounds go out with this batch's
-				while (next_dp < n_total && next_dp - k < dp_merge && slot[next_dp].begun) ++next_dp;
-				k_end = next_dp;
+				// (MPA_DP_MERGE) planned batches that are waiting for a lane ride along: their rounds go out with this batch's.  Only the
+				// batches right behind this one that nobody has claimed yet (the wait above released the lock: other lanes may have moved
+				// next_dp on, and what they claimed is theirs)
+				k_end = k + 1;
+				while (dp_merge > 1 && next_dp == k_end && k_end < n_total && k_end - k < dp_merge && slot[k_end].begun) ++next_dp, ++k_end;
 			}
 			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
 			std::vector<DpJob> jobs;

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/r03t}
 mkdir -p $OUT
 WL=/dev/shm/mpa_wl
-(time timeout 600 python -m pytest tests/test_map_gpu.py -m gpu -q -x -k "merged or stream") > $OUT/pytest_merge.log 2>&1; grep -h "passed\|failed\|Error" $OUT/pytest_merge.log | tail -3
+(time timeout 900 python -m pytest tests -m gpu -q -x) > $OUT/pytest_gpu.log 2>&1; grep -h "passed\|failed\|Error\|Abort" $OUT/pytest_gpu.log | tail -3
 run() {
   ( env $2 timeout 600 python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline --workload-cache $WL $3 ) > $OUT/$1.json 2> $OUT/$1.err
   python tools/bench_line.py "$1 [$2 $3]" $OUT/$1.json
@@ -22,6 +22,5 @@ run base "" ""
 run m2 "MPA_DP_MERGE=2" ""
 run m2l3 "MPA_DP_MERGE=2 MPA_DP_LANES=3" ""
 run m3l2 "MPA_DP_MERGE=3 MPA_DP_LANES=2" ""
-run m2l4 "MPA_DP_MERGE=2 MPA_DP_LANES=4" ""
-run m2l3_40 "MPA_DP_MERGE=2 MPA_DP_LANES=3" "--steps 40 --warmup 10"
+run base2 "" ""
 rm -f $OUT/*.err
