@@ -192,6 +192,16 @@ int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, co
  * those calls on the one-wave path -- same results, no error.  How often that happened on this context: */
 int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx);
 
+/* Bytes of device memory (HBM) this process holds through the library -- resident index (genome, occurrence lists, splice-score
+ * track) plus every grow-only pool of every context -- and how often a pool had to be re-allocated (each growth is a hipFree,
+ * which waits for the whole device).  What bench.py reports as hbm_resident_gb / pool_growth_events. */
+int64_t mpa_device_bytes(void);
+int64_t mpa_pool_growths(void);
+/* Wall-clock milliseconds and calls of the stream pipeline's stages (mpa_map_batches) since the last reset, summed over the
+ * stage's threads: [0] seeding (sketch, lookup, device seeding + both chaining rounds), [1] planning (regions, refinement, plans),
+ * [2] the DP rounds of a batch, host round trips included, [3] output (statistics, flatten, text).  ms / calls may be NULL. */
+void mpa_stage_clocks(double ms[4], int64_t calls[4], int reset);
+
 /* ---- boundary #1: batched mp_map() ------------------------------------------------------------------------ */
 /* mp_feat_t / mp_extra_t / mp_reg1_t (miniprot.h:108-145) flattened for a C ABI */
 typedef struct {

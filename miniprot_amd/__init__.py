@@ -116,6 +116,9 @@ def lib():
         if hasattr(L, "mpa_dp_handoff_retries"):                      # (absent from older builds loaded through MPA_LIB_PATH)
             L.mpa_dp_handoff_retries.argtypes = [C.c_void_p]
             L.mpa_dp_handoff_retries.restype = C.c_int64
+        L.mpa_device_bytes.restype = C.c_int64
+        L.mpa_pool_growths.restype = C.c_int64
+        L.mpa_stage_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mpa_free.argtypes = [C.c_void_p]
         for name, res, args in [
             ("mpa_batch_begin", C.c_void_p, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int]),
@@ -184,6 +187,23 @@ class Context:
     def handoff_retries(self):
         """DP rounds repeated because a workgroup hand-off of a split extension call timed out (mpa_dp_handoff_retries)."""
         return int(lib().mpa_dp_handoff_retries(self.h))
+
+    @staticmethod
+    def device_bytes():
+        """bytes of HBM held through the library: resident index + every pool of every context (mpa_device_bytes)"""
+        return int(lib().mpa_device_bytes())
+
+    @staticmethod
+    def stage_clocks(reset=False):
+        """{stage: (wall ms, calls)} of mpa_map_batches' stages since the last reset (mpa_stage_clocks)"""
+        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        lib().mpa_stage_clocks(ms, n, 1 if reset else 0)
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(("seeding", "planning", "dp", "output"))}
+
+    @staticmethod
+    def pool_growths():
+        """how often a device pool had to be re-allocated so far (mpa_pool_growths)"""
+        return int(lib().mpa_pool_growths())
 
     def __del__(self):
         try:

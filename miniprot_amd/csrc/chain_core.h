@@ -76,6 +76,7 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_EXTRACT_PROF)
 	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
 	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
+	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }   // index of the lowest lane whose ballot bit is clear (width() if none)
 };
 #define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
 
@@ -224,6 +225,40 @@ MPA_HD inline void place_in_order(const SparseItem *src, int64_t n_src, Pair64 *
 	}
 }
 
+// The cycle-leader walk of the reference's digit pass (ksort.h:132-142) over the buckets [k_first, 256) of `tail`, whose bucket
+// boundaries are cursor[] / limit[].  Nearly every slot already holds an element of its own bucket (the heads were filled by
+// place_in_order, the rest are roots), and the reference's loop merely steps over those one at a time: the team tests
+// C::width() consecutive slots at once and only the displacement cycles -- which move data -- are replayed one element at a
+// time, by every lane alike.  With a team of one this is the reference's loop.
+template<class C, int SHIFT> MPA_HD inline void walk_buckets(Pair64 *tail, uint32_t *cursor, const uint32_t *limit, int k_first)
+{
+	for (int k = k_first; k < 256;) {
+		uint32_t c = cursor[k];
+		const uint32_t lim = limit[k];
+		while (c < lim) {                                        // step over the slots that are already in place
+			const uint32_t i = c + (uint32_t)C::lane();
+			const bool in_place = i < lim && (int)(tail[i < lim ? i : c].x >> SHIFT & 0xff) == k;
+			const int n = C::first_unset(C::ballot(in_place));
+			c += (uint32_t)n;
+			if (n < C::width()) break;
+		}
+		C::sync();
+		cursor[k] = c;
+		C::sync();
+		if (c == lim) { ++k; continue; }
+		Pair64 carried = tail[c];                                // a displacement cycle: until an element of bucket k turns up
+		int d = (int)(carried.x >> SHIFT & 0xff);
+		do {
+			const Pair64 placed = carried;
+			carried = tail[cursor[d]];
+			tail[cursor[d]++] = placed;
+			d = (int)(carried.x >> SHIFT & 0xff);
+		} while (d != k);
+		tail[cursor[k]++] = carried;
+		C::sync();
+	}
+}
+
 // The last digit pass (shift 0) of the reference's sort over a region of n slots that holds roots (key k0, the smallest key
 // present) everywhere except at `items` (m of them, ascending pos).  Writes the m non-roots in their final order to out[0, m).
 template<class C> MPA_HD inline void replay_low_digit(int64_t n, int k0, const SparseItem *items, int64_t m, Pair64 *out, uint32_t *hist)
@@ -254,19 +289,7 @@ template<class C> MPA_HD inline void replay_low_digit(int64_t n, int k0, const S
 	C::sync();
 	place_in_order<C, 0>(items, first_tail, tail, cursor, k0, [](int64_t, const Pair64 &, bool) {}, [](int64_t, const Pair64 &) {});
 	// the remaining buckets, entirely inside the tail (same walk as pairs_digit_level)
-	for (int k = k0 + 1; k < 256;) {
-		if (cursor[k] == limit[k]) { ++k; continue; }
-		int d = (int)(tail[cursor[k]].x & 0xff);
-		if (d == k) { ++cursor[k]; continue; }
-		Pair64 carried = tail[cursor[k]];
-		do {
-			const Pair64 placed = carried;
-			carried = tail[cursor[d]];
-			tail[cursor[d]++] = placed;
-			d = (int)(carried.x & 0xff);
-		} while (d != k);
-		tail[cursor[k]++] = carried;
-	}
+	walk_buckets<C, 0>(tail, cursor, limit, k0 + 1);
 	C::sync();
 }
 
@@ -339,19 +362,7 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		},
 		[&](int64_t i, const Pair64 &old) { if (old.y != MPA_ABSENT) moved[n_moved++] = SparseItem{ high[i].pos, old }; });
 	C::sync();
-	for (int k = 1; k < 256;) {                             // buckets 1..255 (same walk as pairs_digit_level)
-		if (cursor[k] == limit[k]) { ++k; continue; }
-		int d = (int)(tail8[cursor[k]].x >> 8 & 0xff);
-		if (d == k) { ++cursor[k]; continue; }
-		Pair64 carried = tail8[cursor[k]];
-		do {
-			const Pair64 placed = carried;
-			carried = tail8[cursor[d]];
-			tail8[cursor[d]++] = placed;
-			d = (int)(carried.x >> 8 & 0xff);
-		} while (d != k);
-		tail8[cursor[k]++] = carried;
-	}
+	walk_buckets<C, 8>(tail8, cursor, limit, 1);            // buckets 1..255 (same walk as pairs_digit_level)
 	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
 	{
 		C::sync();

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -31,6 +32,11 @@ namespace mpa {
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return MPA_ERR_HIP; } } while (0)
 
+// bytes of HBM this process holds through the pools below and the resident index, and how often a pool had to grow
+// (mpa_device_bytes / mpa_pool_growths: bench.py's hbm_resident_gb and pool_growth_events)
+static std::atomic<long long> g_dev_bytes{0}, g_pool_growths{0};
+static thread_local bool tl_alloc_failed = false;         // the last pool request of this thread could not be met (device seeding then declines instead of failing)
+
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
@@ -40,7 +46,7 @@ struct DevBuf {
 		// (free, then allocate: measured -- round 3, call 18 -- a pool that keeps its old block until the stream is over and only
 		// hipMalloc()s pays 25 ms per growth instead of 6: the allocator hands the block just freed straight back, a fresh one is
 		// mapped)
-		if (p) (void)hipFree(p);
+		if (p) { (void)hipFree(p); g_dev_bytes -= (long long)cap; ++g_pool_growths; }
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
@@ -50,12 +56,23 @@ struct DevBuf {
 		want += want / 3 + 4096;
 		hipError_t e = hipMalloc(&p, want);
 		if (e != hipSuccess && tl_pool_scale > 1) { (void)hipGetLastError(); want = bytes + bytes / 3 + 4096; e = hipMalloc(&p, want); }
-		if (e != hipSuccess) { set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
+		if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr, tl_alloc_failed = true; set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
+		g_dev_bytes += (long long)cap;
 		timing_note("    pool growth (device)", now_ms() - t0);
 		return MPA_OK;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr, cap = 0; }
+	// exactly `bytes` (the caller has added its own slack)
+	int ensure_exact(size_t bytes) {
+		if (bytes <= cap) return MPA_OK;
+		if (p) { (void)hipFree(p); g_dev_bytes -= (long long)cap; ++g_pool_growths; }
+		p = nullptr, cap = 0;
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr, tl_alloc_failed = true; set_error("hipMalloc(" + std::to_string(bytes) + ") failed"); return MPA_ERR_HIP; }
+		cap = bytes;
+		g_dev_bytes += (long long)cap;
+		return MPA_OK;
+	}
+	void release() { if (p) { (void)hipFree(p); g_dev_bytes -= (long long)cap; } p = nullptr, cap = 0; }
 	template<typename T> T *as() { return (T*)p; }
 };
 
@@ -64,6 +81,7 @@ struct DeviceIndex {
 	uint8_t *seq = nullptr;
 	int64_t *ctg_off = nullptr, *ctg_len = nullptr;
 	uint32_t *kb = nullptr;                   // k-mer occurrence lists (block ids), uploaded on first GPU seeding call
+	size_t kb_bytes = 0;
 	uint8_t *spsc = nullptr;                  // splice-score track (--spsc), uploaded with the genome when the index has one
 };
 
@@ -83,17 +101,23 @@ struct HostPinned {
 	template<typename T> T *as() { return (T*)p; }
 };
 
+// What a seeding call leaves for the planning stage: pinned host memory only.  In the stream pipeline the device pools belong to
+// the SEEDER (two of them), the results to the batch (one holder per batch between the start of its seeding and the end of its
+// planning), so that a batch waiting to be planned does not pin down a full set of device pools.
+struct SeedHold { HostPinned h_pos, h_f, h_pred, h_a, h_U, h_A; };
+
 struct SeedBufs {
-	DevBuf jobs, key[2], val[2], f, pred, mark, flag, idx, tmp, qfirst, cfirst, o_pos, o_f, o_pred, o_a;
-	HostPinned h_jobs, h_pos, h_f, h_pred, h_a;
+	DevBuf jobs, key[2], f, pred, mark, flag, idx, tmp, qfirst, cfirst;
+	HostPinned h_jobs;
+	SeedHold own;                                                          // results of a call without a holder of its own (blocking path, refinement)
 	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
 	HostPinned h_rhits;
-	DevBuf pf_w, pf_dst, pf_rem, pf_jfirst, pf_qfirst2, pf_err, val64[2];   // pre-sort anchor filter (k_seed_prefilter)
+	DevBuf pf_qfirst2, val64[2];                                            // first kept anchor of every query; the kept anchors' values
 	DevBuf s_meta, s_cur, s_cur2, s_kept, s_base, s_out, s_flag, dkey;      // k_seed_sift: segments + per-query tables, list cursors, per-segment results, dense keys
 	HostPinned h_meta, h_back;                                             // ... their staging (up) and qfirst2 / flags / cfirst (down)
 	DevBuf x_all;                                                          // device chaining: views, extraction scratch, survivors, main-chain state, chains (carved up per call)
 	DevBuf rx_all, rx_keys;                                                // device refinement: pairing tables, pair keys (two buffers), chain state (carved up per call)
-	HostPinned h_U, h_A, h_xoff;                                           // ... the chains of every query (down)
+	HostPinned h_xoff;                                                     // ... offsets of the chains of every query (down)
 	DevBuf c_a, c_f, c_pred, c_mark, c_flag, c_first, c_long;        // chain forward pass (k_chain_fwd, k_chain_fwd_wave: list of long runs + its counter)
 	HostPinned hc_a, hc_f, hc_pred;
 };
@@ -121,8 +145,11 @@ struct mpa_ctx_s {
 	hipEvent_t wait_ev = nullptr;             // blocking-sync event: a host thread that waits for the device SLEEPS (wait_stream)
 	int side_off = 0;                         // first side stream a round uses (lets the DP lanes of a stream of batches sit on different hardware queues)
 	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
+	hipStream_t prep_stream = nullptr;        // high-priority stream of a round's k_prep_rows / k_prep_prof: short and wide, on every round's critical path
+	hipEvent_t prep_ev[2] = {};               // uploads done -> prep may start; prep done -> the round may start
 	bool no_split = false;                    // this mpa_dp_run() repeats a round whose workgroup hand-off timed out: 512/1024-column calls go to k_ext_huge
 	int64_t handoff_retries = 0;              // how often that has happened on this context (mpa_dp_handoff_retries)
+	std::vector<SeedHold*> holds;             // result holders of the stream pipeline's batches (owned; ctx_seed_hold)
 };
 
 namespace mpa {
@@ -131,22 +158,17 @@ namespace mpa {
 // pipeline keeps eight or nine host threads waiting for the device at any time (DP lanes, seeders, planners), and on a host
 // that gives the process a CPU quota (16 cores per GPU on the boxes this was measured on) spinning waiters eat the very cores
 // the host stages need.  An event created with hipEventBlockingSync makes the runtime block on the signal instead.
-// MPA_SPIN_WAIT=1 restores the spinning wait.
 // Measured (round 3): even the "blocking" hipEventSynchronize costs a waiting thread about half a core, so the wait polls the
-// event and SLEEPS in between (MPA_WAIT_US, default 100 us per nap after a short burst of immediate polls; 0 = the runtime's
-// blocking wait).
+// event and SLEEPS 100 us between polls after a short burst of immediate ones.
 static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 {
-	static const bool spin = [] { const char *e = getenv("MPA_SPIN_WAIT"); return e && atoi(e) != 0; }();
-	static const int nap_us = [] { const char *e = getenv("MPA_WAIT_US"); return e ? atoi(e) : 100; }();
-	if (spin || !ctx->wait_ev) return hipStreamSynchronize(s);
+	if (!ctx->wait_ev) return hipStreamSynchronize(s);
 	hipError_t e = hipEventRecord(ctx->wait_ev, s);
 	if (e != hipSuccess) return e;
-	if (nap_us <= 0) return hipEventSynchronize(ctx->wait_ev);
 	for (int polls = 0;; ++polls) {
 		e = hipEventQuery(ctx->wait_ev);
 		if (e != hipErrorNotReady) return e;
-		if (polls >= 8) { struct timespec ts = { 0, (long)nap_us * 1000L }; nanosleep(&ts, nullptr); }
+		if (polls >= 8) { struct timespec ts = { 0, 100000L }; nanosleep(&ts, nullptr); }
 	}
 }
 
@@ -174,6 +196,7 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	}
 	mi->dev = d;
 	undo.d = nullptr;
+	g_dev_bytes += (long long)(mi->seq.size() + mi->spsc.size());
 	return MPA_OK;
 }
 
@@ -182,7 +205,8 @@ void dev_free_index(mpa_idx_s *mi)
 	if (!mi->dev) return;
 	(void)hipSetDevice(mi->dev->device);
 	(void)hipFree(mi->dev->seq); (void)hipFree(mi->dev->ctg_off); (void)hipFree(mi->dev->ctg_len);
-	if (mi->dev->kb) (void)hipFree(mi->dev->kb);
+	g_dev_bytes -= (long long)(mi->seq.size() + mi->spsc.size());
+	if (mi->dev->kb) { (void)hipFree(mi->dev->kb); g_dev_bytes -= (long long)mi->dev->kb_bytes; }
 	if (mi->dev->spsc) (void)hipFree(mi->dev->spsc);
 	delete mi->dev;
 	mi->dev = nullptr;
@@ -242,44 +266,6 @@ static int ext_class_of(int32_t ncol)
 	return -1;
 }
 
-// the three narrow classes (16/32/64 lanes per call) in one launch; a.waves = the whole descriptor array
-static hipError_t launch_ext_narrow(const ExtArgs &a, const int *first, const int *cnt, hipStream_t s)
-{
-	// LDS of the largest instantiation (G = 16: 4 rings)
-	const size_t lds = (((size_t)2 * 64 * PROF_COL_STRIDE + 7) & ~(size_t)7) + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4;
-	NarrowMap m{};
-	for (int k = 0; k < 3; ++k) m.first[k] = first[k], m.cnt[k] = cnt[k];
-	hipLaunchKernelGGL(k_ext_narrow, dim3((unsigned)(cnt[0] + cnt[1] + cnt[2])), dim3(64), lds, s, a, m);
-	return hipGetLastError();
-}
-
-template<int NW> static hipError_t launch_ext_wide(const ExtWideArgs &a, int n_groups, hipStream_t s)
-{
-	const size_t lds = (size_t)NW * 2 * 22 * 64 * 2 + 12 * NW * 4 + (NW <= 4 ? 64 : 128) * 8 + 128 * (2 * NW + 1) * 4;
-	if (lds > 48 * 1024) {
-		int dev = 0;
-		(void)hipGetDevice(&dev);
-		hipError_t e = ensure_dynamic_lds((const void*)k_ext_wide<NW>, dev, lds);
-		if (e != hipSuccess) return e;
-	}
-	hipLaunchKernelGGL((k_ext_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
-	return hipGetLastError();
-}
-
-static hipError_t launch_ext_wide_class(int k, const ExtWideArgs &wa, int n_groups, hipStream_t s)
-{
-	return k == 3 ? launch_ext_wide<2>(wa, n_groups, s) : launch_ext_wide<4>(wa, n_groups, s);
-}
-
-// classes 5 (257..512 columns) and 6 (513..1024): one launch of 256-thread workgroups, two / four per pair of calls
-static hipError_t launch_ext_wide_split(const ExtWideArgs &wa, int n8, int n16, hipStream_t s)
-{
-	const size_t lds = (size_t)4 * 2 * 22 * 64 * 2 + 12 * 4 * 4 + 64 * 8 + 128 * (2 * 4 + 1) * 4 + 96 * 8;
-	SplitMap m{ n16, n8, n8, 0 };                          // wa.waves: the class-5 groups, then the class-6 ones
-	hipLaunchKernelGGL(k_ext_wide_split, dim3((unsigned)(4 * n16 + 2 * n8)), dim3(256), lds, s, wa, m);
-	return hipGetLastError();
-}
-
 template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s)
 {
 	const size_t lds = (size_t)NW * 22 * 64 * 2 + 2 * NW * 16 + 64 * 4;
@@ -287,7 +273,12 @@ template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_gro
 	return hipGetLastError();
 }
 
+} // namespace mpa
+
+extern "C" {
+
 // traceback classes 0,1,2 (16/32/64 lanes) and 7 (block-major, > 1024 columns) in one launch; a.waves = whole array
+// (the traceback chunks after the first, which do not ride in the round's launch)
 static hipError_t launch_glob_narrow(const GlobArgs &a, const int *first, const int *cnt, hipStream_t s)
 {
 	const size_t lds = (size_t)22 * 64 * 2 + (size_t)4 * 32 * 4;
@@ -325,6 +316,12 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreate(&ctx->fork_ev) == hipSuccess;
+	{
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		ok = ok && hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, greatest) == hipSuccess;
+		for (auto &e : ctx->prep_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+	}
 	ok = ok && hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
 	if (!ok) {                                            // a null handle would silently alias the legacy default stream
 		set_error("creating the context's HIP streams/events failed");
@@ -345,16 +342,22 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	SeedBufs &B = ctx->seed;
 	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
 	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
-	                   &B.jobs, &B.key[0], &B.key[1], &B.val[0], &B.val[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
-	                   &B.o_pos, &B.o_f, &B.o_pred, &B.o_a, &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
+	                   &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
+	                   &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
 	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
-	                   &B.pf_w, &B.pf_dst, &B.pf_rem, &B.pf_jfirst, &B.pf_qfirst2, &B.pf_err, &B.val64[0], &B.val64[1],
+	                   &B.pf_qfirst2, &B.val64[0], &B.val64[1],
 	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys }) b->release();
-	for (HostPinned *h : { &B.h_jobs, &B.h_pos, &B.h_f, &B.h_pred, &B.h_a, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_U, &B.h_A, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
+	for (HostPinned *h : { &B.h_jobs, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
+	auto drop_hold = [](SeedHold &H) { for (HostPinned *h : { &H.h_pos, &H.h_f, &H.h_pred, &H.h_a, &H.h_U, &H.h_A }) h->release(); };
+	drop_hold(B.own);
+	for (SeedHold *H : ctx->holds) { drop_hold(*H); delete H; }
+	ctx->holds.clear();
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
 	if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
+	for (auto &e : ctx->prep_ev) if (e) (void)hipEventDestroy(e);
+	if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
 	for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
 	if (ctx->seed_stream && ctx->seed_stream != ctx->stream) (void)hipStreamDestroy(ctx->seed_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -385,6 +388,11 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 	return ctx->siblings[k - 1];
 }
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off) { ctx->side_off = off; }
+SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k)
+{
+	while ((int)ctx->holds.size() <= k) ctx->holds.push_back(new SeedHold());
+	return ctx->holds[(size_t)k];
+}
 
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
@@ -396,118 +404,23 @@ void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 		t.launches_ext += u.launches_ext, t.launches_glob += u.launches_glob;
 		t.cells_ext_round += u.cells_ext_round, t.cells_glob_round += u.cells_glob_round, t.ms_round += u.ms_round, t.launches_round += u.launches_round;
 		u = mpa_dp_stats_t();
+		ctx->handoff_retries += sb->handoff_retries, sb->handoff_retries = 0;
 	}
 }
 } // namespace mpa
 
 namespace mpa {
-// dev_prechain_forward() with the pre-sort filter (MPA_SEED_PREFILTER=1).  The caller has uploaded the jobs and qfirst and made
-// sure the per-anchor buffers exist for all n anchors; only the kept anchors (8-16 % at genome scale) are gathered and sorted.
-static int dev_prechain_forward_filtered(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_block, const PreParams &pp, int nb, int qb, int32_t n_query, const int64_t *qfirst,
-                                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin)
-{
-	SeedBufs &B = ctx->seed;
-	hipStream_t s = ctx->seed_stream;
-	const int64_t n = qfirst[n_query];
-	if (n >= (int64_t)1 << 32) { set_error("GPU seeding: more than 2^32 anchors in a batch"); return MPA_ERR_UNSUPPORTED; }
-	// ranges of PF_PART_BLOCKS blocks over the index's block ids [0, n_block); the kernel reports a block past the last range
-	const int32_t n_part = (int32_t)(((uint64_t)n_block + PF_PART_BLOCKS - 1) / PF_PART_BLOCKS);
-	std::vector<int64_t> jfirst((size_t)n_query + 1, 0);
-	for (int64_t j = 0; j < n_jobs; ++j) ++jfirst[(size_t)jobs[j].qid + 1];
-	for (int32_t q = 0; q < n_query; ++q) jfirst[(size_t)q + 1] += jfirst[(size_t)q];
-	if (B.pf_w.ensure((size_t)n * 4) != MPA_OK || B.pf_dst.ensure((size_t)n * 4) != MPA_OK || B.pf_rem.ensure((size_t)n_query * n_part * 4 + 16) != MPA_OK ||
-	    B.pf_jfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_qfirst2.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.pf_err.ensure(16) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(hipMemcpyAsync(B.pf_jfirst.p, jfirst.data(), ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemsetAsync(B.pf_err.p, 0, 16, s));
-	HIP_TRY(ensure_dynamic_lds((const void*)k_seed_prefilter, ctx->device, PF_LDS));
-	HIP_TRY(wait_stream(ctx, s));                       // (jfirst is a local)
-	hipLaunchKernelGGL(k_seed_prefilter, dim3((unsigned)n_part, (unsigned)n_query), dim3(PF_THREADS), PF_LDS, s, B.jobs.as<SeedJobDev>(), B.pf_jfirst.as<int64_t>(), d->kb,
-	                   n_part, B.pf_w.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_err.as<int32_t>());
-	HIP_TRY(hipGetLastError());
-	size_t scan_bytes = 0;
-	auto keep_it = rocprim::make_transform_iterator(B.pf_w.as<uint32_t>(), KeepBit());
-	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, keep_it, B.pf_dst.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-	if (B.tmp.ensure(scan_bytes + 256) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, keep_it, B.pf_dst.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-	hipLaunchKernelGGL(k_seed_prefilter_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.qfirst.as<int64_t>(), n_query, n, n_part, B.pf_w.as<uint32_t>(),
-	                   B.pf_dst.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.pf_qfirst2.as<int64_t>());
-	HIP_TRY(hipGetLastError());
-	std::vector<int64_t> qfirst2((size_t)n_query + 1, 0);
-	int32_t kerr = 0;
-	HIP_TRY(hipMemcpyAsync(qfirst2.data(), B.pf_qfirst2.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(&kerr, B.pf_err.p, 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(wait_stream(ctx, s));
-	if (kerr) { set_error("k_seed_prefilter: a block id past the last range"); return MPA_ERR_HIP; }
-	const int64_t n2 = qfirst2[(size_t)n_query];
-	timing_note("    seed: pre-sort filter (wait)", now_ms() - t_begin);
-	if (n2 == 0) return MPA_OK;
-	for (int k = 0; k < 2; ++k) if (B.val64[k].ensure((size_t)n2 * 8) != MPA_OK) return MPA_ERR_HIP;
-	const unsigned nblk = (unsigned)((n2 + 255) / 256);
-	hipLaunchKernelGGL(k_seed_gather_kept, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, n_part, B.pf_w.as<uint32_t>(),
-	                   B.pf_dst.as<uint32_t>(), B.pf_rem.as<uint32_t>(), B.key[0].as<uint64_t>(), B.val64[0].as<uint64_t>());
-	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n2, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
-	HIP_TRY(hipGetLastError());
-	size_t tmp_bytes = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val64[0].as<uint64_t>(), B.val64[1].as<uint64_t>(),
-	                                  (size_t)n2, 0u, (unsigned)(nb + qb), s));
-	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
-	if (B.tmp.ensure(std::max(tmp_bytes, scan_bytes) + 256) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(rocprim::radix_sort_pairs(B.tmp.p, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val64[0].as<uint64_t>(), B.val64[1].as<uint64_t>(),
-	                                  (size_t)n2, 0u, (unsigned)(nb + qb), s));
-	const uint64_t *key = B.key[1].as<uint64_t>();
-	const uint64_t *val = B.val64[1].as<uint64_t>();
-	hipLaunchKernelGGL(k_prechain_fwd<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
-	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>(), s));
-	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.pf_qfirst2.as<int64_t>(), n_query, n2, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
-	                   B.cfirst.as<int64_t>());
-	HIP_TRY(hipGetLastError());
-	const double t_issued = now_ms();
-	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(wait_stream(ctx, s));
-	const double t_kernels = now_ms();
-	const int64_t m = out.cfirst[n_query];
-	out.m = m;
-	if (m == 0) return MPA_OK;
-	if (B.o_pos.ensure((size_t)m * 4) != MPA_OK || B.o_f.ensure((size_t)m * 4) != MPA_OK || B.o_pred.ensure((size_t)m * 4) != MPA_OK || B.o_a.ensure((size_t)m * 8) != MPA_OK ||
-	    B.h_pos.ensure((size_t)m * 4) != MPA_OK || B.h_f.ensure((size_t)m * 4) != MPA_OK || B.h_pred.ensure((size_t)m * 4) != MPA_OK || B.h_a.ensure((size_t)m * 8) != MPA_OK) return MPA_ERR_HIP;
-	hipLaunchKernelGGL(k_seed_compact<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
-	                   B.pred.as<int32_t>(), B.o_pos.as<int32_t>(), B.o_f.as<int32_t>(), B.o_pred.as<int32_t>(), B.o_a.as<uint64_t>());
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(B.h_pos.p, B.o_pos.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(wait_stream(ctx, s));
-	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
-	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
-	timing_note("    seed: compact + download", now_ms() - t_kernels);
-	return MPA_OK;
-}
-
-// MPA_SEED_MODE: "sift" (default) = k_seed_sift, per-query merge + LDS sort + isolation filter; "census" = k_seed_prefilter, then
-// a global radix sort of the kept anchors; "sort" = gather and radix-sort every anchor (round 1).  MPA_SEED_PREFILTER=0/1 is the
-// older spelling of sort/census.
-static int seed_mode()
-{
-	if (const char *e = getenv("MPA_SEED_MODE")) return !strcmp(e, "sort") ? 0 : !strcmp(e, "census") ? 1 : 2;
-	if (const char *e = getenv("MPA_SEED_PREFILTER")) return atoi(e) != 0 ? 1 : 0;
-	return 2;
-}
-
 // dev_prechain_forward() with k_seed_sift (the default).  The caller has uploaded the jobs.  Per-anchor memory: 16 bytes of
 // staging; everything behind the sift is sized by the kept anchors.  The result arrays are written by k_seed_compact straight
 // into pinned host memory (no copy kernels, no second pass over HBM).
 static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int64_t n2, int nb, const uint64_t *key, const uint64_t *val, const int64_t *d_qfirst,
-                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out);
+                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out, SeedHold &H);
 
 static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_block, const PreParams &pp, int nb, int32_t n_query, const int64_t *qfirst,
-                                     const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin, const ChainParams *pre_cp, const ChainParams *main_cp)
+                                     const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, double t_begin, const ChainParams *pre_cp, const ChainParams *main_cp, SeedHold &H)
 {
 	SeedBufs &B = ctx->seed;
 	hipStream_t s = ctx->seed_stream;
-	const int64_t n = qfirst[n_query];
 	if (n_block >= 0x7fffffffu) { set_error("GPU seeding: more than 2^31 blocks"); return MPA_ERR_UNSUPPORTED; }
 	// ---- segments: a query's block space in pieces of ~seg_target anchors (evenly, the kernel adapts inside a segment)
 	const int64_t seg_target = [] { const char *e = getenv("MPA_SIFT_SEG"); const int64_t v = e ? atoll(e) : 49152; return v < 256 ? (int64_t)256 : v; }();   // (read per call: the tests flip it)
@@ -516,7 +429,10 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	static thread_local std::vector<int32_t> qseg;
 	segs.clear();
 	int64_t n_cur = 0;                                         // cursors: one per (segment, list of its query)
-	jfirst.assign((size_t)n_query + 1, 0), qseg.assign((size_t)n_query + 1, 0);
+	static thread_local std::vector<int64_t> sfirst;          // first staging slot of every query (sift_stage_slots)
+	jfirst.assign((size_t)n_query + 1, 0), qseg.assign((size_t)n_query + 1, 0), sfirst.assign((size_t)n_query + 1, 0);
+	for (int32_t q = 0; q < n_query; ++q) sfirst[(size_t)q + 1] = sfirst[(size_t)q] + sift_stage_slots(qfirst[q + 1] - qfirst[q]);
+	const int64_t n_stage = sfirst[(size_t)n_query];
 	for (int64_t j = 0; j < n_jobs; ++j) ++jfirst[(size_t)jobs[j].qid + 1];
 	for (int32_t q = 0; q < n_query; ++q) jfirst[(size_t)q + 1] += jfirst[(size_t)q];
 	for (int32_t q = 0; q < n_query; ++q) {
@@ -539,33 +455,26 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	qseg[(size_t)n_query] = (int32_t)segs.size();
 	const int32_t n_seg = (int32_t)segs.size();
 	if (n_seg == 0) return MPA_OK;
-	// one pinned block up: qfirst | jfirst | segments | qseg
+	// one pinned block up: qfirst | jfirst | sfirst | segments | qseg
 	const size_t meta_q = ((size_t)n_query + 1) * 8, seg_bytes = (size_t)n_seg * sizeof(SiftSeg);
-	const size_t off_jf = meta_q, off_seg = 2 * meta_q, off_qs = off_seg + seg_bytes, meta_bytes = off_qs + ((size_t)n_query + 1) * 4;
+	const size_t off_jf = meta_q, off_sf = 2 * meta_q, off_seg = 3 * meta_q, off_qs = off_seg + seg_bytes, meta_bytes = off_qs + ((size_t)n_query + 1) * 4;
 	int rc;
 	if ((rc = B.h_meta.ensure(meta_bytes))) return rc;
 	char *hm = B.h_meta.as<char>();
-	memcpy(hm, qfirst, meta_q), memcpy(hm + off_jf, jfirst.data(), meta_q), memcpy(hm + off_seg, segs.data(), seg_bytes), memcpy(hm + off_qs, qseg.data(), ((size_t)n_query + 1) * 4);
+	memcpy(hm, qfirst, meta_q), memcpy(hm + off_jf, jfirst.data(), meta_q), memcpy(hm + off_sf, sfirst.data(), meta_q), memcpy(hm + off_seg, segs.data(), seg_bytes), memcpy(hm + off_qs, qseg.data(), ((size_t)n_query + 1) * 4);
 	if ((rc = B.s_meta.ensure(meta_bytes)) || (rc = B.s_cur.ensure((size_t)n_cur * 4 + 16)) || (rc = B.s_cur2.ensure((size_t)n_cur * 4 + 16)) ||
 	    (rc = B.s_kept.ensure((size_t)n_seg * 4)) || (rc = B.s_base.ensure((size_t)n_seg * 8)) || (rc = B.s_out.ensure(((size_t)n_seg + 1) * 8)) ||
 	    (rc = B.s_flag.ensure((size_t)n_query * 4 + 16)) || (rc = B.pf_qfirst2.ensure(meta_q)) || (rc = B.cfirst.ensure(meta_q)) ||
-	    (rc = B.key[0].ensure((size_t)n * 8)) || (rc = B.key[1].ensure((size_t)n * 8)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;
+	    (rc = B.key[0].ensure((size_t)n_stage * 8 + 64)) || (rc = B.key[1].ensure((size_t)n_stage * 8 + 64)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;
 	HIP_TRY(hipMemcpyAsync(B.s_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(B.s_flag.p, 0, (size_t)n_query * 4 + 16, s));
 	const char *dm = B.s_meta.as<char>();
-	const int64_t *d_qfirst = (const int64_t*)dm, *d_jfirst = (const int64_t*)(dm + off_jf);
+	const int64_t *d_qfirst = (const int64_t*)dm, *d_jfirst = (const int64_t*)(dm + off_jf), *d_sfirst = (const int64_t*)(dm + off_sf);
 	const SiftSeg *d_segs = (const SiftSeg*)(dm + off_seg);
 	const int32_t *d_qseg = (const int32_t*)(dm + off_qs);
-	// MPA_SIFT_CAP: anchors per LDS buffer of k_seed_sift, 2048 or 4096 (the default): fewer, larger ranges per segment
-	static const int sift_cap = [] { const char *e = getenv("MPA_SIFT_CAP"); return e && atoi(e) == 2048 ? 2048 : 4096; }();
-	if (sift_cap == 2048)
-		hipLaunchKernelGGL(k_seed_sift<2048>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d->kb, n_block, nb,
-		                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
-		                   B.s_flag.as<int32_t>());
-	else
-		hipLaunchKernelGGL(k_seed_sift<4096>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d->kb, n_block, nb,
-		                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
-		                   B.s_flag.as<int32_t>());
+	hipLaunchKernelGGL(k_seed_sift<4096>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
+	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
+	                   B.s_flag.as<int32_t>());
 	hipLaunchKernelGGL(k_sift_offsets, dim3(1), dim3(256), 0, s, d_segs, n_seg, n_query, d_qseg, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_out.as<int64_t>(),
 	                   B.pf_qfirst2.as<int64_t>());
 	HIP_TRY(hipGetLastError());
@@ -610,20 +519,19 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	out.m = m;
 	timing_note("    seed: copy + pre-chain + scan (wait)", t_kernels - t_sift);
 	if (m == 0) return MPA_OK;
-	// both chaining rounds on the device (MPA_DEVICE_CHAINS=0: hand the linked anchors to the host instead, as rounds 1-2 did)
+	// both chaining rounds on the device (main_cp == nullptr: the caller wants the pre-chain's linked anchors, as rounds 1-2 did)
 	{
-		static const bool device_chains = [] { const char *e = getenv("MPA_DEVICE_CHAINS"); return e ? atoi(e) != 0 : true; }();
-		if (device_chains && main_cp && pre_cp) {
-			rc = dev_chains_on_device(ctx, n_query, m, n2, nb, key, val, d_qfirst, h_flag, *pre_cp, *main_cp, out);
+		if (main_cp && pre_cp) {
+			rc = dev_chains_on_device(ctx, n_query, m, n2, nb, key, val, d_qfirst, h_flag, *pre_cp, *main_cp, out, H);
 			if (rc != MPA_ERR_UNSUPPORTED) { timing_note("    seed: chains on the device", now_ms() - t_kernels); return rc; }
 		}
 	}
-	if ((rc = B.h_pos.ensure((size_t)m * 4)) || (rc = B.h_f.ensure((size_t)m * 4)) || (rc = B.h_pred.ensure((size_t)m * 4)) || (rc = B.h_a.ensure((size_t)m * 8))) return rc;
+	if ((rc = H.h_pos.ensure((size_t)m * 4)) || (rc = H.h_f.ensure((size_t)m * 4)) || (rc = H.h_pred.ensure((size_t)m * 4)) || (rc = H.h_a.ensure((size_t)m * 8))) return rc;
 	hipLaunchKernelGGL((k_seed_compact<uint64_t, true>), dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(),
-	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), B.h_pos.as<int32_t>(), B.h_f.as<int32_t>(), B.h_pred.as<int32_t>(), B.h_a.as<uint64_t>());
+	                   B.f.as<int32_t>(), B.pred.as<int32_t>(), H.h_pos.as<int32_t>(), H.h_f.as<int32_t>(), H.h_pred.as<int32_t>(), H.h_a.as<uint64_t>());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(wait_stream(ctx, s));
-	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
+	out.pos = H.h_pos.as<int32_t>(), out.f = H.h_f.as<int32_t>(), out.pred = H.h_pred.as<int32_t>(), out.a = H.h_a.as<uint64_t>();
 	timing_note("    seed: compact into pinned memory", now_ms() - t_kernels);
 	return MPA_OK;
 }
@@ -638,7 +546,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 // (~11 000 per query at 3 Gbp), and the host no longer spends a core-second per mini-batch on chaining.
 // key/val: the kept anchors (dense, sorted), with B.f / B.pred / B.flag / B.idx / B.cfirst from the pre-chain's forward pass.
 static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int64_t n2, int nb, const uint64_t *key, const uint64_t *val, const int64_t *d_qfirst,
-                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out)
+                                const int32_t *h_flag, const ChainParams &pre, const ChainParams &mainp, PrechainSparse &out, SeedHold &H)
 {
 	SeedBufs &B = ctx->seed;
 	hipStream_t s = ctx->seed_stream;
@@ -647,17 +555,20 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	const size_t M = (size_t)m, NQ = (size_t)n_query;
 	size_t at = 0;
 	auto carve = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t o_vpos = carve(M * 4), o_vf = carve(M * 4), o_vpred = carve(M * 4), o_va = carve(M * 8);
+	const size_t o_vpos = carve(M * 8), o_vf = o_vpos + M * 4, o_vpred = carve(M * 4), o_va = carve(M * 8);
 	const size_t o_mark = carve(M * 4), o_order = carve(M * 4), o_ends = carve((M + 64 * NQ + 64) * sizeof(Pair64)), o_tail8 = carve(M * sizeof(Pair64)),
-	             o_firstp = carve(M * sizeof(Pair64)), o_items = carve(M * sizeof(SparseItem)), o_moved = carve(M * sizeof(SparseItem)), o_merged = carve(M * sizeof(SparseItem)),
-	             o_kept = carve(M), o_packed = carve(M * 8), o_usorted = carve(M * 8), o_stack = carve((M / 64 + 6 * NQ + 16) * sizeof(SortRange));
+	             o_items = carve(M * sizeof(SparseItem)), o_moved = carve(M * sizeof(SparseItem)), o_merged = carve(M * sizeof(SparseItem)),
+	             o_kept = carve(M), o_stack = carve((M / 64 + 6 * NQ + 16) * sizeof(SortRange));
+	// (the chain layout's scratch -- packed anchors, sorted u, first positions -- is only live after the sort replay and the
+	// extraction: k_chain_extract puts it into the problem's own `moved` and `merged` lists)
 	const size_t o_pre_a = carve(M * 8), o_pre_u = carve(M * 8), o_pre_na = carve(NQ * 8 + 8), o_pre_nu = carve(NQ * 8 + 8), o_status = carve(NQ * 4 + 16);
 	const size_t o_mf = carve(M * 4), o_mpred = carve(M * 4), o_mmark = carve(M * 4);
 	const int32_t kSerialRun = 48;                          // longer runs of the main chain get a wavefront each (k_chain_fwd_wave)
 	const size_t long_cap = M / (size_t)(kSerialRun + 1) + 16, o_long = carve(long_cap * sizeof(LongRun)), o_nlong = carve(64);
-	const size_t o_out_a = carve(M * 8), o_out_u = carve(M * 8), o_na = carve(NQ * 8 + 8), o_nu = carve(NQ * 8 + 8), o_offa = carve(NQ * 8 + 16), o_offu = carve(NQ * 8 + 16);
+	// (the main chains go where the pre-chain's view was: it is dead once the pre-chain has been extracted)
+	const size_t o_out_a = o_va, o_out_u = o_vpos, o_na = carve(NQ * 8 + 8), o_nu = carve(NQ * 8 + 8), o_offa = carve(NQ * 8 + 16), o_offu = carve(NQ * 8 + 16);
 	int rc;
-	if (at > B.x_all.cap && (rc = B.x_all.ensure(at + at / 3))) return rc;   // (generous: a re-allocation is a hipFree, which waits for the whole device)
+	if ((rc = B.x_all.ensure(at))) return rc;                // (ensure() adds a third of slack: a re-allocation is a hipFree, which waits for the whole device)
 	char *X = B.x_all.as<char>();
 	HIP_TRY(hipMemsetAsync(X + o_status, 0, NQ * 4 + 16, s));
 	const unsigned nblk2 = (unsigned)((n2 + 255) / 256), nblkm = (unsigned)((m + 255) / 256);
@@ -667,9 +578,9 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	ExtractArgs xa;
 	xa.first = B.cfirst.as<int64_t>(), xa.cnt = nullptr, xa.ntot_first = d_qfirst;
 	xa.v_pos = (const int32_t*)(X + o_vpos), xa.v_f = (const int32_t*)(X + o_vf), xa.v_pred = (const int32_t*)(X + o_vpred), xa.v_a = (const uint64_t*)(X + o_va);
-	xa.mark = (int32_t*)(X + o_mark), xa.order = (int32_t*)(X + o_order), xa.ends = (Pair64*)(X + o_ends), xa.tail8 = (Pair64*)(X + o_tail8), xa.firstp = (Pair64*)(X + o_firstp);
+	xa.mark = (int32_t*)(X + o_mark), xa.order = (int32_t*)(X + o_order), xa.ends = (Pair64*)(X + o_ends), xa.tail8 = (Pair64*)(X + o_tail8);
 	xa.items = (SparseItem*)(X + o_items), xa.moved = (SparseItem*)(X + o_moved), xa.merged = (SparseItem*)(X + o_merged);
-	xa.kept = (uint8_t*)(X + o_kept), xa.packed = (uint64_t*)(X + o_packed), xa.u_sorted = (uint64_t*)(X + o_usorted), xa.stack = (SortRange*)(X + o_stack);
+	xa.kept = (uint8_t*)(X + o_kept), xa.stack = (SortRange*)(X + o_stack);
 	xa.a_out = (uint64_t*)(X + o_pre_a), xa.u_out = (uint64_t*)(X + o_pre_u), xa.n_a = (int64_t*)(X + o_pre_na), xa.n_u = (int64_t*)(X + o_pre_nu);
 	xa.status = (int32_t*)(X + o_status), xa.p = pre, xa.set_only = 1;
 	// MPA_EXTRACT_PROF=1 (debug): per-phase wall clock of the extraction kernel, averaged over the problems of the launch
@@ -739,16 +650,16 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	HIP_TRY(hipMemcpyAsync(h_status, X + o_status, NQ * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(wait_stream(ctx, s));
 	const int64_t tot_a = h_offa[n_query], tot_u = h_offu[n_query];
-	if ((rc = B.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = B.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
+	if ((rc = H.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = H.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
 	if (tot_a > 0 || tot_u > 0) {
 		hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)n_query), dim3(256), 0, s, B.cfirst.as<int64_t>(), (const int64_t*)(X + o_na), (const int64_t*)(X + o_nu),
 		                   (const int64_t*)(X + o_offa), (const int64_t*)(X + o_offu), (const uint64_t*)(X + o_out_a), (const uint64_t*)(X + o_out_u),
-		                   B.h_A.as<uint64_t>(), B.h_U.as<uint64_t>());
+		                   H.h_A.as<uint64_t>(), H.h_U.as<uint64_t>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(wait_stream(ctx, s));
 	}
 	out.a_first.assign(h_offa, h_offa + n_query + 1), out.u_first.assign(h_offu, h_offu + n_query + 1);
-	out.A = B.h_A.as<uint64_t>(), out.U = B.h_U.as<uint64_t>();
+	out.A = H.h_A.as<uint64_t>(), out.U = H.h_U.as<uint64_t>();
 	out.has_chains = true;
 	bool any = !out.on_host.empty();
 	for (int32_t q = 0; q < n_query && !any; ++q) any = h_status[q] != 0;
@@ -764,7 +675,7 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 // offset); qfirst[n_query + 1]: first anchor of every query.  out: per query a sparse ChainView's arrays
 // (pred = index into the query's part of the view, -1 for none).
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
-                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main)
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main, SeedHold *hold)
 {
 	const int64_t n = qfirst[n_query];
 	out.cfirst.assign((size_t)n_query + 1, 0);
@@ -782,7 +693,8 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 			uint32_t *p = nullptr;
 			HIP_TRY(hipMalloc((void**)&p, mi->kb.size() * 4 + 16));
 			HIP_TRY(hipMemcpy(p, mi->kb.data(), mi->kb.size() * 4, hipMemcpyHostToDevice));
-			d->kb = p;
+			d->kb = p, d->kb_bytes = mi->kb.size() * 4 + 16;
+			g_dev_bytes += (long long)d->kb_bytes;
 		}
 	}
 	PreParams pp;
@@ -794,14 +706,14 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	while ((1ULL << nb) < (uint64_t)mi->n_block + (uint64_t)pp.max_dblock + 2) ++nb;
 	while ((1LL << qb) < n_query) ++qb;
 	if (nb + qb > 64) { set_error("GPU pre-chain: too many queries x blocks for a 64-bit key"); return MPA_ERR_UNSUPPORTED; }
-	const int mode = pp.max_dblock == 1 ? seed_mode() : 0;     // (the filters assume the pre-chain's one-block reach)
+	if (pp.max_dblock != 1) { set_error("GPU seeding: the sift assumes a pre-chain that reaches one block"); return MPA_ERR_UNSUPPORTED; }
 	{	// the working set is ~60 bytes per anchor (sift: 16 of staging, the rest sized by the kept ones); a batch that does not fit
 		// stays on the host (the caller falls back)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			const SeedBufs &Bc = ctx->seed;
-			const size_t have = Bc.key[0].cap + Bc.key[1].cap + Bc.val[0].cap + Bc.val[1].cap + Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap;
-			if ((size_t)n * (mode == 2 ? 28 : 60) > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
+			const size_t have = Bc.key[0].cap + Bc.key[1].cap + Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap + Bc.x_all.cap + Bc.dkey.cap + Bc.val64[0].cap;
+			if ((size_t)n * 40 > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
 		}
 	}
 	SeedBufs &B = ctx->seed;
@@ -818,60 +730,13 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	for (int64_t i = 0; i < n_jobs; ++i) hj[i] = SeedJobDev{ jobs[i].kb_off, jobs[i].dst, jobs[i].cnt, jobs[i].qpos, jobs[i].qid, 0 };
 	if (B.jobs.ensure((size_t)n_jobs * sizeof(SeedJobDev)) != MPA_OK) return MPA_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(B.jobs.p, hj, (size_t)n_jobs * sizeof(SeedJobDev), hipMemcpyHostToDevice, s));
-	// the default: merge the occurrence lists per query in block order, keep what has a neighbour (k_seed_sift, seed_exec.hip)
-	if (mode == 2) return dev_prechain_forward_sift(ctx, d, mi->n_block, pp, nb, n_query, qfirst, jobs, n_jobs, out, t_begin, &pre, main);
-	if (B.qfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK || B.cfirst.ensure(((size_t)n_query + 1) * 8) != MPA_OK) return MPA_ERR_HIP;
-	for (int k = 0; k < 2; ++k) if (B.key[k].ensure((size_t)n * 8) != MPA_OK || B.val[k].ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
-	if (B.f.ensure((size_t)n * 4) != MPA_OK || B.pred.ensure((size_t)n * 4) != MPA_OK || B.mark.ensure((size_t)n * 4) != MPA_OK ||
-	    B.flag.ensure((size_t)n * 4) != MPA_OK || B.idx.ensure((size_t)n * 4) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(hipMemcpyAsync(B.qfirst.p, qfirst, ((size_t)n_query + 1) * 8, hipMemcpyHostToDevice, s));
-	// MPA_SEED_MODE=census: drop the anchors that have no neighbour within one block before they are gathered and sorted
-	// (k_seed_prefilter, seed_exec.hip); the rest of the stage then runs on the kept ones with a 64-bit sort value
-	if (mode == 1) return dev_prechain_forward_filtered(ctx, d, mi->n_block, pp, nb, qb, n_query, qfirst, jobs, n_jobs, out, t_begin);
-	const unsigned nblk = (unsigned)((n + 255) / 256);
-	hipLaunchKernelGGL(k_seed_gather, dim3((unsigned)n_jobs), dim3(256), 0, s, B.jobs.as<SeedJobDev>(), (int32_t)n_jobs, d->kb, nb, B.key[0].as<uint64_t>(), B.val[0].as<uint32_t>());
-	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
-	HIP_TRY(hipGetLastError());
-	// ---- stable sort on (query, block): the anchors were gathered in ascending query position
-	size_t tmp_bytes = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val[0].as<uint32_t>(), B.val[1].as<uint32_t>(),
-	                                  (size_t)n, 0u, (unsigned)(nb + qb), s));
-	size_t scan_bytes = 0;
-	HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-	if (B.tmp.ensure(std::max(tmp_bytes, scan_bytes) + 256) != MPA_OK) return MPA_ERR_HIP;
-	HIP_TRY(rocprim::radix_sort_pairs(B.tmp.p, tmp_bytes, B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.val[0].as<uint32_t>(), B.val[1].as<uint32_t>(),
-	                                  (size_t)n, 0u, (unsigned)(nb + qb), s));
-	const uint64_t *key = B.key[1].as<uint64_t>();
-	const uint32_t *val = B.val[1].as<uint32_t>();
-	hipLaunchKernelGGL(k_prechain_fwd<uint32_t>, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
-	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(rocprim::exclusive_scan(B.tmp.p, scan_bytes, B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-	hipLaunchKernelGGL(k_seed_bounds, dim3((unsigned)(n_query / 256 + 1)), dim3(256), 0, s, B.qfirst.as<int64_t>(), n_query, n, B.idx.as<uint32_t>(), B.flag.as<uint32_t>(),
-	                   B.cfirst.as<int64_t>());
-	HIP_TRY(hipGetLastError());
-	const double t_issued = now_ms();
-	HIP_TRY(hipMemcpyAsync(out.cfirst.data(), B.cfirst.p, ((size_t)n_query + 1) * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(wait_stream(ctx, s));
-	const double t_kernels = now_ms();
-	const int64_t m = out.cfirst[n_query];
-	out.m = m;
-	if (m == 0) return MPA_OK;
-	if (B.o_pos.ensure((size_t)m * 4) != MPA_OK || B.o_f.ensure((size_t)m * 4) != MPA_OK || B.o_pred.ensure((size_t)m * 4) != MPA_OK || B.o_a.ensure((size_t)m * 8) != MPA_OK ||
-	    B.h_pos.ensure((size_t)m * 4) != MPA_OK || B.h_f.ensure((size_t)m * 4) != MPA_OK || B.h_pred.ensure((size_t)m * 4) != MPA_OK || B.h_a.ensure((size_t)m * 8) != MPA_OK) return MPA_ERR_HIP;
-	hipLaunchKernelGGL(k_seed_compact<uint32_t>, dim3(nblk), dim3(256), 0, s, key, val, n, nb, B.qfirst.as<int64_t>(), B.flag.as<uint32_t>(), B.idx.as<uint32_t>(), B.f.as<int32_t>(),
-	                   B.pred.as<int32_t>(), B.o_pos.as<int32_t>(), B.o_f.as<int32_t>(), B.o_pred.as<int32_t>(), B.o_a.as<uint64_t>());
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(B.h_pos.p, B.o_pos.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_f.p, B.o_f.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_pred.p, B.o_pred.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(B.h_a.p, B.o_a.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-	HIP_TRY(wait_stream(ctx, s));
-	out.pos = B.h_pos.as<int32_t>(), out.f = B.h_f.as<int32_t>(), out.pred = B.h_pred.as<int32_t>(), out.a = B.h_a.as<uint64_t>();
-	timing_note("    seed: buffers + job upload + launches", t_issued - t_begin);
-	timing_note("    seed: kernels (wait)", t_kernels - t_issued);
-	timing_note("    seed: compact + download", now_ms() - t_kernels);
-	return MPA_OK;
+	// merge the occurrence lists per query in block order, keep what has a neighbour (k_seed_sift, seed_exec.hip)
+	tl_alloc_failed = false;
+	const int rc = dev_prechain_forward_sift(ctx, d, mi->n_block, pp, nb, n_query, qfirst, jobs, n_jobs, out, t_begin, &pre, main, hold ? *hold : B.own);
+	// a pool that could not grow (the admission check above is an estimate): the batch is seeded on the host, as for any batch
+	// that does not fit -- nothing has been handed to the caller yet
+	if (rc == MPA_ERR_HIP && tl_alloc_failed) { (void)hipStreamSynchronize(s); return MPA_ERR_UNSUPPORTED; }
+	return rc;
 }
 } // namespace mpa
 
@@ -982,8 +847,9 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	HIP_TRY(hipMemcpyAsync(kb_new.data(), d_kb, (size_t)n_kb * 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(wait_stream(ctx, s));
 	mi->ki.swap(ki_new), mi->kb.swap(kb_new), mi->n_kb = n_kb;
-	if (d->kb) (void)hipFree(d->kb);
-	d->kb = d_kb;                                          // stays resident for the seeding kernels
+	if (d->kb) { (void)hipFree(d->kb); g_dev_bytes -= (long long)d->kb_bytes; }
+	d->kb = d_kb, d->kb_bytes = (size_t)n_kb * 4 + 16;     // stays resident for the seeding kernels
+	g_dev_bytes += (long long)d->kb_bytes;
 	d_kb = nullptr;                                        // (ownership moved: the guard lets go)
 	timing_note("index build on the GPU", now_ms() - t0);
 	return MPA_OK;
@@ -1267,13 +1133,12 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	const size_t M = (size_t)np;
 	size_t xat = 0;
 	auto xcarve = [&](size_t bytes) { const size_t o = xat; xat += (bytes + 255) & ~(size_t)255; return o; };
-	const size_t x_mark = xcarve(M * 4), x_order = xcarve(M * 4), x_ends = xcarve((M + 64 * NW + 64) * sizeof(Pair64)), x_tail8 = xcarve(M * sizeof(Pair64)), x_firstp = xcarve(M * sizeof(Pair64)),
-	             x_items = xcarve(M * sizeof(SparseItem)), x_moved = xcarve(M * sizeof(SparseItem)), x_merged = xcarve(M * sizeof(SparseItem)), x_kept = xcarve(M), x_packed = xcarve(M * 8),
-	             x_usorted = xcarve(M * 8), x_stack = xcarve((M / 64 + 6 * NW + 16) * sizeof(SortRange)), x_status = xcarve(NW * 4 + 16), x_f = xcarve(M * 4), x_pred = xcarve(M * 4),
+	const size_t x_mark = xcarve(M * 4), x_order = xcarve(M * 4), x_ends = xcarve((M + 64 * NW + 64) * sizeof(Pair64)), x_tail8 = xcarve(M * sizeof(Pair64)),
+	             x_items = xcarve(M * sizeof(SparseItem)), x_moved = xcarve(M * sizeof(SparseItem)), x_merged = xcarve(M * sizeof(SparseItem)), x_kept = xcarve(M), x_stack = xcarve((M / 64 + 6 * NW + 16) * sizeof(SortRange)), x_status = xcarve(NW * 4 + 16), x_f = xcarve(M * 4), x_pred = xcarve(M * 4),
 	             x_fm = xcarve(M * 4), x_outa = xcarve(M * 8), x_outu = xcarve(M * 8), x_na = xcarve(NW * 8 + 8), x_nu = xcarve(NW * 8 + 8), x_offa = xcarve(NW * 8 + 16), x_offu = xcarve(NW * 8 + 16);
 	const int32_t kSerialRun = 48;
 	const size_t long_cap = M / (size_t)(kSerialRun + 1) + 16, x_long = xcarve(long_cap * sizeof(LongRun)), x_nlong = xcarve(64);
-	if (xat > B.x_all.cap && (rc = B.x_all.ensure(xat + xat / 3))) return rc;
+	if ((rc = B.x_all.ensure(xat))) return rc;
 	char *X = B.x_all.as<char>();
 	HIP_TRY(hipMemsetAsync(X + x_status, 0, NW * 4 + 16, s));
 	HIP_TRY(hipMemsetAsync(X + x_nlong, 0, 64, s));
@@ -1286,9 +1151,9 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	ExtractArgs xa;
 	xa.first = d_first, xa.cnt = nullptr, xa.ntot_first = nullptr;
 	xa.v_pos = nullptr, xa.v_f = (const int32_t*)(X + x_f), xa.v_pred = (const int32_t*)(X + x_pred), xa.v_a = (const uint64_t*)d_a;
-	xa.mark = (int32_t*)(X + x_mark), xa.order = (int32_t*)(X + x_order), xa.ends = (Pair64*)(X + x_ends), xa.tail8 = (Pair64*)(X + x_tail8), xa.firstp = (Pair64*)(X + x_firstp);
+	xa.mark = (int32_t*)(X + x_mark), xa.order = (int32_t*)(X + x_order), xa.ends = (Pair64*)(X + x_ends), xa.tail8 = (Pair64*)(X + x_tail8);
 	xa.items = (SparseItem*)(X + x_items), xa.moved = (SparseItem*)(X + x_moved), xa.merged = (SparseItem*)(X + x_merged);
-	xa.kept = (uint8_t*)(X + x_kept), xa.packed = (uint64_t*)(X + x_packed), xa.u_sorted = (uint64_t*)(X + x_usorted), xa.stack = (SortRange*)(X + x_stack);
+	xa.kept = (uint8_t*)(X + x_kept), xa.stack = (SortRange*)(X + x_stack);
 	xa.a_out = (uint64_t*)(X + x_outa), xa.u_out = (uint64_t*)(X + x_outu), xa.n_a = (int64_t*)(X + x_na), xa.n_u = (int64_t*)(X + x_nu);
 	xa.status = (int32_t*)(X + x_status), xa.p = cp, xa.set_only = 0;
 	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_win), dim3(64), 0, s, xa, (int32_t)n_win);
@@ -1304,15 +1169,16 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	HIP_TRY(wait_stream(ctx, s));
 	for (size_t w = 0; w < NW; ++w) if (h_status[w]) { set_error("device refinement: a chain extraction needs the host"); return MPA_ERR_UNSUPPORTED; }   // (dense views never do)
 	const int64_t tot_a = h_offa[n_win], tot_u = h_offu[n_win];
-	if ((rc = B.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = B.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
+	SeedHold &H = B.own;
+	if ((rc = H.h_A.ensure((size_t)tot_a * 8 + 64)) || (rc = H.h_U.ensure((size_t)tot_u * 8 + 64))) return rc;
 	if (tot_a > 0 || tot_u > 0) {
 		hipLaunchKernelGGL(k_chain_pack, dim3((unsigned)n_win), dim3(256), 0, s, (const int64_t*)d_first, (const int64_t*)(X + x_na), (const int64_t*)(X + x_nu), (const int64_t*)(X + x_offa),
-		                   (const int64_t*)(X + x_offu), (const uint64_t*)(X + x_outa), (const uint64_t*)(X + x_outu), B.h_A.as<uint64_t>(), B.h_U.as<uint64_t>());
+		                   (const int64_t*)(X + x_offu), (const uint64_t*)(X + x_outa), (const uint64_t*)(X + x_outu), H.h_A.as<uint64_t>(), H.h_U.as<uint64_t>());
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(wait_stream(ctx, s));
 	}
 	out.a_first.assign(h_offa, h_offa + n_win + 1), out.u_first.assign(h_offu, h_offu + n_win + 1);
-	out.A = B.h_A.as<uint64_t>(), out.U = B.h_U.as<uint64_t>();
+	out.A = H.h_A.as<uint64_t>(), out.U = H.h_U.as<uint64_t>();
 	timing_note("    refine: pairs + chains (wait)", now_ms() - t1);
 	return MPA_OK;
 }
@@ -1551,12 +1417,19 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, mi->dev->spsc, mi->l_seq };
 
 	// ---- K3: per-row records and profiles
-	HIP_TRY(hipEventRecord(ctx->ev[0], s));
+	// (on the context's high-priority stream: these two are short, wide and on the round's critical path; in the main stream's
+	// queue they waited behind the round kernels of the other lanes -- 8 ms on average and up to 125 ms for 2.4 ms of work, round 3)
+	hipStream_t ps = ctx->prep_stream;
+	HIP_TRY(hipEventRecord(ctx->prep_ev[0], s));
+	HIP_TRY(hipStreamWaitEvent(ps, ctx->prep_ev[0], 0));
+	HIP_TRY(hipEventRecord(ctx->ev[0], ps));
 	if (!chunks.empty())
-		hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, s, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
-	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
+		hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, ps, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
+	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, ps, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(ctx->ev[1], s));
+	HIP_TRY(hipEventRecord(ctx->ev[1], ps));
+	HIP_TRY(hipEventRecord(ctx->prep_ev[1], ps));
+	HIP_TRY(hipStreamWaitEvent(s, ctx->prep_ev[1], 0));
 	mark("    dp: uploads + prep enqueued");
 	// ---- fork: every kernel class (extension classes and the traceback classes of the first round) gets its
 	// own stream, so the long single-wave tails of the classes overlap instead of adding up
@@ -1564,7 +1437,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	int n_side = 0;
 	struct Launch { int side; bool is_ext; };
 	std::vector<Launch> launches;
-	static const int n_streams = [] { const char *e = getenv("MPA_SIDE_STREAMS"); int v = e ? atoi(e) : mpa_ctx_s::kSide; return v < 1 ? 1 : v > mpa_ctx_s::kSide ? mpa_ctx_s::kSide : v; }();
+	const int n_streams = mpa_ctx_s::kSide;
 	auto begin_side = [&](bool is_ext) -> hipStream_t {
 		const int k = n_side++;
 		hipStream_t st = ctx->side[(k + ctx->side_off) % n_streams];
@@ -1588,9 +1461,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	// rowkey slots follow the order of the wave descriptors (classes 3, 4, 5, 6)
 	int64_t rk_first[kNumExtClasses] = { 0 };
 	{ int64_t at = 0; for (int cls = 3; cls < kNumExtClasses; ++cls) rk_first[cls] = at, at += ewave_cnt[cls]; }
-	// MPA_ONE_LAUNCH (default 1): every DP unit of the round in ONE k_dp_round launch on the context's main stream; 0 = one
-	// launch per kernel class on side streams (the round-1 executor, kept for comparison)
-	static const bool one_launch = [] { const char *e = getenv("MPA_ONE_LAUNCH"); return e ? atoi(e) != 0 : true; }();
+	// every DP unit of the round goes out in ONE k_dp_round launch on the context's main stream
 	GlobArgs ga;
 	ga.tasks = ctx->tasks.as<DTask>(), ga.rec = ctx->rec.as<uint32_t>(), ga.prof = ctx->prof.as<int16_t>();
 	ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc, ga.rowkey64 = nullptr, ga.waves = nullptr;
@@ -1631,11 +1502,10 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		DpUnit *units = (DpUnit*)(hup + up_units);          // (pinned: the copy below needs no wait)
 		const size_t n_units = cu.size();
 		if (sizeof(DpUnit) * n_units > up_off - up_units) { set_error("internal: more DP units than the staging buffer holds"); return MPA_ERR_HIP; }
-		// MPA_UNIT_PRIO (default 1): the units that bound the round's duration issue ahead of the short ones they share a SIMD with
-		static const bool unit_prio = [] { const char *e = getenv("MPA_UNIT_PRIO"); return e ? atoi(e) != 0 : true; }();
+		// the units that bound the round's duration issue ahead of the short ones they share a SIMD with (s_setprio in k_dp_round)
 		for (size_t k = 0; k < cu.size(); ++k) {
 			units[k] = cu[k].u;
-			if (unit_prio) units[k].pad_ = cu[k].cost * 2 >= cu[0].cost ? 3 : cu[k].cost * 4 >= cu[0].cost ? 2 : cu[k].cost * 10 >= cu[0].cost ? 1 : 0;
+			units[k].pad_ = cu[k].cost * 2 >= cu[0].cost ? 3 : cu[k].cost * 4 >= cu[0].cost ? 2 : cu[k].cost * 10 >= cu[0].cost ? 1 : 0;
 		}
 		int rc2;
 		if ((rc2 = ctx->units.ensure(n_units * sizeof(DpUnit)))) return rc2;
@@ -1666,23 +1536,6 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		ctx->stats.launches_ext++;
 		return MPA_OK;
 	};
-	if (!one_launch && ewave_cnt[5] + ewave_cnt[6] > 0) {                              // the two widest classes first: four / two workgroups per pair of calls
-		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[5];
-		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[5] * 2 * key_stride;
-		hipStream_t st = begin_side(true);
-		HIP_TRY(launch_ext_wide_split(wa, ewave_cnt[5], ewave_cnt[6], st));
-		end_side();
-		ctx->stats.launches_ext++;
-	}
-	for (int cls = 4; cls >= 3 && !one_launch; --cls) {
-		if (ewave_cnt[cls] == 0) continue;
-		wa.waves = ctx->waves.as<ExtWave>() + ewave_first[cls];
-		wa.rowkey = ctx->rowkey.as<uint32_t>() + rk_first[cls] * 2 * key_stride;
-		hipStream_t st = begin_side(true);
-		HIP_TRY(launch_ext_wide_class(cls, wa, ewave_cnt[cls], st));
-		end_side();
-		ctx->stats.launches_ext++;
-	}
 	if (!huge_ids.empty()) {                                           // block-major sweep with the traceback kernel's arithmetic, then the replay
 		GlobArgs ha;
 		ha.tasks = ctx->tasks.as<DTask>(), ha.waves = d_hw, ha.rec = ctx->rec.as<uint32_t>(), ha.prof = ctx->prof.as<int16_t>();
@@ -1693,13 +1546,6 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		hipLaunchKernelGGL(k_ext_replay, dim3((unsigned)huge_ids.size()), dim3(64), 0, st, ctx->tasks.as<DTask>(), d_hlist, (int32_t)huge_ids.size(),
 		                   ctx->hkey.as<unsigned long long>(), ctx->extout.as<ExtOut>(), dc, pen);
 		HIP_TRY(hipGetLastError());
-		end_side();
-		ctx->stats.launches_ext++;
-	}
-	if (!one_launch && ewave_cnt[0] + ewave_cnt[1] + ewave_cnt[2] > 0) { // the narrow classes share one launch
-		ea.waves = ctx->waves.as<ExtWave>();
-		hipStream_t st = begin_side(true);
-		HIP_TRY(launch_ext_narrow(ea, ewave_first.data(), ewave_cnt.data(), st));
 		end_side();
 		ctx->stats.launches_ext++;
 	}
@@ -1764,7 +1610,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		// every launch on its own stream (next to the extension classes in the first round); the walk needs them all
 		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
 		const size_t first_glob_launch = launches.size();
-		const bool in_round = one_launch && ri == 0;                       // the first chunk's calls ride in the round's one launch
+		const bool in_round = ri == 0;                       // the first chunk's calls ride in the round's one launch
 		if (in_round) {
 			if ((rc = launch_round(first, cnt, &gwaves, d_gw)) != MPA_OK) return rc;
 			ctx->stats.launches_glob++;
@@ -1792,7 +1638,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		HIP_TRY(hipEventRecord(ctx->ev[5], s));
 		glob_timed = true;                                                // (ev[3..5] are read after the next wait)
 	}
-	if (one_launch && !round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
+	if (!round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
 	mark("    dp: (round without traceback launched)");
 	// ---- join
 	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
@@ -1933,6 +1779,8 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 }
 
 int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx) { return ctx ? ctx->handoff_retries : 0; }
+int64_t mpa_device_bytes(void) { return (int64_t)g_dev_bytes.load(); }
+int64_t mpa_pool_growths(void) { return (int64_t)g_pool_growths.load(); }
 
 } // extern "C"
 

@@ -608,17 +608,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 // occupies a hardware queue and a stream of batches keeps several rounds in flight (dp_exec.hip).
 struct NarrowMap { int32_t first[4], cnt[4]; };
 
-__global__ __launch_bounds__(64) void k_ext_narrow(ExtArgs a, NarrowMap m)
-{
-	int b = blockIdx.x;
-	extern __shared__ uint32_t lds_raw[];
-	const WavePos wp = whole_block((char*)lds_raw);
-	if (b < m.cnt[0]) { ext_narrow<16>(a, a.waves + m.first[0] + b, wp); return; }
-	b -= m.cnt[0];
-	if (b < m.cnt[1]) { ext_narrow<32>(a, a.waves + m.first[1] + b, wp); return; }
-	b -= m.cnt[1];
-	ext_narrow<64>(a, a.waves + m.first[2] + b, wp);
-}
+
 
 // ------------------------------------------------------------------------------------------------
 // K1-wide: extension calls wider than 64 columns.  One workgroup of NW waves per pair of calls (the two
@@ -961,30 +951,9 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 	}
 }
 
-template<int NW>
-__global__ __launch_bounds__(NW * 64) void k_ext_wide(ExtWideArgs a)
-{
-	extern __shared__ uint32_t lds_raw[];
-	ext_wide_body<NW, false>(a, (int)blockIdx.x, SplitPos{ 0, 0, 1, 0 }, whole_block((char*)lds_raw));
-}
 
-// The two widest classes (513..1024 columns: four workgroups per pair of calls; 257..512: two) in one launch of 256-thread
-// workgroups.  Workgroups of a group are consecutive and in column order, so a workgroup's left neighbour is always
-// dispatched before it; a.waves = the 1024-column groups first (n16 of them), then the 512-column ones.
-struct SplitMap { int32_t n16, n8, first16, first8; };
-__global__ __launch_bounds__(256) void k_ext_wide_split(ExtWideArgs a, SplitMap m)
-{
-	const int bid = (int)blockIdx.x;
-	SplitPos pos;
-	int widx;
-	if (bid < 4 * m.n16) pos.group = bid >> 2, pos.blk = bid & 3, pos.n_blk = 4, pos.xg_first = 3 * pos.group, widx = m.first16 + pos.group;
-	else {
-		const int k = bid - 4 * m.n16;
-		pos.group = m.n16 + (k >> 1), pos.blk = k & 1, pos.n_blk = 2, pos.xg_first = 3 * m.n16 + (k >> 1), widx = m.first8 + (k >> 1);
-	}
-	extern __shared__ uint32_t lds_raw[];
-	ext_wide_body<4, true>(a, widx, pos, whole_block((char*)lds_raw));
-}
+
+
 
 // ------------------------------------------------------------------------------------------------
 // K2: global alignment with traceback.  int32 arithmetic, one column per lane, one call per group of

@@ -58,15 +58,11 @@ struct QueryState {
 	std::vector<uint64_t> seeds;         // kept seeds (query position << 32 | index bucket), ascending; only between the seeding sub-stages
 	std::vector<uint64_t> ext_refine;    // per region: window extension limits of the refinement (between the planning sub-stages)
 	int64_t win0 = 0;                    // first refinement window of this query in the batch's list (device refinement)
-	std::vector<uint64_t> pre;           // the pre-chain's survivors, between the two halves of planning when the main chain's forward pass runs on the device
-	std::vector<std::vector<uint64_t>> ref_pairs;   // per region: the refinement's anchor pairs, likewise for the refinement chains
 	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
 	std::vector<mpa_dp_task_t> local2;   // likewise for round 2 (the retries)
 	int64_t base2 = 0;
-	std::vector<mpa_dp_task_t> local_gap;   // anchor-gap traceback calls when they are deferred to round 3 (mpa_batch_s::defer_gaps)
-	int64_t base_gap = 0;
 };
 
 } // namespace mpa
@@ -90,9 +86,6 @@ struct mpa_batch_s {
 	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
 	std::vector<QueryState> qs;
 	std::vector<mpa_dp_task_t> tasks;
-	bool defer_gaps = false;         // the traceback calls between kept anchors go out with round 3 instead of round 1: the same
-	                                 // work, but a round then has at most ~3 long kernels in flight, which lets three batches share
-	                                 // the hardware queues (MPA_DEFER_GAPS)
 	bool seeded_on_device = false;   // between the two seeding phases: `sparse` holds the device's pre-chain result
 	PrechainSparse sparse;
 };
@@ -167,7 +160,6 @@ static void trace(const char *stage, int32_t batch, const char *what)
 
 static thread_local int tl_pool_lane = 0;
 static thread_local int tl_thread_div = 1;          // pipeline stages with light host work take a fraction of the threads
-static thread_local int tl_unit_parts = 1;          // the unit being seeded / planned is one of this many parts of a mini-batch (the device-stage thresholds are per batch)
 template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 {
 	std::function<void(int64_t)> f = fn;
@@ -180,6 +172,14 @@ template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 
 // per-substage CPU-time accumulators of stage A (thread CPU time summed over the workers; printed with MPA_TIMING=1)
 static std::atomic<int64_t> g_acc[16];
+// wall-clock microseconds and calls of the stream pipeline's stages since the last reset (mpa_stage_clocks): 0 seeding, 1 planning,
+// 2 DP rounds of a batch (all of them, host round trips included), 3 output (flatten + text)
+static std::atomic<int64_t> g_stage_us[4], g_stage_n[4];
+struct StageClock {
+	int k; double t0;
+	explicit StageClock(int k_) : k(k_), t0(now_ms()) {}
+	~StageClock() { g_stage_us[k] += (int64_t)((now_ms() - t0) * 1000.0), ++g_stage_n[k]; }
+};
 static const char *const kAccName[16] = { "A.sketch+lookup", "A.sort anchors", "A.pre-chain", "A.chain", "A.regions", "A.refine", "A.plan", "A.round-1 plan",
 	"  refine: fetch window", "  refine: sketch nt4", "  refine: sketch prot+sort", "  refine: pairs+sort", "  refine: chain", "  refine: n regions", "  anchors (x1000, all queries / threads)", "  pre-chain survivors (x1000)" };
 // (thread CPU time, not wall time: under a CPU quota the wall time of a thread says how often it was throttled, not what it cost)
@@ -583,8 +583,7 @@ static inline ChainParams main_chain_params(const mpa_idx_s *mi, const mpa_mapop
 }
 
 static void stage_windows_from_chains(mpa_batch_s *b, QueryState &qs, const std::vector<uint64_t> &u, const std::vector<uint64_t> &a);
-// f/pred != nullptr: the forward pass of the main chain ran on the device (dev_chain_forward)
-static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a, const int32_t *f = nullptr, const int32_t *pred = nullptr)
+static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<uint64_t> &a)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
@@ -593,7 +592,7 @@ static void stage_chain_to_windows(mpa_batch_s *b, QueryState &qs, std::vector<u
 	u.clear();
 	const ChainParams cp = main_chain_params(mi, opt);
 	(void)is_splice;
-	{ AccTimer tm(3); if (f) chain_anchors_after_forward(cp, f, pred, a, u); else chain_anchors(cp, a, u); }
+	{ AccTimer tm(3); chain_anchors(cp, a, u); }
 	stage_windows_from_chains(b, qs, u, a);
 }
 
@@ -622,25 +621,8 @@ static inline void refine_window(const mpa_idx_s *mi, const Region &r, uint64_t 
 }
 
 // (4) refinement of every region (with the device's scan results if there are any), then the alignment plans
-// (4a) only the anchor pairs of every region's refinement (the chains follow once their forward pass has run on the device)
-static void stage_refine_pairs(mpa_batch_s *b, QueryState &qs, const RefineHits *rh)
-{
-	AccTimer tm(5);
-	const mpa_mapopt_t &opt = b->opt;
-	RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
-	qs.ref_pairs.resize(qs.regs.size());
-	for (size_t i = 0; i < qs.regs.size(); ++i) {
-		const int64_t w = qs.win0 + (int64_t)i;
-		refine_region_pairs(b->mi, opt, rq, qs.regs[i], (int32_t)(qs.ext_refine[i] >> 32), (int32_t)qs.ext_refine[i],
-		                    rh ? rh->hits.data() + rh->first[w] : nullptr, rh ? rh->first[w + 1] - rh->first[w] : 0, qs.ref_pairs[i]);
-	}
-}
-
-// pairs_ready: stage_refine_pairs() has run; fwd != nullptr: the forward passes of the refinement chains come from the device,
-// fwd_first[w] = offset of refinement window w (= qs.win0 + region) in fwd->f / fwd->pred
 // rc != nullptr: the whole refinement ran on the device (dev_refine_chains): the chains of refinement window w = qs.win0 + region
-static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh, bool pairs_ready = false, const ChainIO *fwd = nullptr,
-                                 const int64_t *fwd_first = nullptr, const RefineChains *rc = nullptr)
+static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHits *rh, const RefineChains *rc = nullptr)
 {
 	const mpa_idx_s *mi = b->mi;
 	const mpa_mapopt_t &opt = b->opt;
@@ -656,14 +638,6 @@ static void stage_refine_to_plan(mpa_batch_s *b, QueryState &qs, const RefineHit
 				refine_region_from_chains(mi, opt, regs[i], (int32_t)(ext[i] >> 32), rc->U + rc->u_first[w], rc->u_first[w + 1] - rc->u_first[w], rc->A + rc->a_first[w]);
 				if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
 			}
-		} else if (pairs_ready) {
-			for (size_t i = 0; i < regs.size(); ++i) {
-				const int64_t w = qs.win0 + (int64_t)i;
-				if (fwd) refine_region_chain(mi, opt, regs[i], (int32_t)(ext[i] >> 32), qs.ref_pairs[i], fwd->f + fwd_first[w], fwd->pred + fwd_first[w]);
-				else refine_region_chain(mi, opt, regs[i], (int32_t)(ext[i] >> 32), qs.ref_pairs[i]);   // (the device declined: host pass over the pairs)
-				if (regs[i].cnt > 0) kept.push_back(std::move(regs[i]));
-			}
-			std::vector<std::vector<uint64_t>>().swap(qs.ref_pairs);
 		} else {
 			RefineQuery rq(qs.seq, qs.qlen, opt.kmer2, rh == nullptr);
 			for (size_t i = 0; i < regs.size(); ++i) {
@@ -762,7 +736,7 @@ static void plan_round1(mpa_batch_s *b, QueryState &qs)
 			if (!(r.a[i] >> 31 & 1)) continue;
 			const int32_t ne1 = (int32_t)(r.a[i] >> 32) + 1, ae1 = (int32_t)((uint32_t)r.a[i] << 1 >> 1) + 1;
 			pl.gaps.emplace_back();
-			make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, qs.qid, (int32_t)pi, b->defer_gaps ? qs.local_gap : qs.local1, pl.gaps.back());
+			make_segment(b, qs, r, pl, ne0, ne1, ae0, ae1, qs.qid, (int32_t)pi, qs.local1, pl.gaps.back());
 			ne0 = ne1, ae0 = ae1;
 		}
 	}
@@ -789,7 +763,7 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, con
 			AlignPlan &pl = qs.plans[pi];
 			const Region &r = qs.regs[pl.reg];
 			const mpa_dp_rst_t *mine = rst + qs.base1;                 // this query's slice of the round-1 results
-			if (!b->defer_gaps) for (Segment &g : pl.gaps) store_result(g, mine, pool);
+			for (Segment &g : pl.gaps) store_result(g, mine, pool);
 			pl.l_nt = mine[pl.t_left].nt_len, pl.l_aa = mine[pl.t_left].aa_len;
 			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
 				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
@@ -816,7 +790,6 @@ static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, con
 
 static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 {
-	const mpa_mapopt_t &opt = b->opt;
 	std::vector<mpa_dp_task_t> next;
 	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
 		QueryState &qs = b->qs[qi];
@@ -838,12 +811,6 @@ static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
 			}
 		}
 	}
-	if (b->defer_gaps)
-		for (QueryState &qs : b->qs) {
-			qs.base_gap = (int64_t)next.size();
-			next.insert(next.end(), qs.local_gap.begin(), qs.local_gap.end());
-			std::vector<mpa_dp_task_t>().swap(qs.local_gap);
-		}
 	b->tasks.swap(next);
 }
 
@@ -857,7 +824,6 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 			r.cigar.clear();
 			if (pl.has_left_span) store_result(pl.left_span, rst, pool);
 			if (pl.has_right_span) store_result(pl.right_span, rst, pool);
-			if (b->defer_gaps && rst) for (Segment &g : pl.gaps) store_result(g, rst + qs.base_gap, pool);
 			auto add = [&](const Segment &s) {
 				for (uint32_t c : s.cigar) append_cigar(r.cigar, c & 0xf, (int32_t)(c >> 4));
 				score += s.score;
@@ -896,15 +862,12 @@ static const int64_t kDeviceSeedingMinAnchors = 8000000;
 
 // Phase 1 of a batch: seeds of every query; with a device context and a batch that is worth it, also the anchors, their
 // sort and the forward pass of the pre-chain (seed_exec.hip).
-static int gpu_chain_mode();
-static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, bool want_chains = true)
+static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, bool want_chains = true, SeedHold *hold = nullptr)
 {
-	if (gpu_chain_mode() != 0) want_chains = false;
 	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
 	mpa_batch_s *b = new mpa_batch_s();
 	b->mi = mi, b->opt = *opt, b->q = *q, b->n_threads = n_threads > 1 ? n_threads : 1;
 	mpa_dpopt_from_mapopt(opt, &b->dpopt);
-	{ const char *e = getenv("MPA_DEFER_GAPS"); b->defer_gaps = e ? atoi(e) != 0 : false; }
 	b->qs.resize(q->n_seq);
 	for (int32_t i = 0; i < q->n_seq; ++i) {
 		b->qs[i].qid = i, b->qs[i].seq = q->seqs + q->q_off[i], b->qs[i].qlen = (int32_t)(q->q_off[i + 1] - q->q_off[i]);
@@ -921,7 +884,7 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	static thread_local std::vector<SeedJob> jobs;
 	qfirst.assign((size_t)q->n_seq + 1, 0), jfirst.assign((size_t)q->n_seq + 1, 0);
 	for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
-	if (mode < 0 && qfirst[q->n_seq] * tl_unit_parts < kDeviceSeedingMinAnchors) return b;
+	if (mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) return b;
 	if (jobs.size() < jfirst[q->n_seq]) jobs.resize(jfirst[q->n_seq]);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
 	// (pointers, not the thread_local vectors: the workers have their own, empty, instances of those)
@@ -943,7 +906,7 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	// arrangement -- forward passes on the device, extraction on the host -- or the caller only wants the pre-chain)
 	const ChainParams main_cp = main_chain_params(mi, *opt);
 	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse,
-	                                    want_chains ? &main_cp : nullptr);
+	                                    want_chains ? &main_cp : nullptr, hold);
 	if (rc == MPA_ERR_UNSUPPORTED) {                    // e.g. the batch does not fit the device: seed on the host
 		if (timing_on()) fprintf(stderr, "[mpa-timing]   device seeding declined (%s): seeding on the host\n", mpa_last_error());
 		return b;
@@ -1005,82 +968,25 @@ static void query_groups(const char *aa, int32_t l_aa, int32_t k, QueryGroups &o
 	}
 }
 
-// MPA_GPU_REFINE_CHAINS (default 1): with the device refinement engaged, pairing, pair sort and the refinement chains run on the
-// device too (dev_refine_chains); 0 = scan on the device, pairing and chaining on the host (rounds 1-2)
-static bool gpu_refine_chains_mode()
-{
-	const char *e = getenv("MPA_GPU_REFINE_CHAINS");
-	return e ? atoi(e) != 0 : true;
-}
-
-// MPA_GPU_CHAIN=1: the forward passes of the main chain and of the refinement chains on the device (k_chain_fwd); default: on
-// the host.  Measured at config 3 (3 Gbp x 20 000 proteins, three DP lanes, 64 host threads): 0.96-1.01 s with the host passes,
-// 1.09-1.11 s with the device passes -- the pass itself is 24-28 ms per 2 000-protein batch next to three DP rounds in flight
-// (19 M anchors up, f/pred down) and it cuts the planning stage's one parallel region in two; the host pass it replaces is
-// about a third of the main-chain work, the extraction (which has to stay on the host) the rest.
-static int gpu_chain_mode()
-{
-	const char *e = getenv("MPA_GPU_CHAIN");
-	return e ? (atoi(e) != 0 ? 1 : 0) : 0;
-}
-
 static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 {
 	const double t0 = now_ms();
 	const int64_t n_q = (int64_t)b->qs.size();
-	const int chain_mode = gpu_chain_mode();
-	bool dev_chain = rctx && chain_mode != 0;
-	if (!dev_chain) {
-		parallel_for(b->n_threads, n_q, [&](int64_t i) {
-			static thread_local std::vector<uint64_t> a, u;
-			const PrechainSparse &ps = b->sparse;
-			if (b->seeded_on_device && ps.has_chains && !(!ps.on_host.empty() && ps.on_host[(size_t)i])) {
-				// both chaining rounds ran on the device: its chains are what mp_chain() returns for this query (map.c:195)
-				g_acc[14] += b->qs[i].n_anchor * 1000;
-				u.assign(ps.U + ps.u_first[(size_t)i], ps.U + ps.u_first[(size_t)i + 1]);
-				a.assign(ps.A + ps.a_first[(size_t)i], ps.A + ps.a_first[(size_t)i + 1]);
-				stage_windows_from_chains(b, b->qs[i], u, a);
-				return;
-			}
-			if (b->seeded_on_device && !ps.has_chains) stage_anchors_from_device(b, b->qs[i], ps, a);
-			else stage_anchors_host(b, b->qs[i], a);
-			stage_chain_to_windows(b, b->qs[i], a);
-		});
-	} else {
-		// the pre-chain's survivors of every query first; then the forward pass of all main chains in one k_chain_fwd launch
-		// (chain.c:181-209; one thread per independent run of anchors), then extraction and the rest per query
-		parallel_for(b->n_threads, n_q, [&](int64_t i) {
-			if (b->seeded_on_device) stage_anchors_from_device(b, b->qs[i], b->sparse, b->qs[i].pre);
-			else stage_anchors_host(b, b->qs[i], b->qs[i].pre);
-		});
-		static thread_local std::vector<int64_t> first;
-		first.assign((size_t)n_q + 1, 0);
-		for (int64_t i = 0; i < n_q; ++i) first[i + 1] = first[i] + (int64_t)b->qs[i].pre.size();
-		ChainIO io;
-		int rc = MPA_ERR_UNSUPPORTED;
-		{
-			const double t1 = now_ms();
-			if ((rc = dev_chain_buffers(rctx, first[n_q], io)) == MPA_OK) {
-				const int64_t *fp = first.data();
-				uint64_t *dst = io.a;
-				parallel_for(b->n_threads, n_q, [&, fp, dst](int64_t i) {
-					const std::vector<uint64_t> &v = b->qs[i].pre;
-					if (!v.empty()) memcpy(dst + fp[i], v.data(), v.size() * 8);
-				});
-				rc = dev_chain_forward(rctx, main_chain_params(b->mi, b->opt), (int32_t)n_q, first.data(), io);
-			}
-			timing_note("  main chains: forward pass on the GPU", now_ms() - t1);
+	parallel_for(b->n_threads, n_q, [&](int64_t i) {
+		static thread_local std::vector<uint64_t> a, u;
+		const PrechainSparse &ps = b->sparse;
+		if (b->seeded_on_device && ps.has_chains && !(!ps.on_host.empty() && ps.on_host[(size_t)i])) {
+			// both chaining rounds ran on the device: its chains are what mp_chain() returns for this query (map.c:195)
+			g_acc[14] += b->qs[i].n_anchor * 1000;
+			u.assign(ps.U + ps.u_first[(size_t)i], ps.U + ps.u_first[(size_t)i + 1]);
+			a.assign(ps.A + ps.a_first[(size_t)i], ps.A + ps.a_first[(size_t)i + 1]);
+			stage_windows_from_chains(b, b->qs[i], u, a);
+			return;
 		}
-		if (rc != MPA_OK) dev_chain = false;                  // too small to be worth it, or declined: everything on the host
-		const bool fwd = rc == MPA_OK;
-		const int64_t *fp = first.data();
-		parallel_for(b->n_threads, n_q, [&, fp, fwd](int64_t i) {
-			QueryState &qs = b->qs[i];
-			if (fwd) stage_chain_to_windows(b, qs, qs.pre, io.f + fp[i], io.pred + fp[i]);
-			else stage_chain_to_windows(b, qs, qs.pre);
-			std::vector<uint64_t>().swap(qs.pre);
-		});
-	}
+		if (b->seeded_on_device && !ps.has_chains) stage_anchors_from_device(b, b->qs[i], ps, a);
+		else stage_anchors_host(b, b->qs[i], a);
+		stage_chain_to_windows(b, b->qs[i], a);
+	});
 	b->sparse = PrechainSparse();
 	timing_note("  plan: anchors..windows (wall)", now_ms() - t0);
 	const double t_a = now_ms();
@@ -1105,7 +1011,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 				n_bases += ae - as;
 			}
 		}
-		if (!wins.empty() && (mode == 1 || n_bases * tl_unit_parts >= kDeviceRefineMinBases) && gpu_refine_chains_mode() && !dev_chain && b->opt.kmer2 <= 6) {
+		if (!wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
 			// the whole refinement on the device: groups of every query (in parallel), then scan + pairing + sort + chains
 			static thread_local std::vector<QueryGroups> per;
 			static thread_local RefineGroupsHost G;
@@ -1133,7 +1039,7 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 			timing_note("  refinement on the GPU (scan + pairs + chains)", now_ms() - t1);
 			chains_on_device = rc == MPA_OK;                   // anything else: the scan alone below, or the host
 		}
-		if (!chains_on_device && !wins.empty() && (mode == 1 || n_bases * tl_unit_parts >= kDeviceRefineMinBases)) {
+		if (!chains_on_device && !wins.empty() && (mode == 1 || n_bases >= kDeviceRefineMinBases)) {
 			std::vector<uint32_t> w;
 			qw_first.assign((size_t)n_q + 1, 0), qwords.clear();
 			for (int64_t i = 0; i < n_q; ++i) {
@@ -1151,35 +1057,9 @@ static void batch_plan_phase(mpa_batch_s *b, mpa_ctx_t *rctx)
 	const RefineHits *rhp = on_device ? &rh : nullptr;
 	timing_note("  plan: windows + scan (wall)", now_ms() - t_a);
 	const double t_b = now_ms();
-	// the refinement chains (base resolution, chain.c:123-139): with the device, their forward passes in one launch too
-	ChainIO rio;
-	static thread_local std::vector<int64_t> rfirst;
-	bool ref_fwd = false;
-	if (dev_chain) {
-		int64_t n_win = 0;
-		for (int64_t i = 0; i < n_q; ++i) b->qs[i].win0 = n_win, n_win += (int64_t)b->qs[i].regs.size();   // (the same numbering as the device scan's)
-		parallel_for(b->n_threads, n_q, [&, rhp](int64_t i) { stage_refine_pairs(b, b->qs[i], rhp); });
-		rfirst.assign((size_t)n_win + 1, 0);
-		for (int64_t i = 0; i < n_q; ++i)
-			for (size_t r = 0; r < b->qs[i].regs.size(); ++r) rfirst[(size_t)b->qs[i].win0 + r + 1] = (int64_t)b->qs[i].ref_pairs[r].size();
-		for (int64_t w = 0; w < n_win; ++w) rfirst[(size_t)w + 1] += rfirst[(size_t)w];
-		if (n_win > 0 && rfirst[(size_t)n_win] > 0 && dev_chain_buffers(rctx, rfirst[(size_t)n_win], rio) == MPA_OK) {
-			const int64_t *fp = rfirst.data();
-			uint64_t *dst = rio.a;
-			parallel_for(b->n_threads, n_q, [&, fp, dst](int64_t i) {
-				const QueryState &qs = b->qs[i];
-				for (size_t r = 0; r < qs.regs.size(); ++r)
-					if (!qs.ref_pairs[r].empty()) memcpy(dst + fp[qs.win0 + (int64_t)r], qs.ref_pairs[r].data(), qs.ref_pairs[r].size() * 8);
-			});
-			ref_fwd = dev_chain_forward(rctx, refine_chain_params(b->opt), (int32_t)n_win, rfirst.data(), rio) == MPA_OK;
-		}
-	}
-	const ChainIO *riop = ref_fwd ? &rio : nullptr;
-	const int64_t *rfp = rfirst.data();
-	const bool pairs_ready = dev_chain;
 	const RefineChains *rcp = chains_on_device ? &rchains : nullptr;
-	parallel_for(b->n_threads, n_q, [&, rhp, riop, rfp, pairs_ready, rcp](int64_t i) {
-		stage_refine_to_plan(b, b->qs[i], rhp, pairs_ready, riop, rfp, rcp);
+	parallel_for(b->n_threads, n_q, [&, rhp, rcp](int64_t i) {
+		stage_refine_to_plan(b, b->qs[i], rhp, rcp);
 		AccTimer tm(7);
 		plan_round1(b, b->qs[i]);
 	});
@@ -1508,26 +1388,6 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 
 // Several mini-batches as a three-stage software pipeline: [seed..plan of batch k+1] | [DP rounds of batch k on the GPU]
 // | [flatten + format batch k-1].  Each stage is one host thread driving its own worker-pool lane.
-// the results of consecutive slices of a batch (slice s starts at query q0[s]) as the result of the whole batch; frees the parts
-static mpa_result_t *merge_results(const std::vector<mpa_result_t*> &parts, const std::vector<int32_t> &q0, int32_t n_seq)
-{
-	mpa_result_s *res = new mpa_result_s();
-	res->n_seq = n_seq;
-	res->hit_off.assign((size_t)n_seq + 1, 0);
-	for (size_t s = 0; s < parts.size(); ++s) {
-		mpa_result_s *p = parts[s];
-		if (!p) continue;
-		const int64_t h0 = (int64_t)res->hits.size(), c0 = (int64_t)res->cigars.size(), f0 = (int64_t)res->feats.size();
-		for (int32_t i = 0; i < p->n_seq; ++i) res->hit_off[(size_t)q0[s] + i] = h0 + p->hit_off[i];
-		for (mpa_hit_t h : p->hits) { h.qid += q0[s], h.cigar_off += c0, h.feat_off += f0; res->hits.push_back(h); }
-		res->cigars.insert(res->cigars.end(), p->cigars.begin(), p->cigars.end());
-		res->feats.insert(res->feats.end(), p->feats.begin(), p->feats.end());
-		delete p;
-	}
-	res->hit_off[(size_t)n_seq] = (int64_t)res->hits.size();
-	return res;
-}
-
 // claim != nullptr: the job's batches are handed out by the caller -- claim(user) returns the index (into batches[]) of the next
 // batch this call should map, or -1 when the job has none left -- so that several callers (one process per GPU) can share one
 // job and each takes work as fast as it gets through it (the kt_for work stealing of map.c:264-271, between processes).
@@ -1540,30 +1400,14 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
 	g_trace_t0 = now_ms();
-	// What moves through the pipeline is a UNIT: a whole mini-batch, or -- for the first and the last mini-batches of the stream -- a
-	// quarter of one.  A stream of K batches takes (K - 1) steps plus the time ONE batch needs to get through all stages (seeding,
-	// planning, three DP rounds: ~0.6 s at config 3); while the pipeline fills and drains most of the GPU idles.  The DP rounds of a
-	// quarter batch last as long as those of a whole one (a round is as long as its longest window), but its seeding and planning
-	// take a quarter of the time and the quarters run side by side on the lanes, so the first DP round starts ~0.25 s earlier and
-	// the last one ends ~0.25 s earlier.  Results and text of a split batch are merged back: the caller sees whole batches
-	// (MPA_EDGE_SPLIT = parts; default 1 = off, see below).
-	// Measured (config 3, 5 warm-up + 20 timed steps, profiles/r03_experiments.txt): OFF by default.  The device pools of a lane or a
-	// seeding context are grow-only and sized by the first units it sees; a context that met only quarter batches in the warm-up
-	// stream re-grows every pool when its first whole batch arrives in the timed one (hipFree waits for the whole device): 6.9-10.9 M
-	// residues/s against 17.7 M without the split.  In a long stream the pools settle and the split does what it is meant to; it is
-	// kept as an opt-in (and tested for identity), MPA_EDGE_SPLIT_HEAD=1 splits the first batches as well.
-	const int edge_parts = [] { const char *e = getenv("MPA_EDGE_SPLIT"); const int v = e ? atoi(e) : 1; return v < 2 ? 1 : v > 8 ? 8 : v; }();
-	const bool edge_head = [] { const char *e = getenv("MPA_EDGE_SPLIT_HEAD"); return e && atoi(e) != 0; }();
-	const int edge_batches = 2;                           // how many batches at either end are split
-	const int edge_min = [] { const char *e = getenv("MPA_EDGE_SPLIT_MIN"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();   // a part has at least this many queries (the tests lower it)
 	struct Slot {
 		mpa_batch_t *b = nullptr;
 		int32_t g = 0, j = 0;                             // index into batches[]; ordinal of the batch among those this call maps
-		int32_t part = 0, n_parts = 1, q0 = 0;            // which part of the batch, and its first query
-		mpa_qbatch_t q{};                                 // the unit's queries (a slice of batches[g])
+		mpa_qbatch_t q{};                                 // the batch's queries
 		bool seeded = false, begun = false, dp_done = false;
 	};
-	std::vector<Slot> slot((size_t)n_batches * (size_t)edge_parts);
+	std::vector<Slot> slot((size_t)n_batches);
+	std::vector<uint8_t> taken((size_t)n_batches, 0);   // batches a claim has handed out already
 	std::mutex mu, claim_mu;
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK, next_seed = 0, next_plan = 0;
@@ -1584,7 +1428,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
 	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
 	// third context land on the queues of the second one's (measured, rocprofv3 queue ids), three further on they do not
-	{ const char *e = getenv("MPA_LANE2_SIDE_OFF"); if (n_lanes > 2) ctx_set_side_offset(lane_ctx[2], e ? atoi(e) : 3); }
+	if (n_lanes > 2) ctx_set_side_offset(lane_ctx[2], 3);
 	// Planners: the planning stage (pre-chain extraction, chaining, refinement, plans) is memory-bound host work that gains
 	// nothing from more than ~32 threads, so two batches are planned side by side with half the threads each
 	// (MPA_PLANNERS, default 2).  The seeder's own streams and buffers, one set per batch that can be between seeding and
@@ -1600,15 +1444,16 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	n_seed = std::max(1, std::min(n_seed, 4));
 	// Depth of the pipeline.  A seeding context is busy from the start of a batch's seeding to the end of its planning, and a
 	// planned batch waits for a DP lane: seeding of batch k waits for the plan of batch k - n_seed_ctx, the plan of batch k for
-	// the end of the DP of batch k - (lanes + planners).  MPA_SEED_CTX_EXTRA more contexts / MPA_PLAN_AHEAD more planned batches
-	// loosen that coupling; measured at config 3 they change nothing (70.1 vs 70.3 ms per step with 2 / 3), because the stages
-	// share one GPU whose wide, memory-bound seeding kernels are what the stream is bound by -- so the defaults stay at 0.
-	int seed_extra = 0, plan_ahead = 0;
-	if (const char *e = getenv("MPA_SEED_CTX_EXTRA")) seed_extra = std::max(0, std::min(atoi(e), 6));
-	if (const char *e = getenv("MPA_PLAN_AHEAD")) plan_ahead = std::max(0, std::min(atoi(e), 8));
-	const int n_seed_ctx = n_plan + n_seed + seed_extra;
-	std::vector<mpa_ctx_t*> seed_ctx((size_t)n_seed_ctx, nullptr);
-	for (int k = 0; k < n_seed_ctx; ++k) if (!(seed_ctx[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
+	// the end of the DP of batch k - (lanes + planners).  Deeper coupling was measured to change nothing (rounds 2-3).
+	const int plan_ahead = 0;
+	// Device contexts (streams + pools): one per seeder and one per planner.  What a seeded batch leaves for its planner is pinned
+	// host memory only (SeedHold): n_seed_ctx holders, one per batch that can be between the start of seeding and the end of planning.
+	const int n_seed_ctx = n_plan + n_seed;
+	std::vector<mpa_ctx_t*> seed_dev((size_t)n_seed, nullptr), plan_dev((size_t)n_plan, nullptr);
+	for (int k = 0; k < n_seed; ++k) if (!(seed_dev[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
+	for (int k = 0; k < n_plan; ++k) if (!(plan_dev[k] = ctx_sibling(ctx, n_lanes + n_seed + k))) return MPA_ERR_HIP;
+	std::vector<SeedHold*> hold((size_t)n_seed_ctx, nullptr);
+	for (int k = 0; k < n_seed_ctx; ++k) hold[k] = ctx_seed_hold(ctx, k);
 	static const char *const kSeedName[4] = { "seed0", "seed1", "seed2", "seed3" };
 	static const char *const kPlanName[6] = { "plan0", "plan1", "plan2", "plan3", "plan4", "plan5" };
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
@@ -1628,16 +1473,16 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 					const int32_t want = claim ? claim(claim_user) : (next_own < n_batches ? next_own++ : -1);
 					std::lock_guard<std::mutex> g(mu);
 					if (want < 0 || want >= n_batches) { exhausted = true, n_total = n_created; cv.notify_all(); return; }   // the job has no batch left
-					const mpa_qbatch_t &bq = batches[want];
-					const bool edge = (edge_head && n_claimed < edge_batches) || (want >= n_batches - edge_batches && n_batches > 2 * edge_batches);
-					const int parts = edge && bq.n_seq >= edge_min * edge_parts ? edge_parts : 1;
-					for (int p = 0; p < parts; ++p) {
-						Slot &u = slot[(size_t)n_created + p];
-						const int32_t a0 = (int32_t)((int64_t)bq.n_seq * p / parts), a1 = (int32_t)((int64_t)bq.n_seq * (p + 1) / parts);
-						u.g = want, u.j = n_claimed, u.part = p, u.n_parts = parts, u.q0 = a0;
-						u.q = mpa_qbatch_t{ a1 - a0, bq.seqs, bq.q_off + a0 };
+					// (a claim function that hands a batch out twice -- a counter that was not reset, a wrong job key -- would run the
+					// slots, results[] and order[] past the caller's arrays: an error, not heap corruption)
+					if (n_created >= n_batches || taken[(size_t)want]) {
+						if (rc_all == MPA_OK) rc_all = MPA_ERR_ARG, err = "mpa_map_batches_claim: claim() returned batch " + std::to_string(want) + " twice (or more batches than the job has)";
+						exhausted = true, n_total = n_created; cv.notify_all(); return;
 					}
-					n_created += parts, ++n_claimed;
+					taken[(size_t)want] = 1;
+					Slot &u = slot[(size_t)n_created];
+					u.g = want, u.j = n_claimed, u.q = batches[want];
+					++n_created, ++n_claimed;
 				}
 				std::lock_guard<std::mutex> g(mu);
 				k = next_seed++;                                      // (a free seeder takes the next unit in input order)
@@ -1648,8 +1493,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK) return;
 			}
 			trace(kSeedName[sd], k, "begin");
-			tl_unit_parts = tl_pool_scale = slot[k].n_parts;
-			mpa_batch_t *b = batch_seed_phase(seed_ctx[k % n_seed_ctx], mi, opt, &slot[k].q, n_threads);
+			mpa_batch_t *b;
+			{ StageClock sc(0); b = batch_seed_phase(seed_dev[sd], mi, opt, &slot[k].q, n_threads, true, hold[k % n_seed_ctx]); }
 			trace(kSeedName[sd], k, "end");
 			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1673,8 +1518,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 				if (rc_all != MPA_OK || k >= n_total) return;       // (k >= n_total: the job ran out before this slot was claimed)
 			}
 			trace(kPlanName[pl], k, "begin");
-			tl_unit_parts = tl_pool_scale = slot[k].n_parts;
-			batch_plan_phase(slot[k].b, seed_ctx[k % n_seed_ctx]);
+			{ StageClock sc(1); batch_plan_phase(slot[k].b, plan_dev[pl]); }
 			trace(kPlanName[pl], k, "end");
 			std::lock_guard<std::mutex> g(mu);
 			slot[k].begun = true, ++n_planned;
@@ -1687,9 +1531,6 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		tl_pool_lane = 1, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "output: worker pool";
 		CpuSpan cs("output: stage thread (flatten + format)");
-		std::vector<mpa_result_t*> parts;                     // the finished parts of the batch that is being assembled
-		std::vector<int32_t> part_q0;
-		std::string part_text;
 		for (int32_t k = 0; k < (int32_t)slot.size(); ++k) {
 			{
 				std::unique_lock<std::mutex> g(mu);
@@ -1698,26 +1539,14 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			}
 			trace("finish", k, "begin");
 			const Slot &u = slot[k];
+			StageClock sc(3);
 			mpa_result_t *r = mpa_batch_finish(slot[k].b);
 			slot[k].b = nullptr;
 			char *t = nullptr;
 			int64_t tl = 0;
-			if (names) tl = mpa_format_output(mi, opt, &u.q, names[u.g] + u.q0, r, id_io, &t);   // (units finish in input order: the hit ids run on)
-			if (u.n_parts == 1) { results[u.j] = r; if (names) text[u.j] = t, text_len[u.j] = tl; }
-			else {
-				parts.push_back(r), part_q0.push_back(u.q0);
-				if (names) { part_text.append(t, (size_t)tl); free(t); }
-				if (u.part == u.n_parts - 1) {                    // the batch is complete: one result, one text
-					results[u.j] = merge_results(parts, part_q0, batches[u.g].n_seq);
-					parts.clear(), part_q0.clear();
-					if (names) {
-						text[u.j] = (char*)malloc(part_text.size() + 1);
-						memcpy(text[u.j], part_text.data(), part_text.size());
-						text[u.j][part_text.size()] = 0, text_len[u.j] = (int64_t)part_text.size();
-						part_text.clear();
-					}
-				}
-			}
+			if (names) tl = mpa_format_output(mi, opt, &u.q, names[u.g], r, id_io, &t);   // (batches finish in input order: the hit ids run on)
+			results[u.j] = r;
+			if (names) text[u.j] = t, text_len[u.j] = tl;
 			trace("finish", k, "end");
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("output stage: ") + e.what()); } });
@@ -1749,8 +1578,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
 			std::vector<DpJob> jobs;
 			for (int32_t j = k; j < k_end; ++j) { trace(lane_name[d], j, "begin"); jobs.push_back(DpJob{ &slot[j].q, slot[j].b }); }
-			tl_pool_scale = k_end - k > 1 ? 1 : slot[k].n_parts;
-			const int rc = run_dp_rounds_merged(cd, mi, jobs);
+			int rc;
+			{ StageClock sc(2); rc = run_dp_rounds_merged(cd, mi, jobs); }
 			for (int32_t j = k; j < k_end; ++j) trace(lane_name[d], j, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
@@ -1762,7 +1591,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
-	tl_thread_div = 1, tl_pool_lane = 0;                   // (lane 0 ran on the caller's thread)
+	tl_thread_div = 1, tl_pool_lane = 0, tl_pool_scale = 1;   // (lane 0 ran on the caller's thread)
 	finisher.join();
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();
@@ -1783,6 +1612,15 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	return rc_all;
 }
 
+void mpa_stage_clocks(double ms[4], int64_t calls[4], int reset)
+{
+	for (int k = 0; k < 4; ++k) {
+		if (ms) ms[k] = (double)g_stage_us[k].load() / 1000.0;
+		if (calls) calls[k] = g_stage_n[k].load();
+		if (reset) g_stage_us[k] = 0, g_stage_n[k] = 0;
+	}
+}
+
 int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
 {
@@ -1801,63 +1639,7 @@ static int mpa_map_batch_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_map
 {
 	*out = nullptr;
 	if (!ctx) { set_error("mpa_map_batch needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
-	// Sub-batches: the batch is cut into a few contiguous slices that run through the stage machine concurrently, each on
-	// its own device context (streams + buffers).  Host stages of one slice overlap the GPU rounds of the others; the
-	// parallel regions of the host stages are serialised by the worker pool, which is exactly the pipelining we want.
-	int n_sub = 1;
-	if (const char *e = getenv("MPA_SUBBATCH")) n_sub = atoi(e);
-	// (measured on MI355X, round 1: no gain at 1k-4k proteins -- the slices contend for hardware queues and the worker pool -- so off by default)
-	if (n_sub < 1) n_sub = 1;
-	if (n_sub > q->n_seq) n_sub = q->n_seq > 0 ? q->n_seq : 1;
-	if (n_sub == 1) return run_batch_on(ctx, mi, opt, q, n_threads, out);
-
-	// cut points balanced by residues
-	std::vector<int32_t> cut(n_sub + 1, 0);
-	{
-		const int64_t total = q->q_off[q->n_seq] - q->q_off[0];
-		int32_t i = 0;
-		for (int s = 1; s < n_sub; ++s) {
-			const int64_t want = q->q_off[0] + total * s / n_sub;
-			while (i < q->n_seq && q->q_off[i] < want) ++i;
-			cut[s] = i;
-		}
-		cut[n_sub] = q->n_seq;
-	}
-	std::vector<mpa_result_t*> part(n_sub, nullptr);
-	std::vector<int> rc(n_sub, MPA_OK);
-	std::vector<std::string> err(n_sub);
-	std::vector<std::thread> th;
-	std::vector<mpa_ctx_t*> sub_ctx(n_sub, nullptr);
-	for (int s = 0; s < n_sub; ++s) if (!(sub_ctx[s] = ctx_sibling(ctx, s))) return MPA_ERR_HIP;   // (before any thread exists)
-	for (int s = 0; s < n_sub; ++s) {
-		mpa_ctx_t *cs = sub_ctx[s];
-		th.emplace_back([&, s, cs]() {
-			mpa_qbatch_t sq{ cut[s + 1] - cut[s], q->seqs, q->q_off + cut[s] };
-			if (sq.n_seq > 0) rc[s] = run_batch_on(cs, mi, opt, &sq, n_threads, &part[s]);
-			if (rc[s] != MPA_OK) err[s] = mpa_last_error();
-		});
-	}
-	for (auto &t : th) t.join();
-	ctx_absorb_sibling_stats(ctx);
-	for (int s = 0; s < n_sub; ++s)
-		if (rc[s] != MPA_OK) { set_error(err[s]); for (auto *p : part) delete p; return rc[s]; }
-	// merge in input order
-	mpa_result_s *res = new mpa_result_s();
-	res->n_seq = q->n_seq;
-	res->hit_off.assign((size_t)q->n_seq + 1, 0);
-	for (int s = 0; s < n_sub; ++s) {
-		mpa_result_s *p = part[s];
-		if (!p) continue;
-		const int64_t h0 = (int64_t)res->hits.size(), c0 = (int64_t)res->cigars.size(), f0 = (int64_t)res->feats.size();
-		for (int32_t i = 0; i < p->n_seq; ++i) res->hit_off[cut[s] + i] = h0 + p->hit_off[i];
-		for (mpa_hit_t h : p->hits) { h.qid += cut[s], h.cigar_off += c0, h.feat_off += f0; res->hits.push_back(h); }
-		res->cigars.insert(res->cigars.end(), p->cigars.begin(), p->cigars.end());
-		res->feats.insert(res->feats.end(), p->feats.begin(), p->feats.end());
-		delete p;
-	}
-	res->hit_off[q->n_seq] = (int64_t)res->hits.size();
-	*out = res;
-	return MPA_OK;
+	return run_batch_on(ctx, mi, opt, q, n_threads, out);
 }
 
 int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)

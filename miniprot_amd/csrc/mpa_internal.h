@@ -123,7 +123,10 @@ struct ChainIO { uint64_t *a = nullptr; int32_t *f = nullptr, *pred = nullptr; }
 int dev_chain_buffers(mpa_ctx_t *ctx, int64_t n, ChainIO &io);
 int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &p, int32_t n_prob, const int64_t *first, const ChainIO &io);
 // main != nullptr: carry on with the main chain on the device (has_chains), if the seeding mode supports it
+// hold != nullptr: the pinned result buffers live there (valid until the holder's next use) instead of in the context
+struct SeedHold;
+SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k);   // k-th result holder of a context (created on first use, owned by it)
 int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, int32_t n_query, const int64_t *qfirst,
-                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main = nullptr);
+                         const SeedJob *jobs, int64_t n_jobs, PrechainSparse &out, const ChainParams *main = nullptr, SeedHold *hold = nullptr);
 
 } // namespace mpa

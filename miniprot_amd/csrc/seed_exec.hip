@@ -1,16 +1,16 @@
 // seed_exec.hip -- GPU side of the seeding stage, included by dp_exec.hip.
 //
-// For a whole mini-batch at once:
-//   k_seed_gather   anchors of every kept seed: (query, block) key + query position      map.c:163-177
-//   rocPRIM         one stable LSD radix sort over (query, block)                          map.c:178 (radix_sort_mp64)
-//   k_prechain_fwd  forward pass of the block-resolution pre-chain                         chain.c:112-151,181-209
-//   scan + k_seed_compact   only anchors that are chained -- have a predecessor or are one -- travel back to the host
+// For a whole mini-batch at once (drivers in dp_exec.hip):
+//   k_seed_sift     the anchors of a query merged from its occurrence lists in (block, seed) order -- the order of
+//                   radix_sort_mp64 over block << 32 | query position, map.c:163-178 -- and filtered in LDS: only anchors with
+//                   another one in the same or an adjacent block survive (the only ones the pre-chain can link)
+//   k_prechain_fwd  forward pass of the block-resolution pre-chain over the kept anchors    chain.c:112-151,181-209
+//   scan + k_seed_compact   the linked anchors as a sparse view (position in the query's FULL sorted list, f, pred, anchor)
+//   k_chain_extract / k_chain_fwd / k_chain_fwd_wave   pre-chain extraction, main chain, main-chain extraction (chain.c:8-110,160-219)
 // The pre-chain only links anchors at most one 256-bp block apart, so the sorted anchors of a query fall into
 // independent "runs" (maximal stretches in which consecutive blocks differ by at most max_dblock); ~97 % of the anchors
-// at genome scale are runs of one, and of the rest about half link to nothing (wrong order or distance on the query): the
-// extraction (host, chain_extract on a sparse ChainView) never needs to see an anchor that is neither chained nor chained onto.
-// One thread walks one run with exactly the reference's loop; the arithmetic of comput_sc() includes two float
-// operations, compiled without FMA contraction like the host code.
+// at genome scale are runs of one.  One thread walks one run with exactly the reference's loop; the arithmetic of
+// comput_sc() includes two float operations, compiled without FMA contraction like the host code.
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -21,18 +21,7 @@ struct U32ToU64 { __host__ __device__ uint64_t operator()(uint32_t x) const { re
 
 struct SeedJobDev { int64_t kb_off, dst; int32_t cnt, qpos, qid, pad; };
 
-__global__ __launch_bounds__(256) void k_seed_gather(const SeedJobDev *jobs, int32_t n_jobs, const uint32_t *kb, int nb, uint64_t *key, uint32_t *val)
-{
-	MPA_SHORT_KERNEL();
-	const int32_t j = blockIdx.x;
-	if (j >= n_jobs) return;
-	const SeedJobDev s = jobs[j];
-	const uint64_t hi = (uint64_t)s.qid << nb;
-	for (int32_t k = threadIdx.x; k < s.cnt; k += 256) {
-		key[s.dst + k] = hi | kb[s.kb_off + k];
-		val[s.dst + k] = (uint32_t)s.qpos;
-	}
-}
+
 
 struct PreParams { int32_t max_dist_x, max_dist_y, bw, max_skip, max_iter, kmer, bbit, is_spliced, max_dblock; float coef_log; };
 
@@ -70,11 +59,8 @@ __device__ __forceinline__ int32_t d_link_score(uint64_t kcur, uint32_t qcur, ui
 	return sc;
 }
 
-// The value that travels with an anchor through the sort: its query position (uint32_t), or -- when the anchors were filtered
-// before the sort (k_seed_prefilter) -- query position | the number of the query's dropped anchors that sort below it << 32.
-__device__ __forceinline__ uint32_t qpos_of(uint32_t v) { return v; }
+// The value that travels with a kept anchor: query position | its rank in the query's full sorted anchor list << 32 (k_seed_sift).
 __device__ __forceinline__ uint32_t qpos_of(uint64_t v) { return (uint32_t)v; }
-__device__ __forceinline__ int32_t dropped_below(uint32_t) { return 0; }
 __device__ __forceinline__ int32_t dropped_below(uint64_t v) { return (int32_t)(v >> 32); }
 
 // one thread per anchor; the thread of a run's first anchor walks the run (mp_chain's forward loop, chain.c:181-209)
@@ -256,10 +242,9 @@ struct ExtractArgs {
 	const uint64_t *v_a;
 	// scratch, all indexed like the views; ends / stack have 64 / 5 extra entries per problem
 	int32_t *mark, *order;
-	Pair64 *ends, *tail8, *firstp;
-	SparseItem *items, *moved, *merged;
+	Pair64 *ends, *tail8;
+	SparseItem *items, *moved, *merged;   // (the chain layout's scratch -- packed anchors, sorted u, first positions -- reuses a problem's moved / merged: dead by then)
 	uint8_t *kept;
-	uint64_t *packed, *u_sorted;
 	SortRange *stack;
 	// results
 	uint64_t *a_out, *u_out;         // at first[q]
@@ -314,6 +299,7 @@ struct CoopWave {
 		for (int b = 0; b < 8; ++b) { const unsigned long long m = __ballot((d >> b) & 1); eq &= ((d >> b) & 1) ? m : ~m; }
 		*rank = __popcll(eq & ((1ull << lane()) - 1ull)), *cnt = __popcll(eq);
 	}
+	static __device__ __forceinline__ int first_unset(uint64_t m) { return m == ~0ull ? 64 : __ffsll((long long)~m) - 1; }
 	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
 };
 
@@ -328,8 +314,9 @@ __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_p
 	const int64_t n_total = x.ntot_first ? x.ntot_first[q + 1] - x.ntot_first[q] : m;
 	const ChainView v{ n_total, m, x.v_pos ? x.v_pos + off : nullptr, x.v_f + off, x.v_pred + off, x.v_a + off };
 	const int64_t eoff = off + 64 * (int64_t)q;
-	const ExtractScratch S{ x.mark + off, x.order + off, x.ends + eoff, m + 64, x.items + off, x.moved + off, x.merged + off, x.tail8 + off, x.firstp + off,
-	                        x.kept + off, x.packed + off, x.u_sorted + off, x.stack + (eoff / 64 + 5 * (int64_t)q), hist };
+	// (packed: m words, u_sorted: m words -- inside the 3 m words of THIS problem's moved list; first: m pairs inside its merged list)
+	const ExtractScratch S{ x.mark + off, x.order + off, x.ends + eoff, m + 64, x.items + off, x.moved + off, x.merged + off, x.tail8 + off, (Pair64*)(x.merged + off),
+	                        x.kept + off, (uint64_t*)(x.moved + off), (uint64_t*)(x.moved + off) + m, x.stack + (eoff / 64 + 5 * (int64_t)q), hist };
 	int64_t n_a = 0, n_u = 0;
 	const int rc = chain_extract_core<CoopWave>(x.p, v, S, x.a_out + off, &n_a, x.u_out + off, &n_u, x.set_only != 0);
 	if (threadIdx.x != 0) return;
@@ -458,8 +445,8 @@ __global__ __launch_bounds__(256) void k_seed_fill(int64_t n, int32_t kmer, int3
 	if (i < n) f[i] = kmer, pred[i] = -1, mark[i] = -1, flag[i] = 0;
 }
 
-// ABS_POS: the high half of the value IS the anchor's rank in the query's full sorted list (k_seed_sift) rather than the
-// number of dropped anchors below it (k_seed_prefilter).  The outputs may be pinned host memory: every element is written once.
+// ABS_POS: the high half of the value IS the anchor's rank in the query's full sorted list (k_seed_sift).  The outputs may be
+// pinned host memory: every element is written once.
 template<typename V, bool ABS_POS = false>
 __global__ __launch_bounds__(256) void k_seed_compact(const uint64_t *key, const V *val, int64_t n, int nb, const int64_t *qfirst, const uint32_t *flag,
                                                       const uint32_t *idx, const int32_t *f, const int32_t *pred, int32_t *o_pos, int32_t *o_f, int32_t *o_pred, uint64_t *o_a)
@@ -487,27 +474,6 @@ __global__ __launch_bounds__(256) void k_seed_bounds(const int64_t *qfirst, int3
 	cfirst[q] = i < n ? (int64_t)idx[i] : (n > 0 ? (int64_t)idx[n - 1] + flag[n - 1] : 0);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Pre-sort anchor filter (MPA_SEED_PREFILTER=1; off by default until it has been measured at scale).
-//
-// The pre-chain (map.c:186-192: mp_chain with max_dist_x = one block) can only link anchors of a query that lie in the same
-// or in adjacent 256-bp blocks, and an anchor that is neither linked nor linked onto never reaches the host.  84-92 % of the
-// anchors at genome scale have no such neighbour, yet all of them are gathered, sorted, walked and compacted.  Whether a block
-// has a neighbour needs no order: one workgroup per (query, range of 131 008 blocks) takes a two-bit census of the range in LDS
-// (bit 0: a hit in this block, bit 1: a second hit) from the query's occurrence lists -- each of which is ascending, so the
-// part of a list inside the range is two binary searches away -- and then decides, block by block,
-//     keep = hit && (second hit || hit in block - 1 || hit in block + 1)
-// exactly (one halo block on either side of the range).  Kept anchors go on to the sort; a dropped anchor is alone in its
-// block, so the number of dropped anchors that sort below a kept one is the number of dropped BLOCKS below its block: a prefix
-// popcount over the census, carried along as the high half of a 64-bit sort value, from which k_seed_compact restores the
-// anchor's position in the query's full sorted list (the host's sparse replay of the reference's sort needs it, host_core.cpp).
-// ------------------------------------------------------------------------------------------------
-#define PF_THREADS 256                                    /* = PF_WORDS / 32: one group of 32 words per thread in the prefix scan */
-#define PF_WORDS 8192                                     /* 16 two-bit fields per word: 131 072 fields = 32 KB of LDS */
-#define PF_PART_BLOCKS (PF_WORDS * 16 - 64)               /* blocks a workgroup owns: field 0 and field PF_PART_BLOCKS + 1 are halo */
-#define PF_LDS ((size_t)PF_WORDS * 4 + (size_t)PF_THREADS * 4 + 64 * 4)
-struct KeepBit { __host__ __device__ uint32_t operator()(uint32_t x) const { return x >> 31; } };
-
 __device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, uint64_t x)   // first index with a[i] >= x
 {
 	int32_t lo = 0, hi = n;
@@ -515,123 +481,9 @@ __device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, u
 	return lo;
 }
 
-// w[gather position of an anchor] = 1 << 31 | (dropped blocks of its range below its block) for a kept anchor, 0 for a dropped one;
-// rem[query * n_part + range] = dropped anchors of the range
-__global__ __launch_bounds__(PF_THREADS) void k_seed_prefilter(const SeedJobDev *jobs, const int64_t *jfirst, const uint32_t *kb, int32_t n_part,
-                                                               uint32_t *w, uint32_t *rem, int32_t *err)
-{
-	extern __shared__ uint32_t pf_lds[];
-	uint32_t *bm = pf_lds, *tsum = pf_lds + PF_WORDS, *wsum = tsum + PF_THREADS;
-	const int32_t part = blockIdx.x, q = blockIdx.y, t = threadIdx.x;
-	const int64_t base = (int64_t)part * PF_PART_BLOCKS;             // first block this workgroup owns
-	const int64_t j0 = jfirst[q], j1 = jfirst[q + 1];
-#pragma unroll
-	for (int k = 0; k < PF_WORDS / PF_THREADS; ++k) bm[t + PF_THREADS * k] = 0;
-	__syncthreads();
-	// ---- census of [base - 1, base + PF_PART_BLOCKS]
-	int32_t mine = 0;
-	for (int64_t j = j0 + t; j < j1; j += PF_THREADS) {
-		const SeedJobDev s = jobs[j];
-		const uint32_t *list = kb + s.kb_off;
-		const int32_t lo = d_lower_bound(list, s.cnt, (uint64_t)(base > 0 ? base - 1 : 0));
-		const int32_t hi = d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS + 1);
-		for (int32_t k = lo; k < hi; ++k) {
-			const uint32_t fi = (uint32_t)((int64_t)list[k] - base + 1);
-			const uint32_t sh = (fi & 15u) * 2u;
-			const uint32_t old = atomicOr(&bm[fi >> 4], 1u << sh);
-			if ((old >> sh) & 1u) atomicOr(&bm[fi >> 4], 2u << sh);
-		}
-		mine += hi - lo;
-		if (part == n_part - 1 && d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS) < s.cnt) *err = 1;   // a block past the last range: n_part is wrong
-	}
-	if (__syncthreads_or(mine > 0) == 0) { if (t == 0) rem[(int64_t)q * n_part + part] = 0; return; }
-	// ---- fields: bit 0 stays "hit", bit 1 becomes "dropped" (neighbours only ever read bit 0, which does not change)
-#pragma unroll 4
-	for (int k = 0; k < PF_WORDS / PF_THREADS; ++k) {
-		const int idx = k * PF_THREADS + t;
-		const uint32_t c = bm[idx], l = idx > 0 ? bm[idx - 1] : 0u, r = idx + 1 < PF_WORDS ? bm[idx + 1] : 0u;
-		const uint32_t S = c & 0x55555555u, M = (c >> 1) & 0x55555555u;
-		const uint32_t L = (S << 2) | ((l >> 30) & 1u), R = (S >> 2) | ((r & 1u) << 30);
-		uint32_t rm = S & ~(M | L | R);
-		if (idx == 0) rm &= ~1u;                                            // the halo fields belong to the neighbouring ranges
-		if (idx == (PF_PART_BLOCKS + 1) >> 4) rm &= ~(1u << (((PF_PART_BLOCKS + 1) & 15) * 2));
-		bm[idx] = S | (rm << 1);
-		uint32_t cnt = (uint32_t)__popc(rm);                                // dropped blocks of this group of 32 words
-#pragma unroll
-		for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-		if ((t & 31) == 0) tsum[idx >> 5] = cnt;
-	}
-	__syncthreads();
-	{	// exclusive scan of the group counts (one per thread)
-		const uint32_t v = tsum[t];
-		uint32_t inc = v;
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if ((t & 63) >= off) inc += o; }
-		if ((t & 63) == 63) wsum[t >> 6] = inc;
-		__syncthreads();
-		uint32_t before = 0;
-		for (int k = 0; k < (t >> 6); ++k) before += wsum[k];
-		tsum[t] = before + inc - v;
-		if (t == PF_THREADS - 1) rem[(int64_t)q * n_part + part] = before + inc;
-	}
-	__syncthreads();
-	// ---- verdicts of the anchors this workgroup owns: blocks [base, base + PF_PART_BLOCKS)
-	for (int64_t j = j0 + t; j < j1; j += PF_THREADS) {
-		const SeedJobDev s = jobs[j];
-		const uint32_t *list = kb + s.kb_off;
-		const int32_t lo = d_lower_bound(list, s.cnt, (uint64_t)base);
-		const int32_t hi = d_lower_bound(list, s.cnt, (uint64_t)base + PF_PART_BLOCKS);
-		for (int32_t k = lo; k < hi; ++k) {
-			const uint32_t fi = (uint32_t)((int64_t)list[k] - base + 1);
-			const uint32_t word = fi >> 4, sh = (fi & 15u) * 2u;
-			const uint32_t c = bm[word];
-			uint32_t out = 0;
-			if (!((c >> (sh + 1)) & 1u)) {
-				uint32_t below = tsum[word >> 5];
-				for (uint32_t x = word & ~31u; x < word; ++x) below += (uint32_t)__popc(bm[x] & 0xAAAAAAAAu);
-				below += (uint32_t)__popc(c & 0xAAAAAAAAu & ((1u << sh) - 1u));
-				out = 0x80000000u | below;
-			}
-			w[s.dst + k] = out;
-		}
-	}
-}
-
-// per query: exclusive prefix of its ranges' dropped counts; first kept anchor of every query (+ the total)
-__global__ __launch_bounds__(256) void k_seed_prefilter_bounds(const int64_t *qfirst, int32_t n_query, int64_t n, int32_t n_part, const uint32_t *w, const uint32_t *dst2,
-                                                              uint32_t *rem, int64_t *qfirst2)
-{
-	const int32_t q = blockIdx.x * 256 + threadIdx.x;
-	if (q > n_query) return;
-	const int64_t i = qfirst[q];
-	qfirst2[q] = i < n ? (int64_t)dst2[i] : (n > 0 ? (int64_t)dst2[n - 1] + (w[n - 1] >> 31) : 0);
-	if (q == n_query) return;
-	uint32_t acc = 0;
-	for (int32_t k = 0; k < n_part; ++k) { const uint32_t v = rem[(int64_t)q * n_part + k]; rem[(int64_t)q * n_part + k] = acc; acc += v; }
-}
-
-// the kept anchors, in gather order: key = query << nb | block, value = dropped anchors of the query below it << 32 | query position
-__global__ __launch_bounds__(256) void k_seed_gather_kept(const SeedJobDev *jobs, int32_t n_jobs, const uint32_t *kb, int nb, int32_t n_part, const uint32_t *w,
-                                                          const uint32_t *dst2, const uint32_t *rem, uint64_t *key, uint64_t *val)
-{
-	MPA_SHORT_KERNEL();
-	const int32_t j = blockIdx.x;
-	if (j >= n_jobs) return;
-	const SeedJobDev s = jobs[j];
-	const uint64_t hi = (uint64_t)s.qid << nb;
-	for (int32_t k = threadIdx.x; k < s.cnt; k += 256) {
-		const uint32_t ww = w[s.dst + k];
-		if (!(ww >> 31)) continue;
-		const uint32_t b = kb[s.kb_off + k];
-		const uint32_t d = dst2[s.dst + k];
-		key[d] = hi | b;
-		val[d] = (uint64_t)(rem[(int64_t)s.qid * n_part + (int32_t)(b / PF_PART_BLOCKS)] + (ww & 0x7fffffffu)) << 32 | (uint32_t)s.qpos;
-	}
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_seed_sift: anchors of a query, merged from its occurrence lists IN ORDER, isolated ones dropped on the way (default seeding
-// path; replaces k_seed_gather + the global radix sort of every anchor, and the census of k_seed_prefilter).
+// path; it replaced rounds 1-2's gather + global radix sort of every anchor).
 //
 // The anchors of a query (map.c:163-177) are the union of its seeds' occurrence lists, each of which is ascending in the block
 // id, and the order the reference sorts them into (map.c:178, radix_sort_mp64 on block << 32 | query position) is (block, seed)
@@ -685,10 +537,15 @@ __device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0
 	return c;
 }
 
-// skey/sval: staging, indexed like the unfiltered anchors (a segment writes its kept anchors from qfirst[q] + rank base on: the
-// kept ones can never outnumber the anchors below them); seg_kept[seg] / seg_base[seg]: how many and from where.
+// skey/sval: staging.  A query with few anchors owns as many slots as it has anchors (a segment writes its kept anchors from
+// sfirst[q] + rank base on: the kept ones can never outnumber the anchors below them); a query with more than SIFT_FULL_STAGE
+// anchors owns HALF as many -- at genome scale one anchor in eight is kept -- laid out the same way with every offset halved, and
+// a segment that keeps more than half of its anchors (a degenerate, repeat-only query) flags the query for the host instead of
+// writing past its share.  seg_kept[seg] / seg_base[seg]: how many and from where.
+#define SIFT_FULL_STAGE 16384
+__host__ __device__ inline int64_t sift_stage_slots(int64_t n_anchor) { return n_anchor > SIFT_FULL_STAGE ? (n_anchor + 1) / 2 : n_anchor; }
 template<int SIFT_CAP>
-__global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const uint32_t *kb,
+__global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const int64_t *sfirst, const uint32_t *kb,
                                                             uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
                                                             int64_t *seg_base, int32_t *qflag)
 {
@@ -712,7 +569,8 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 	const int64_t c0s = sg.cur_off;                            // this segment's cursors: segments of one query run side by side
 
 	// ---- cursors at the segment's first block; rank base; is there an anchor in block lo0 - 1?
-	uint32_t below = 0, left_nb = 0;
+	const bool half_stage = n_anchor > SIFT_FULL_STAGE;      // (see sift_stage_slots)
+	uint32_t below = 0, left_nb = 0, inside = 0;
 	for (int32_t l = t; l < nl; l += SIFT_THREADS) {
 		const SeedJobDev s = jobs[j0 + l];
 		const uint32_t *list = kb + s.kb_off;
@@ -723,10 +581,18 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 		}
 		cur[c0s + l] = c;
 		below += (uint32_t)c;
+		if (half_stage) inside += (uint32_t)((hi0 < n_block ? d_lower_bound(list, s.cnt, (uint64_t)hi0) : s.cnt) - c);
 	}
 	const uint32_t pos_base = sift_block_sum(below, scr);
 	left_nb = sift_block_sum(left_nb, scr) ? 1u : 0u;
-	const int64_t out0 = qfirst[q] + (int64_t)pos_base;       // where this segment's kept anchors start in the staging arrays
+	// where this segment's kept anchors start in the staging arrays, and how many of them fit there
+	uint32_t stage_cap = 0xffffffffu;
+	int64_t out0 = sfirst[q] + (int64_t)pos_base;
+	if (half_stage) {
+		const uint32_t seg_total = sift_block_sum(inside, scr);
+		out0 = sfirst[q] + (int64_t)(pos_base >> 1);
+		stage_cap = ((pos_base + seg_total) >> 1) - (pos_base >> 1);
+	}
 
 	uint32_t lo = lo0, n_carry = 0, kept_total = 0, emitted = pos_base;
 	uint32_t prev_blk = left_nb ? lo0 - 1 : 0xffffffffu;      // block of the last anchor below the buffer (0xffffffff: none that matters)
@@ -828,6 +694,10 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 			__syncthreads();
 			uint32_t off = kept_total + before;
 			for (uint32_t w = 0; w < wv; ++w) off += wtot[w];
+			if (kept_total + wtot[0] + wtot[1] + wtot[2] + wtot[3] > stage_cap) {   // (uniform) more than half of the segment's anchors kept: the host seeds this query
+				if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
+				return;
+			}
 			if (keep) {
 				const uint32_t l = key & lmask;
 				skey[out0 + off] = ((uint64_t)(uint32_t)q << nb) | (uint64_t)(lo + (key >> LB) - 1u);

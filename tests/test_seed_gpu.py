@@ -25,13 +25,11 @@ def survivors(ctx, idx, mo, q, threads=4):
     return off, a
 
 
-@pytest.mark.parametrize("mode", ["sort", "census", "sift", "sift-small-segments"])
+@pytest.mark.parametrize("mode", ["sift", "sift-small-segments"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_device_seeding_equals_host_seeding(seed, mode, monkeypatch):
-    # sort: every anchor is gathered and radix-sorted; census: anchors without a neighbour within one block are dropped before
-    # the sort (k_seed_prefilter); sift (the default): per-query merge in block order + LDS sort + the same filter (k_seed_sift),
-    # also with segments so small that every query is cut into many of them
-    monkeypatch.setenv("MPA_SEED_MODE", mode.split("-")[0])
+    # k_seed_sift: per-query merge of the occurrence lists in block order + LDS sort + isolation filter, also with segments so
+    # small that every query is cut into many of them
     if mode.endswith("segments"):
         monkeypatch.setenv("MPA_SIFT_SEG", "300")
     rng = np.random.default_rng(seed)
@@ -67,11 +65,11 @@ def test_device_seeding_equals_host_seeding(seed, mode, monkeypatch):
     ctx.close()
 
 
-def test_prefilter_across_block_ranges(monkeypatch):
-    """k_seed_prefilter splits a query's blocks into ranges of 131 008 blocks (33.5 Mbp per strand): a genome with nine
-    ranges, and a gene planted right across the fourth range boundary, so that kept anchors need the halo block of the
-    neighbouring range and the dropped-anchor counts of lower ranges (host side of this test checked on CPU: query 0 keeps
-    anchors in the three blocks below and the two blocks above the boundary)."""
+def test_sift_across_segment_boundaries(monkeypatch):
+    """k_seed_sift cuts a query's block space into segments swept side by side: a 150 Mbp genome with a gene planted right across
+    a segment boundary, so that kept anchors need the neighbouring segment's edge blocks and the rank base of the lower segments
+    (host side of this test checked on CPU: query 0 keeps anchors in the three blocks below and the two blocks above the
+    boundary)."""
     codon = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTG", "M": "ATG",
              "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
     code = {"A": 0, "C": 1, "G": 2, "T": 3}
@@ -90,8 +88,7 @@ def test_prefilter_across_block_ranges(monkeypatch):
     mo = mpa.default_mapopt()
     mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
     off_h, a_h = survivors(None, idx, mo, q, threads=16)
-    for mode, seg in (("sort", None), ("census", None), ("sift", None), ("sift", "2000"), ("sift", "256")):
-        monkeypatch.setenv("MPA_SEED_MODE", mode)
+    for mode, seg in (("sift", None), ("sift", "2000"), ("sift", "256")):
         if seg:
             monkeypatch.setenv("MPA_SIFT_SEG", seg)          # 2 / ~12 segments per query, swept side by side: boundaries all over the genome
         off_d, a_d = survivors(ctx, idx, mo, q, threads=16)
@@ -162,7 +159,6 @@ def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypat
     """k_seed_sift holds the anchors of one range in a 2 048-entry LDS buffer; a query whose seeds put more than that into ONE
     block (here: 3 000 identical k-mers of a poly-L protein over CTG repeats in the genome) is flagged by the kernel and
     seeded on the host, the other queries of the batch stay on the device -- same survivors as the host stage for all of them"""
-    monkeypatch.setenv("MPA_SEED_MODE", "sift")
     contigs, prots, names, planted = gen_synth.generate(2000000, 1, 20, 31, return_planted=True)
     g = contigs[0]
     for at in (300000, 300700, 900000, 1500000):
@@ -291,24 +287,4 @@ def test_device_chain_forward_equals_host_forward(serial_run, monkeypatch):
         args = [200000, 1000, 200000, int(rng.choice([25, 2])), 1000000, 0.75, int(rng.integers(0, 2)), 5, 0]
         linked += both(args, probs)
     assert linked > 5000
-    ctx.close()
-
-
-def test_whole_path_with_device_chains(monkeypatch):
-    """MPA_GPU_CHAIN=1: main chain and refinement chains take their forward passes from k_chain_fwd -- same output bytes as with
-    the host passes (and as the reference: the golden case is one of tests/test_map_gpu.py's)"""
-    from hostpipe import map_batch_gpu
-    case = golden.SYNTH_CASES[1]
-    contigs, prots, names = golden.synth_inputs(case)
-    idx = mpa.Index.from_nt4(contigs, ["chr%d" % (i + 1) for i in range(len(contigs))])
-    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
-    ctx = mpa.Context(0)
-    idx.to_device(ctx)
-    mo = golden.mapopt_for(case)
-    ref = open(golden.path(case["name"] + ".ref.paf"), "rb").read()
-    for chain, seed, refine in (("1", "0", "0"), ("1", "1", "1"), ("0", "1", "1")):
-        monkeypatch.setenv("MPA_GPU_CHAIN", chain), monkeypatch.setenv("MPA_GPU_SEED", seed), monkeypatch.setenv("MPA_GPU_REFINE", refine)
-        out = golden.file_header(case) + b"".join(mpa.map_batches(ctx, idx, mo, [mpa.Queries(prots, names)], 4))
-        assert out == ref, (chain, seed, refine)
-    idx.close()
     ctx.close()
