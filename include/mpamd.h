@@ -295,6 +295,7 @@ int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, c
 int mpa_dbg_chain_forward(mpa_ctx_t *ctx, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, int32_t max_skip, int32_t max_iter, float coef_log,
                           int32_t is_spliced, int32_t kmer, int32_t bbit, int32_t n_prob, const int64_t *first, const uint64_t *a, int32_t *f, int32_t *pred);
 /* the anchors that survive the pre-chain (map.c:186-192), query by query, from the host stage (ctx == NULL) or the device's */
+int64_t mpa_dbg_anchors(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out);
 int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out);
 /* the main chains of every query (what mp_chain() returns at map.c:195): u = score << 32 | anchors of each chain, a = the chains'
  * anchors; from the host stages (ctx == NULL) or from the device, which then runs both chaining rounds (k_chain_extract,
@@ -304,6 +305,9 @@ int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mp
  * the device kernel gets them (per-row records, int16 profile [22][pw]); fills tb[nl][ncol] when not NULL, returns the score. */
 int32_t mpa_dbg_gs32_model(int32_t nl, int32_t al, const uint32_t *rec, const int16_t *prof, int32_t pw, int32_t go, int32_t ge, int32_t io, int32_t fs,
                            uint16_t *tb, int32_t ncol);
+/* (measurement) the 32-column class of score-only extension calls on the anti-diagonal prototype (dp_antidiag.hip:
+ * lane j on row t - j, the mapping BASELINE.json's north_star names) instead of the row sweep: same results; tools/time_wide.py */
+void mpa_dbg_antidiag(mpa_ctx_t *ctx, int on);
 int64_t mpa_dbg_main_chains(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off_u, uint64_t **out_u,
                             int64_t *off_a, uint64_t **out_a);
 

@@ -76,7 +76,8 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_EXTRACT_PROF)
 	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
 	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
-	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }   // index of the lowest lane whose ballot bit is clear (width() if none)
+	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }
+	static MPA_HD int lowest(uint64_t) { return 0; }                    // index of the lowest lane whose ballot bit is set (m != 0)   // index of the lowest lane whose ballot bit is clear (width() if none)
 };
 #define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
 
@@ -182,12 +183,12 @@ MPA_HD inline void sort_pairs_by_x_core(Pair64 *beg, Pair64 *end, SortRange *sta
 // do not belong there: src[0, n_src), in order.  Each is dropped on the head of its own bucket in `tail` (tail[cursor[d]++]),
 // and whatever it displaces is carried on the same way until an element of the first bucket (digit == stop) is displaced --
 // that one ends up in the hole the walk started from, which sink(i, element) is told about.
-// The team takes C::width() elements at a time: as long as every one of them displaces an element of the first bucket -- the
-// overwhelmingly common case: the tail is almost all roots -- the placements do not interact (elements of one digit take
-// consecutive slots in their order, digits have disjoint slots) and are done side by side; a group in which some displacement
-// carries on is replayed one element at a time.  With a team of one this is the sequential walk.
-// sink_par(i, element, have): called by every lane for ITS element of a group placed side by side; sink_uni(i, element): called
-// by all lanes alike for an element of a replayed group.
+// The team takes C::width() elements at a time and places them in rounds: the elements in front of the first one whose
+// displacement carries on (it hit something that is not of the first bucket) do not interact -- elements of one digit take
+// consecutive slots in their order, digits have disjoint slots -- and are placed side by side; that one is replayed alone; the next
+// round starts behind it.  With a team of one this is the sequential walk.
+// sink_par(i, element, have): called by every lane, have = ITS element was placed side by side in this round; sink_uni(i, element):
+// called by all lanes alike for an element that was replayed alone.
 template<class C, int SHIFT, class SinkPar, class SinkUni>
 MPA_HD inline void place_in_order(const SparseItem *src, int64_t n_src, Pair64 *tail, uint32_t *cursor, int stop, SinkPar sink_par, SinkUni sink_uni)
 {
@@ -196,20 +197,34 @@ MPA_HD inline void place_in_order(const SparseItem *src, int64_t n_src, Pair64 *
 		const bool have = i < n_src;
 		const Pair64 e = have ? src[i].e : Pair64{ 0, 0 };
 		const int d = (int)(e.x >> SHIFT & 0xff);
-		int rank = 0, same = 1;
-		C::digit_rank(d, have, &rank, &same);
-		const uint32_t slot = have ? cursor[d] + (uint32_t)rank : 0u;
-		const Pair64 old = have ? tail[slot] : Pair64{ 0, 0 };
-		const bool ends_here = (int)(old.x >> SHIFT & 0xff) == stop;
-		if (!C::any(have && !ends_here)) {
-			if (have) tail[slot] = e;
-			sink_par(i, old, have);
+		const int n_grp = (int)(n_src - base < C::width() ? n_src - base : C::width());
+		// The elements of the group are placed in their order.  Each round: the elements not yet placed look at the slot they
+		// would get if everyone before them just dropped in (elements of one digit take consecutive slots in their order, digits
+		// have disjoint slots); those BEFORE the first one whose displacement carries on -- it hit a non-root: about one slot in
+		// eleven of a pre-chain's tail -- do not interact and are placed side by side; that one is replayed alone, as the reference
+		// walks it; the round after starts behind it.  (Round 3 replayed the whole group one element at a time whenever any of
+		// its 64 displacements carried on, i.e. nearly always.)
+		int done = 0;                                            // elements [0, done) of the group are placed
+		while (done < n_grp) {
+			const bool active = have && C::lane() >= done;
+			int rank = 0, same = 1;
+			C::digit_rank(d, active, &rank, &same);
+			const uint32_t slot = active ? cursor[d] + (uint32_t)rank : 0u;
+			const Pair64 old = active ? tail[slot] : Pair64{ 0, 0 };
+			const bool carries_on = active && (int)(old.x >> SHIFT & 0xff) != stop;
+			const uint64_t bad = C::ballot(carries_on);
+			const int first_bad = bad ? C::lowest(bad) : n_grp;  // (a team of one: 0 if its element carries on)
+			const bool commit = active && C::lane() < first_bad;
+			int crank = 0, csame = 1;
+			C::digit_rank(d, commit, &crank, &csame);
+			if (commit) tail[slot] = e;
+			sink_par(i, old, commit);
 			C::sync();
-			if (have && rank == same - 1) cursor[d] += (uint32_t)same;
+			if (commit && crank == csame - 1) cursor[d] += (uint32_t)csame;
 			C::sync();
-		} else {
-			const int64_t lim = base + C::width() < n_src ? base + C::width() : n_src;
-			for (int64_t g = base; g < lim; ++g) {               // (every lane replays the group: identical state, as in the sequential parts)
+			done = first_bad;
+			if (first_bad < n_grp) {                             // (every lane replays it: identical state, as in the sequential parts)
+				const int64_t g = base + first_bad;
 				Pair64 carried = src[g].e;
 				int dd = (int)(carried.x >> SHIFT & 0xff);
 				do {
@@ -219,8 +234,9 @@ MPA_HD inline void place_in_order(const SparseItem *src, int64_t n_src, Pair64 *
 					dd = (int)(carried.x >> SHIFT & 0xff);
 				} while (dd != stop);
 				sink_uni(g, carried);
+				C::sync();
+				done = first_bad + 1;
 			}
-			C::sync();
 		}
 	}
 }

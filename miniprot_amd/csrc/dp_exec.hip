@@ -25,6 +25,7 @@
 #include "dp_device.h"
 #include "chain_core.h"
 #include "dp_kernels.hip"
+#include "dp_antidiag.hip"
 #include "seed_exec.hip"
 
 namespace mpa {
@@ -145,11 +146,10 @@ struct mpa_ctx_s {
 	hipEvent_t wait_ev = nullptr;             // blocking-sync event: a host thread that waits for the device SLEEPS (wait_stream)
 	int side_off = 0;                         // first side stream a round uses (lets the DP lanes of a stream of batches sit on different hardware queues)
 	hipStream_t seed_stream = nullptr;        // high-priority stream of the seeding kernels: short, and must not queue behind DP tails
-	hipStream_t prep_stream = nullptr;        // high-priority stream of a round's k_prep_rows / k_prep_prof: short and wide, on every round's critical path
-	hipEvent_t prep_ev[2] = {};               // uploads done -> prep may start; prep done -> the round may start
 	bool no_split = false;                    // this mpa_dp_run() repeats a round whose workgroup hand-off timed out: 512/1024-column calls go to k_ext_huge
 	int64_t handoff_retries = 0;              // how often that has happened on this context (mpa_dp_handoff_retries)
 	std::vector<SeedHold*> holds;             // result holders of the stream pipeline's batches (owned; ctx_seed_hold)
+	bool antidiag = false;                    // (measurement) the 32-column extension class runs on the anti-diagonal prototype, k_ext_antidiag (mpa_dbg_antidiag)
 };
 
 namespace mpa {
@@ -316,12 +316,6 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreate(&ctx->fork_ev) == hipSuccess;
-	{
-		int least = 0, greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		ok = ok && hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, greatest) == hipSuccess;
-		for (auto &e : ctx->prep_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-	}
 	ok = ok && hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
 	if (!ok) {                                            // a null handle would silently alias the legacy default stream
 		set_error("creating the context's HIP streams/events failed");
@@ -356,8 +350,6 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
 	if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
-	for (auto &e : ctx->prep_ev) if (e) (void)hipEventDestroy(e);
-	if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
 	for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
 	if (ctx->seed_stream && ctx->seed_stream != ctx->stream) (void)hipStreamDestroy(ctx->seed_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -590,6 +582,8 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 		if (!prof) return MPA_OK;
 		HIP_TRY(hipMalloc((void**)&d_prof, NQ * 64 + 64));
 		HIP_TRY(hipMemsetAsync(d_prof, 0, NQ * 64, s));
+		const int n_prof = (int)NQ;
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof_n), &n_prof, sizeof(n_prof), 0, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &d_prof, sizeof(d_prof), 0, hipMemcpyHostToDevice, s));
 		return MPA_OK;
 	};
@@ -610,6 +604,7 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 		long long *none = nullptr;
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &none, sizeof(none), 0, hipMemcpyHostToDevice, s));
 		HIP_TRY(wait_stream(ctx, s));
+		HIP_TRY(hipDeviceSynchronize());                   // (debug facility: an extraction launched by another context may still be stamping into the buffer)
 		(void)hipFree(d_prof), d_prof = nullptr;
 		return MPA_OK;
 	};
@@ -1295,7 +1290,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.cig_off = cig_total, cig_total += t.cig_cap;
 		if (t.pad_ == 7) t.bnd_off = bnd_total, bnd_total += t.nl;
 	}
-	rec_total += max_nl + 96;                               // kernels prefetch records up to 48 rows past a call's end
+	rec_total += max_nl + 96 + (ctx->antidiag ? 64 : 0);    // kernels prefetch records up to 48 rows past a call's end (the anti-diagonal prototype: 128)
 
 	// ---- waves of the extension kernel
 	std::vector<ExtWave> ewaves;
@@ -1379,7 +1374,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	HIP_TRY(hipMemcpyAsync(ctx->qseq.p, hup + up_q, q_bytes, hipMemcpyHostToDevice, s));
 	if (!ewaves.empty()) HIP_TRY(hipMemcpyAsync(ctx->waves.p, hup + up_waves, sizeof(ExtWave) * ewaves.size(), hipMemcpyHostToDevice, s));
 	// (k_prep_rows writes every row of every call; only the padding the kernels prefetch behind the last call is cleared)
-	HIP_TRY(hipMemsetAsync((char*)ctx->rec.p + (size_t)(rec_total - (max_nl + 96)) * 4, 0, (size_t)(max_nl + 96) * 4, s));
+	{ const int64_t pad = max_nl + 96 + (ctx->antidiag ? 64 : 0); HIP_TRY(hipMemsetAsync((char*)ctx->rec.p + (size_t)(rec_total - pad) * 4, 0, (size_t)pad * 4, s)); }
 	if (n_wide_groups) HIP_TRY(hipMemsetAsync(ctx->rowkey.p, 0, (size_t)(n_wide_groups * 2 * key_stride * 4), s));
 	// split classes: boundary granules (16 B per row and boundary: 3 boundaries per 1024-column group, 1 per 512-column group),
 	// then the per-group completion counters and the error flag; all zero before the launch (a granule's tag is row + 1)
@@ -1417,19 +1412,15 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, mi->dev->spsc, mi->l_seq };
 
 	// ---- K3: per-row records and profiles
-	// (on the context's high-priority stream: these two are short, wide and on the round's critical path; in the main stream's
-	// queue they waited behind the round kernels of the other lanes -- 8 ms on average and up to 125 ms for 2.4 ms of work, round 3)
-	hipStream_t ps = ctx->prep_stream;
-	HIP_TRY(hipEventRecord(ctx->prep_ev[0], s));
-	HIP_TRY(hipStreamWaitEvent(ps, ctx->prep_ev[0], 0));
-	HIP_TRY(hipEventRecord(ctx->ev[0], ps));
+	// (measured, round 4: putting these two on a high-priority stream of their own gives every DP lane a second active hardware
+	// queue, and with ten more queues in use the round kernels are time-sliced: 41 -> 72 ms per launch.  They stay in the lane's
+	// own queue; MPA_SHORT_KERNEL raises their wave priority instead.)
+	HIP_TRY(hipEventRecord(ctx->ev[0], s));
 	if (!chunks.empty())
-		hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, ps, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
-	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, ps, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
+		hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, s, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
+	hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(ctx->ev[1], ps));
-	HIP_TRY(hipEventRecord(ctx->prep_ev[1], ps));
-	HIP_TRY(hipStreamWaitEvent(s, ctx->prep_ev[1], 0));
+	HIP_TRY(hipEventRecord(ctx->ev[1], s));
 	mark("    dp: uploads + prep enqueued");
 	// ---- fork: every kernel class (extension classes and the traceback classes of the first round) gets its
 	// own stream, so the long single-wave tails of the classes overlap instead of adding up
@@ -1476,7 +1467,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			cu.push_back(Cost{ cost, DpUnit{ kind, first, count, blk, n_blk, sgroup, xg_first, 0 } });
 		};
 		for (int cls = 0; cls < 3; ++cls)
-			for (int k = 0; k < ewave_cnt[cls]; k += 4)
+			for (int k = 0; k < ewave_cnt[cls] && !(cls == 1 && ctx->antidiag); k += 4)
 				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(4, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
 		for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
 		for (int k = 0; k < ewave_cnt[4]; ++k) add(U_EXT_W4, ewave_first[4] + k, 1, (int64_t)ewaves[ewave_first[4] + k].max_nl * 370);
@@ -1536,6 +1527,14 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		ctx->stats.launches_ext++;
 		return MPA_OK;
 	};
+	if (ctx->antidiag && ewave_cnt[1] > 0) {                           // (measurement) the 32-column class on the anti-diagonal prototype, one wave per block
+		ea.waves = ctx->waves.as<ExtWave>();
+		hipStream_t st = begin_side(true);
+		hipLaunchKernelGGL(k_ext_antidiag, dim3((unsigned)ewave_cnt[1]), dim3(64), EXT_ANTIDIAG_LDS, st, ea, ewave_first[1]);
+		HIP_TRY(hipGetLastError());
+		end_side();
+		ctx->stats.launches_ext++;
+	}
 	if (!huge_ids.empty()) {                                           // block-major sweep with the traceback kernel's arithmetic, then the replay
 		GlobArgs ha;
 		ha.tasks = ctx->tasks.as<DTask>(), ha.waves = d_hw, ha.rec = ctx->rec.as<uint32_t>(), ha.prof = ctx->prof.as<int16_t>();
@@ -1779,6 +1778,7 @@ int mpa_dp_run(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_t *opt, cons
 }
 
 int64_t mpa_dp_handoff_retries(const mpa_ctx_t *ctx) { return ctx ? ctx->handoff_retries : 0; }
+void mpa_dbg_antidiag(mpa_ctx_t *ctx, int on) { if (ctx) ctx->antidiag = on != 0; }
 int64_t mpa_device_bytes(void) { return (int64_t)g_dev_bytes.load(); }
 int64_t mpa_pool_growths(void) { return (int64_t)g_pool_growths.load(); }
 

@@ -1121,6 +1121,31 @@ int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, c
 // Test hook (not in include/mpamd.h): the anchors that survive the pre-chain (map.c:163-192), query by query, computed on the
 // host (ctx == NULL) or with the device seeding stage (seed_exec.hip).  off[n_seq + 1] receives the offsets into *out
 // (malloc'd, mpa_free).  Returns the total or a negative error code.
+// Test hook: the anchors of every query as map.c:163-178 leaves them (block << 32 | query position, sorted) -- the INPUT of the
+// reference's pre-chain call (map.c:188), so that a test can hand them to the real mp_chain().  off [n_seq + 1]; *out malloc'd.
+int64_t mpa_dbg_anchors(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out)
+{
+	*out = nullptr;
+	const char *saved = getenv("MPA_GPU_SEED");
+	const std::string keep = saved ? saved : "";
+	setenv("MPA_GPU_SEED", "0", 1);
+	mpa_mapopt_t o2 = *opt;
+	o2.flag |= MPA_MF_NO_PRE_CHAIN;                       // (stage_anchors_host then stops after the sort)
+	mpa_batch_t *b = batch_seed_phase(nullptr, mi, &o2, q, n_threads, false);
+	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	if (!b) return MPA_ERR_ARG;
+	std::vector<std::vector<uint64_t>> per((size_t)q->n_seq);
+	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_anchors_host(b, b->qs[i], per[i]); });
+	off[0] = 0;
+	for (int32_t i = 0; i < q->n_seq; ++i) off[i + 1] = off[i] + (int64_t)per[i].size();
+	uint64_t *o = (uint64_t*)malloc((size_t)std::max<int64_t>(off[q->n_seq], 1) * 8);
+	for (int32_t i = 0; i < q->n_seq; ++i) if (!per[i].empty()) memcpy(o + off[i], per[i].data(), per[i].size() * 8);
+	*out = o;
+	const int64_t n = off[q->n_seq];
+	delete b;
+	return n;
+}
+
 int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out)
 {
 	*out = nullptr;

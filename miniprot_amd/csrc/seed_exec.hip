@@ -256,6 +256,7 @@ struct ExtractArgs {
 
 // MPA_EXTRACT_PROF: wall-clock stamps of k_chain_extract's phases, 8 per problem (start, chain ends sorted, trees, extraction, end)
 __device__ long long *g_extract_prof = nullptr;
+__device__ int g_extract_prof_n = 0;         // problems the buffer has room for (launches of other contexts may have more)
 
 // the team of chain_core.h on the device: the 64 lanes of one wavefront
 struct CoopWave {
@@ -300,7 +301,8 @@ struct CoopWave {
 		*rank = __popcll(eq & ((1ull << lane()) - 1ull)), *cnt = __popcll(eq);
 	}
 	static __device__ __forceinline__ int first_unset(uint64_t m) { return m == ~0ull ? 64 : __ffsll((long long)~m) - 1; }
-	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
+	static __device__ __forceinline__ int lowest(uint64_t m) { return __ffsll((long long)m) - 1; }
+	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
 };
 
 __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)

@@ -242,3 +242,26 @@ def ora_nasw(nt, aa, P, flag, ss=None):
     if rst.cigar:
         _libc.free(rst.cigar)
     return rst.nt_len, rst.aa_len, rst.score, cig
+
+
+def ref_chain(a, args):
+    """The reference's own mp_chain() (chain.c:160-219) on a copy of the sorted anchors a (uint64): args = (max_dist_x, max_dist_y,
+    bw, max_skip, max_iter, min_cnt, min_sc, coef_log, is_spliced, kmer, bbit).  Returns (u, anchors of the chains)."""
+    import numpy as np
+    r = ref()
+    _libc.malloc.restype = C.c_void_p
+    _libc.malloc.argtypes = [C.c_size_t]
+    _libc.free.argtypes = [C.c_void_p]
+    n = len(a)
+    if n == 0:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint64)
+    p = _libc.malloc(max(8 * n, 8))
+    C.memmove(p, a.ctypes.data, 8 * n)
+    n_u, u = C.c_int32(0), C.c_void_p(0)
+    res = r.mp_chain(*args, n, p, C.byref(n_u), C.byref(u), None)
+    if n_u.value == 0:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint64)
+    uu = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), (n_u.value,)).copy()
+    aa = np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint64)), (int((uu & 0xffffffff).sum()),)).copy()
+    _libc.free(res), _libc.free(u)
+    return uu, aa

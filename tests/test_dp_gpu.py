@@ -176,3 +176,31 @@ def test_splice_score_track(ctx, oracle_built, tmp_path):
     bad, msg = compare(rst, cig, expect, meta, pairs)
     idx.close()
     assert not bad, "%d/%d DP calls differ from the oracle\n%s" % (len(bad), len(tasks), msg)
+
+
+def test_antidiagonal_prototype_equals_the_oracle(oracle_built):
+    """dp_antidiag.hip: the anti-diagonal mapping of the score-only extension sweep (lane j on row t - j; the mapping BASELINE.json's
+    north_star names), switched in for the 32-column class with mpa_dbg_antidiag(): (nt_len, aa_len, score) of left and right
+    extension calls of 17..32 columns -- alone in a wave and packed four to a wave, windows shorter than the diagonal's ramp,
+    long windows, a small x-drop, non-default scores -- against the oracle."""
+    import ctypes as C
+    c2 = mpa.Context(0)
+    mpa.lib().mpa_dbg_antidiag.argtypes = [C.c_void_p, C.c_int]
+    mpa.lib().mpa_dbg_antidiag(c2.h, 1)
+    rng = np.random.default_rng(41)
+    n = 0
+    for (go, ge, io, fs, xd, eb, sp, coef) in [(11, 1, 29, 23, 100, 5, (8, 15, 21, 30, 0, 0), 0.5),
+                                                (11, 1, 29, 23, 15, 5, (8, 15, 21, 30, 0, 0), 0.5),
+                                                (5, 2, 40, 17, 50, 0, (8, 15, 21, 30, 4, 4), 1.0)]:
+        P = refbind.DpParams(refbind.mapping_matrix(fs), go=go, ge=ge, io=io, fs=fs, xdrop=xd, end_bonus=eb, sp=sp, ie_coef=coef)
+        pairs = []
+        for al in (17, 18, 23, 24, 25, 31, 32):
+            for k in range(10):
+                pairs.append(make_task(rng, al=al, flank=int(rng.choice([1, 5, 40, 300, 3000])), p_indel=0.0 if k < 7 else 0.02))
+        pairs += [make_task(rng, al=int(rng.integers(17, 33)), max_intron=6000, flank=5000) for _ in range(12)]
+        pairs += [make_task(rng, al=20, flank=1, p_indel=0.0)]
+        n += run_case(c2, pairs, P, rng, modes=("left", "right"))
+        n += run_case(c2, pairs[:3], P, rng, modes=("right",))     # a wave with empty slots
+    assert c2.dp_stats()["launches_ext"] >= 1
+    assert n > 400
+    c2.close()

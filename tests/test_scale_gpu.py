@@ -104,3 +104,57 @@ def test_long_introns_and_the_widest_extension_classes(ctx, tmp_path):
     ref = _reference(tmp_path, idx, prots, names, ["-G", "500000", "-u"])
     assert ours[0] == ref, _first_difference(ours[0], ref)
     idx.close()
+
+
+def test_gene_families_with_thirty_secondaries(ctx, tmp_path):
+    """The repeat-rich regime a single planted locus per protein never reaches ("Hard parts"): gene FAMILIES --
+    12 diverged copies (2-9 % substitutions, some with a one-base deletion, i.e. a frameshift) of each of 16 two-exon genes, scattered
+    over both strands of two contigs -- mapped with `-N 30 --outn=30 --outs=0.3 -p 0.3 -u`, so that hit.c's secondary selection (mp_select_sub,
+    mp_select_multi_exon, hit.c:159-236), parent assignment and the output filters (map.c:298-305) see a dozen near-equal regions
+    per query, chains of equal score compete for shared anchors and every region is refined, extended and traced back.  Bytes equal
+    the reference's, run live."""
+    codon = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTG", "M": "ATG",
+             "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    contigs, prots, names = gen_synth.generate(40_000_000, 2, 300, 17, mu=7.0, sigma=1.2, imax=20000)
+    rng = np.random.default_rng(171)
+    fam_prots, fam_names = [], []
+    for f in range(16):
+        p = bytes(prots[f]).decode()
+        cds = np.array([code[c] for a in p for c in codon.get(a, "GCT")], np.uint8)
+        cut = 3 * int(rng.integers(len(p) // 3, 2 * len(p) // 3)) + int(rng.integers(0, 3))      # intron in any phase
+        ilen = int(rng.integers(200, 6000))
+        intron = rng.integers(0, 4, ilen).astype(np.uint8)
+        intron[:2] = [2, 3]; intron[-2:] = [0, 2]; intron[2] = 0; intron[-3] = 1                 # GTA ... CAG
+        gene = np.concatenate([cds[:cut], intron, cds[cut:], np.array([3, 0, 0], np.uint8)])
+        for k in range(12):
+            cp = gene.copy()
+            m = rng.random(len(cp)) < rng.uniform(0.02, 0.09)
+            cp[m] = rng.integers(0, 4, int(m.sum())).astype(np.uint8)
+            if k % 4 == 3:
+                cp = np.delete(cp, int(rng.integers(30, len(cp) - 30)))
+            c = int(rng.integers(0, 2))
+            at = int(rng.integers(1000, len(contigs[c]) - len(cp) - 1000))
+            contigs[c][at:at + len(cp)] = comp[cp[::-1]] if rng.random() < 0.5 else cp
+        fam_prots.append(bytes(prots[f])), fam_names.append("fam%02d" % f)
+    prots = list(prots[16:]) + fam_prots
+    names = list(names[16:]) + fam_names
+    idx = mpa.Index.from_nt4(contigs, ["chr1", "chr2"])
+    del contigs
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, min(32, NCPU)))
+    idx.to_device(ctx)
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    mo.best_n = 30
+    mo.out_n = 30
+    mo.out_sim = 0.3                                            # --outs: secondaries down to 30 % of the best score are printed
+    mo.pri_ratio = 0.3                                          # -p: ... and kept
+    n = len(prots)
+    batches = [mpa.Queries(prots[a:b], names[a:b]) for a, b in ((0, n // 2), (n // 2, n))]
+    ours = b"".join(mpa.map_batches(ctx, idx, mo, batches, min(64, NCPU)))
+    ref = _reference(tmp_path, idx, prots, names, ["-N", "30", "--outn=30", "--outs=0.3", "-p", "0.3", "-u"])
+    assert ours == ref, _first_difference(ours, ref)
+    fam_lines = [l for l in ours.split(b"\n") if l.startswith(b"fam")]
+    assert len(fam_lines) >= 16 * 8, "the families did not produce their secondaries (%d lines)" % len(fam_lines)
+    idx.close()

@@ -8,6 +8,7 @@ import pytest
 import miniprot_amd as mpa
 import golden  # noqa: F401  (puts tools/ on sys.path)
 import gen_synth
+import refbind
 
 pytestmark = pytest.mark.gpu
 
@@ -287,4 +288,70 @@ def test_device_chain_forward_equals_host_forward(serial_run, monkeypatch):
         args = [200000, 1000, 200000, int(rng.choice([25, 2])), 1000000, 0.75, int(rng.integers(0, 2)), 5, 0]
         linked += both(args, probs)
     assert linked > 5000
+    ctx.close()
+
+
+def raw_anchors(idx, mo, q, threads=4):
+    L = mpa.lib()
+    L.mpa_dbg_anchors.restype = C.c_int64
+    L.mpa_dbg_anchors.argtypes = [C.c_void_p, C.POINTER(mpa.MapOpt), C.POINTER(mpa.QBatch), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    off = np.zeros(len(q.seqs) + 1, np.int64)
+    out = C.c_void_p()
+    n = L.mpa_dbg_anchors(idx.h, C.byref(mo), C.byref(q.c), threads, off.ctypes.data, C.byref(out))
+    assert n >= 0, mpa.last_error()
+    a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), (max(n, 1),))[:n].copy()
+    L.mpa_free(out)
+    return off, a
+
+
+@pytest.mark.skipif(not refbind.have_ref(), reason="oracle/_ref/libminiprot_ref.so not built")
+@pytest.mark.parametrize("seed", [5, 6])
+def test_device_chaining_rounds_equal_the_reference_mp_chain(seed):
+    """Both chaining rounds of the device path against the REFERENCE ITSELF (oracle/_ref/libminiprot_ref.so, mp_chain, chain.c:160-219),
+    not against the host stage: the anchors of every query (map.c:163-178) go through the reference's pre-chain call (map.c:188:
+    min_cnt 2, min_sc 0, one block of reach) and its sort (map.c:191-192) -- which must give k_seed_sift + k_prechain_fwd +
+    k_chain_extract(set)'s survivors -- and those through the reference's main-chain call (map.c:194-195), which must give
+    k_chain_fwd / k_chain_fwd_wave + k_chain_extract's chains: u[] (score << 32 | anchors) and the anchors, chain by chain, in the
+    order mp_chain() returns them.  Tandem gene copies: many equal chain scores, i.e. the tie order of the reference's unstable
+    radix sort decides which chain claims a shared anchor."""
+    rng = np.random.default_rng(seed)
+    contigs, prots, names, planted = gen_synth.generate(3000000, 2, 40, 30 + seed, return_planted=True)
+    g = contigs[0]
+    for k in range(6):
+        src = int(rng.integers(0, len(g) - 20000))
+        seg = g[src:src + int(rng.integers(2000, 9000))].copy()
+        at = int(rng.integers(0, len(g) - 10 * len(seg)))
+        for r in range(int(rng.integers(2, 6))):
+            g[at + r * len(seg):at + (r + 1) * len(seg)] = seg
+    idx = mpa.Index.from_nt4(contigs, ["chr1", "chr2"])
+    mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 4))
+    ctx = mpa.Context(0)
+    idx.to_device(ctx)
+    extra = [b"M" + bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), 300).tolist()), b"MA", bytes(planted[0]) + bytes(planted[1]) + bytes(planted[0])]
+    q = mpa.Queries(list(prots) + [bytes(p) for p in planted[:10]] + extra)
+    kmer, bbit = 6, 8                                            # mp_idxopt_init (options.c:14-22): what Index.from_nt4 builds with
+    n_chains = n_surv = 0
+    for flags in (0, 1):
+        mo = mpa.default_mapopt()
+        if flags:
+            mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+            mo.max_occ = 200
+        is_spliced = 0 if (mo.flag & 0x1) else 1                  # MPA_MF_NO_SPLICE
+        a_off, a_all = raw_anchors(idx, mo, q)
+        s_off, s_dev = survivors(ctx, idx, mo, q)
+        n_back, du_off, du, da_off, da = main_chains(ctx, idx, mo, q)
+        w = 1 << bbit
+        for i in range(len(q.seqs)):
+            a = a_all[a_off[i]:a_off[i + 1]]
+            _, pre = refbind.ref_chain(a, (w, w, w, mo.max_chn_max_skip, mo.max_chn_iter, 2, 0, mo.chn_coef_log, is_spliced, kmer, bbit))
+            pre = np.sort(pre)                                     # radix_sort_mp64, map.c:191
+            assert np.array_equal(pre, s_dev[s_off[i]:s_off[i + 1]]), ("pre-chain survivors", flags, i)
+            u, ca = refbind.ref_chain(pre, (mo.max_intron, mo.max_gap, mo.bw, mo.max_chn_max_skip, mo.max_chn_iter, mo.min_chn_cnt, mo.min_chn_sc, mo.chn_coef_log,
+                                            is_spliced, kmer, bbit))
+            assert np.array_equal(u, du[du_off[i]:du_off[i + 1]]), ("main chains: u", flags, i)
+            assert np.array_equal(ca, da[da_off[i]:da_off[i + 1]]), ("main chains: anchors", flags, i)
+            n_chains += len(u)
+            n_surv += len(pre)
+    assert n_chains > 50 and n_surv > 1000
+    idx.close()
     ctx.close()

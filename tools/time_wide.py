@@ -1,5 +1,6 @@
-"""Kernel-time microbenchmark of the extension classes: n_tasks right-extension calls of `al` columns x `nl` rows (results are
-not checked here).  python tools/time_wide.py al nl n_tasks"""
+"""Kernel-time microbenchmark of the DP classes: n_tasks right-extension calls (flag 4) or traceback calls (flag 1) of `al` columns x
+`nl` rows (results are not checked here).  python tools/time_wide.py al nl n_tasks [flag] [antidiag]
+antidiag = 1: the 32-column extension class on the anti-diagonal prototype (dp_antidiag.hip) instead of the row sweep."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -10,6 +11,11 @@ rng = np.random.default_rng(1)
 g = rng.integers(0, 4, nl * n + 1000).astype(np.uint8)
 idx = mpa.Index.from_nt4([g], ["c"])
 ctx = mpa.Context(0); idx.to_device(ctx)
+antidiag = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+if antidiag:
+    import ctypes as C
+    mpa.lib().mpa_dbg_antidiag.argtypes = [C.c_void_p, C.c_int]
+    mpa.lib().mpa_dbg_antidiag(ctx.h, 1)
 aa = bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), al * n).tolist())
 q = mpa.Queries([aa[i * al:(i + 1) * al] for i in range(n)])
 tasks = np.zeros(n, mpa.DP_TASK)
@@ -22,4 +28,4 @@ for it in range(3):
     mpa.dp_run(ctx, idx, dp, q, tasks)
     st = ctx.dp_stats()
     ms = st["ms_ext"] if flag != 1 else st["ms_glob"]
-    print("al %d nl %d x %d flag %d: %.2f ms -> %.1f ns/row (backtrack %.2f ms)" % (al, nl, n, flag, ms, ms * 1e6 / nl, st["ms_backtrack"]))
+    print("al %d nl %d x %d flag %d%s: %.2f ms -> %.1f ns/row (backtrack %.2f ms)" % (al, nl, n, flag, " ANTIDIAG" if antidiag else "", ms, ms * 1e6 / nl, st["ms_backtrack"]))
