@@ -12,6 +12,35 @@
  * mini-batches through mpa_map_batches().  No usable HIP device: a message on stderr and abort() -- there is no
  * CPU fallback.
  */
+/*
+  The interface declared here -- record layouts, constants and prototypes -- is that of lh3/miniprot (v0.18-r281), reproduced
+  so that programs written against the reference's header compile and link against this library unchanged.  miniprot is
+  distributed under the following licence, whose notice is retained as it requires:
+
+  The MIT License
+
+  Copyright (c) 2022-     Dana-Farber Cancer Institute
+
+  Permission is hereby granted, free of charge, to any person obtaining
+  a copy of this software and associated documentation files (the
+  "Software"), to deal in the Software without restriction, including
+  without limitation the rights to use, copy, modify, merge, publish,
+  distribute, sublicense, and/or sell copies of the Software, and to
+  permit persons to whom the Software is furnished to do so, subject to
+  the following conditions:
+
+  The above copyright notice and this permission notice shall be
+  included in all copies or substantial portions of the Software.
+
+  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND,
+  EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+  MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+  NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS
+  BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN
+  ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN
+  CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE
+  SOFTWARE.
+*/
 #ifndef MINIPROT_H
 #define MINIPROT_H
 

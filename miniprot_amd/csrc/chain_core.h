@@ -77,7 +77,8 @@ struct CoopSerial {          // a team of one: the host
 	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
 	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
 	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }
-	static MPA_HD int lowest(uint64_t) { return 0; }                    // index of the lowest lane whose ballot bit is set (m != 0)   // index of the lowest lane whose ballot bit is clear (width() if none)
+	static MPA_HD int lowest(uint64_t) { return 0; }                    // index of the lowest lane whose ballot bit is set (m != 0)
+	static MPA_HD uint64_t *scratch(int64_t *cap) { *cap = 0; return nullptr; }   // fast memory shared by the team (LDS on the device), in 8-byte words   // index of the lowest lane whose ballot bit is clear (width() if none)
 };
 #define MPA_COOP_FOR(C, i, n) for (int64_t i = C::lane(); i < (int64_t)(n); i += C::width())
 
@@ -133,6 +134,50 @@ MPA_HD inline void pairs_digit_level(Pair64 *beg, Pair64 *end, int shift, uint32
 		} while (d != k);
 		beg[cursor[k]++] = carried;
 	}
+}
+
+// The same digit level (shift 0) on elements packed into 8 bytes -- key << 32 | payload (0xffffffff: MPA_ABSENT) -- as they sit in
+// the team's fast scratch memory: same counts, same walk, same result as pairs_digit_level(.., 0, ..) on the unpacked elements.
+MPA_HD inline void packed_digit_level0(uint64_t *beg, uint32_t n, uint32_t *hist)
+{
+	uint32_t *cnt = hist, *cursor = hist + 256, *limit = hist + 512;
+	for (int d = 0; d < 256; ++d) cnt[d] = 0;
+	for (uint32_t i = 0; i < n; ++i) ++cnt[beg[i] >> 32 & 0xff];
+	bool single = false;
+	{
+		uint32_t at = 0;
+		for (int d = 0; d < 256; ++d) { cursor[d] = at, at += cnt[d], limit[d] = at; if (cnt[d] == n) single = true; }
+	}
+	for (int k = 0; !single && k < 256;) {
+		if (cursor[k] == limit[k]) { ++k; continue; }
+		int d = (int)(beg[cursor[k]] >> 32 & 0xff);
+		if (d == k) { ++cursor[k]; continue; }
+		uint64_t carried = beg[cursor[k]];
+		do {
+			const uint64_t placed = carried;
+			carried = beg[cursor[d]];
+			beg[cursor[d]++] = placed;
+			d = (int)(carried >> 32 & 0xff);
+		} while (d != k);
+		beg[cursor[k]++] = carried;
+	}
+}
+
+// pairs_digit_level(beg, end, 0, hist) by the whole team: a bucket that fits the team's scratch memory and whose keys fit 32 bits
+// (the caller's guarantee) is copied there by all lanes, walked there (every step of the walk is a dependent memory access: tens
+// of cycles in LDS against hundreds to HBM) and copied back; anything else is walked in place.  A team of one has no scratch.
+template<class C> MPA_HD inline void team_digit_level0(Pair64 *beg, Pair64 *end, uint32_t *hist)
+{
+	int64_t cap = 0;
+	uint64_t *fast = C::scratch(&cap);
+	const int64_t n = end - beg;
+	if (!fast || n > cap) { pairs_digit_level(beg, end, 0, hist); C::sync(); return; }
+	MPA_COOP_FOR(C, i, n) fast[i] = beg[i].x << 32 | (beg[i].y == MPA_ABSENT ? 0xffffffffull : (beg[i].y & 0xffffffffull));
+	C::sync();
+	packed_digit_level0(fast, (uint32_t)n, hist);
+	C::sync();
+	MPA_COOP_FOR(C, i, n) { const uint64_t p = fast[i]; beg[i] = Pair64{ p >> 32, (p & 0xffffffffull) == 0xffffffffull ? MPA_ABSENT : (p & 0xffffffffull) }; }
+	C::sync();
 }
 
 // every level below `shift` too (the reference recurses; the buckets are independent, so a work list gives the same result)
@@ -378,20 +423,42 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		},
 		[&](int64_t i, const Pair64 &old) { if (old.y != MPA_ABSENT) moved[n_moved++] = SparseItem{ high[i].pos, old }; });
 	C::sync();
+	C::mark_time(5);
 	walk_buckets<C, 8>(tail8, cursor, limit, 1);            // buckets 1..255 (same walk as pairs_digit_level)
+	C::mark_time(6);
 	// ---- level 2 inside bucket 0: the low scores at their (possibly new) positions, ascending
 	{
 		C::sync();
 		const int64_t n_low = coop_compact<C>(a_end, [&](int64_t i) { return items[i].e.x < 256; }, [&](int64_t i, int64_t k) { merged[k] = items[i]; });
-		// ... merged with the moved ones by position (both ascending, positions distinct): backwards, in place
-		int64_t i = n_low - 1, j = n_moved - 1, k = n_low + n_moved - 1;
-		while (j >= 0) {
-			if (i >= 0 && merged[i].pos > moved[j].pos) merged[k--] = merged[i--];
-			else merged[k--] = moved[j--];
+		// ... merged with the moved ones by position (both ascending, positions distinct).  One lane: backwards, in place.  A team:
+		// every element finds its place by itself -- its own rank plus the number of elements of the OTHER list in front of it (a
+		// binary search) -- into the item list, which is dead by now and becomes the merged list.
+		if (C::width() == 1 || n_moved == 0) {
+			int64_t i = n_low - 1, j = n_moved - 1, k = n_low + n_moved - 1;
+			while (j >= 0) {
+				if (i >= 0 && merged[i].pos > moved[j].pos) merged[k--] = merged[i--];
+				else merged[k--] = moved[j--];
+			}
+		} else {
+			C::sync();
+			MPA_COOP_FOR(C, i, n_low) {
+				const int64_t pos = merged[i].pos;
+				int64_t lo = 0, hi = n_moved;
+				while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (moved[mid].pos < pos) lo = mid + 1; else hi = mid; }
+				items[i + lo] = merged[i];
+			}
+			MPA_COOP_FOR(C, j, n_moved) {
+				const int64_t pos = moved[j].pos;
+				int64_t lo = 0, hi = n_low;
+				while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (merged[mid].pos < pos) lo = mid + 1; else hi = mid; }
+				items[j + lo] = moved[j];
+			}
+			merged = items;
 		}
 		n_merged = n_low + n_moved;
 	}
 	C::sync();
+	C::mark_time(7);
 	for (int d = 0; d < 256; ++d) cnt_hi[d] = d ? cnt8[d] : 0u;   // (the level-2 passes below reuse the first 768 words of S.hist)
 	C::sync();
 	int64_t n_out = 0;
@@ -406,10 +473,16 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		for (int64_t i = 0; i < n_merged; ++i) out[n_out++] = merged[i].e;
 	}
 	// ---- level 2 inside the other buckets (all of it is present): digit pass or insertion sort, as the reference recurses
+	// (the buckets are independent: the short ones -- insertion sort, no shared state -- go one to a lane, side by side; the long ones
+	// one after the other by the whole team.  start[] / cnt_hi[] sit in the part of S.hist the digit passes do not touch.)
+	for (int d = 1 + C::lane(); d < 256; d += C::width()) {
+		Pair64 *b = tail8 + start[d];
+		if (cnt_hi[d] > 1 && cnt_hi[d] <= 64) pairs_insertion(b, b + cnt_hi[d]);
+	}
+	C::sync();
 	for (int d = 1; d < 256; ++d) {
-		Pair64 *b = tail8 + start[d], *e = b + cnt_hi[d];
-		if (cnt_hi[d] > 64) pairs_digit_level(b, e, 0, S.hist);
-		else if (cnt_hi[d] > 1) pairs_insertion(b, e);
+		Pair64 *b = tail8 + start[d];
+		if (cnt_hi[d] > 64) team_digit_level0<C>(b, b + cnt_hi[d], S.hist);
 	}
 	C::sync();
 	MPA_COOP_FOR(C, i, m_hi) out[n_out + i] = tail8[i];   // (buckets 1..255 lie back to back from tail8[0] on)
@@ -545,10 +618,10 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 	Pair64 *first = S.first;
 	{
 		int64_t k = 0;
-		for (int64_t c = 0; c < n_u; ++c) {
+		for (int64_t c = 0; c < n_u; ++c) {                      // (the chains one after the other, a chain's anchors shared out over the lanes)
 			const int64_t cnt = (int64_t)(uint32_t)u[c];
-			for (int64_t j = 0; j < cnt; ++j) packed[k + j] = v.a[order[k + cnt - 1 - j]];
-			first[c] = Pair64{ packed[k] >> 32, (uint64_t)k << 32 | (uint64_t)c };
+			MPA_COOP_FOR(C, j, cnt) packed[k + j] = v.a[order[k + cnt - 1 - j]];
+			if (C::lane() == 0) first[c] = Pair64{ v.a[order[k + cnt - 1]] >> 32, (uint64_t)k << 32 | (uint64_t)c };
 			k += cnt;
 		}
 	}
@@ -559,12 +632,12 @@ template<class C> MPA_HD inline int chain_extract_core(const ChainParams &p, con
 	for (int64_t c = 0; c < n_u; ++c) {
 		const uint32_t which = (uint32_t)first[c].y;
 		const int64_t cnt = (int64_t)(uint32_t)u[which], from = (int64_t)(first[c].y >> 32);
-		u_sorted[c] = u[which];
-		for (int64_t j = 0; j < cnt; ++j) a_out[k + j] = packed[from + j];
+		if (C::lane() == 0) u_sorted[c] = u[which];
+		MPA_COOP_FOR(C, j, cnt) a_out[k + j] = packed[from + j];
 		k += cnt;
 	}
 	C::sync();
-	for (int64_t c = 0; c < n_u; ++c) u[c] = u_sorted[c];
+	MPA_COOP_FOR(C, c, n_u) u[c] = u_sorted[c];
 	C::sync();
 	*n_a_out = k, *n_u_out = n_u;
 	C::mark_time(4);

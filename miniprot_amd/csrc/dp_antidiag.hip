@@ -140,6 +140,12 @@ __device__ __forceinline__ void ext_antidiag32(const ExtArgs &a, const ExtWave *
 	uint32_t S = prof2(lds_prof + pbase0 + (rcur.x & 0xff), lds_prof + pbase1 + (rcur.y & 0xff));
 	// records of rows i - 1 and i - 2 feed the donor / acceptor windows of row i; a lane that starts below row 0 picks them up on its way
 	uint32_t hpos = (uint32_t)lane * 4u + (uint32_t)(t & (AD_HIST - 1)) * 256u;   // this lane's slot in the history line of step t (line t mod AD_HIST)
+	{	// the donor / acceptor windows as if steps 0 and 1 had run: the records of rows 0 - col and 1 - col (columns 0 and 1 start
+		// at row 2 and 1 and would otherwise never see rows 0 and 1; further right the lanes pick them up on their way)
+		const uint2 q0 = *(const uint2*)(ringb + (((uint32_t)(0 - col) & (AD_RING - 1)) * 8u)), q1 = *(const uint2*)(ringb + (((uint32_t)(1 - col) & (AD_RING - 1)) * 8u));
+		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
+		ac[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0b070903u), ac[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0b070903u);
+	}
 
 	auto step = [&](auto kc, auto pro) {
 		constexpr int K = decltype(kc)::value;

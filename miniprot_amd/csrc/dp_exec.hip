@@ -592,15 +592,21 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 		std::vector<long long> h(NQ * 8);
 		HIP_TRY(hipMemcpyAsync(h.data(), d_prof, NQ * 64, hipMemcpyDeviceToHost, s));
 		HIP_TRY(wait_stream(ctx, s));
-		double sum[4] = { 0, 0, 0, 0 }, mx = 0;
-		int64_t cnt = 0;
+		double sum[4] = { 0, 0, 0, 0 }, sub[4] = { 0, 0, 0, 0 }, mx = 0;
+		int64_t cnt = 0, cnt2 = 0;
 		for (size_t q = 0; q < NQ; ++q) {
 			if (!h[q * 8 + 4] || !h[q * 8]) continue;
 			for (int k = 0; k < 4; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]) * 1e-5;   // 100 MHz ticks -> ms
 			mx = std::max(mx, (double)(h[q * 8 + 4] - h[q * 8]) * 1e-5), ++cnt;
+			if (h[q * 8 + 5] && h[q * 8 + 6] && h[q * 8 + 7]) {       // the two-level sort replay: its parts (stamps 5-7 lie between 0 and 1)
+				sub[0] += (double)(h[q * 8 + 5] - h[q * 8]) * 1e-5, sub[1] += (double)(h[q * 8 + 6] - h[q * 8 + 5]) * 1e-5;
+				sub[2] += (double)(h[q * 8 + 7] - h[q * 8 + 6]) * 1e-5, sub[3] += (double)(h[q * 8 + 1] - h[q * 8 + 7]) * 1e-5, ++cnt2;
+			}
 		}
 		fprintf(stderr, "[mpa-extract-prof] %s: %lld problems; mean ms: sort replay %.2f, trees %.2f, extraction %.2f, output %.2f; slowest problem %.2f ms\n", what, (long long)cnt,
 		        sum[0] / std::max<int64_t>(cnt, 1), sum[1] / std::max<int64_t>(cnt, 1), sum[2] / std::max<int64_t>(cnt, 1), sum[3] / std::max<int64_t>(cnt, 1), mx);
+		if (cnt2) fprintf(stderr, "[mpa-extract-prof]   two-level replay (%lld problems): level-1 placement %.2f, level-1 walk %.2f, merge %.2f, level 2 %.2f ms\n", (long long)cnt2,
+		                  sub[0] / cnt2, sub[1] / cnt2, sub[2] / cnt2, sub[3] / cnt2);
 		long long *none = nullptr;
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &none, sizeof(none), 0, hipMemcpyHostToDevice, s));
 		HIP_TRY(wait_stream(ctx, s));

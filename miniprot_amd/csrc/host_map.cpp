@@ -61,8 +61,6 @@ struct QueryState {
 	int64_t n_anchor = 0;                // anchors those seeds expand to
 	std::vector<mpa_dp_task_t> local1;   // this query's round-1 DP tasks (plan fields index into it)
 	int64_t base1 = 0;                   // where local1 starts in the batch's round-1 task array
-	std::vector<mpa_dp_task_t> local2;   // likewise for round 2 (the retries)
-	int64_t base2 = 0;
 };
 
 } // namespace mpa
@@ -83,7 +81,7 @@ struct mpa_batch_s {
 	mpa_dpopt_t dpopt;
 	mpa_qbatch_t q;
 	int n_threads = 1;
-	int round = 0;                   // 0: before round 1; 1..3: tasks of that round are out; 4: done
+	int round = 0;                   // 0: before round 1; 1, 2: tasks of that round are out (extensions + gaps; accepted spans); 4: done
 	std::vector<QueryState> qs;
 	std::vector<mpa_dp_task_t> tasks;
 	bool seeded_on_device = false;   // between the two seeding phases: `sparse` holds the device's pre-chain result
@@ -719,17 +717,33 @@ static void store_result(Segment &s, const mpa_dp_rst_t *rst, const uint32_t *po
 
 // round-1 tasks of one query: both extensions of every region plus the gaps between kept anchors
 // (align.c:305-313, all iterations but the first).  Runs inside the threaded stage A.
+// The reference repeats an extension that did not reach the end of the protein with the cheaper intron penalty of a terminal exon
+// (io_end) on a window of at most max_ext rows (align.c:290-296, 324-331).  Whether it will is known only after the first call, but
+// WHAT it would compute is not: window, protein slice and penalty depend on the plan alone.  So the repeat is issued speculatively
+// next to the first call -- at most max_ext (1 000) rows against windows of max_intron / 2, about 4 % more extension rows at
+// config 3 -- and a batch needs two DP rounds instead of three: one launch, one host round trip and one tail fewer.
 static void plan_round1(mpa_batch_s *b, QueryState &qs)
 {
 	const mpa_mapopt_t &opt = b->opt;
+	const bool retry = opt.io > opt.io_end;
 	for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 		AlignPlan &pl = qs.plans[pi];
 		const Region &r = qs.regs[pl.reg];
 		pl.t_left = (int32_t)qs.local1.size();
 		qs.local1.push_back(make_task(qs, r, pl.as, pl.vs1 - pl.as, 0, pl.as1, MPA_F_EXT_LEFT | MPA_F_SS_SKIP0, opt.io));   // starts at the window's first position
+		if (retry) {                                          // 5'-end exon: the same with a cheaper intron, on the window's last max_ext rows
+			const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
+			pl.t_left2 = (int32_t)qs.local1.size();
+			qs.local1.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT | (as_alt == pl.as ? MPA_F_SS_SKIP0 : 0), opt.io_end));
+		}
 		if (pl.has_right) {
 			pl.t_right = (int32_t)qs.local1.size();
 			qs.local1.push_back(make_task(qs, r, pl.mid_ve, pl.ae - pl.mid_ve, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io));
+			if (retry) {                                      // 3'-end exon
+				const int64_t l_ext = std::min<int64_t>(pl.ae - pl.mid_ve, opt.max_ext);
+				pl.t_right2 = (int32_t)qs.local1.size();
+				qs.local1.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
+			}
 		}
 		int32_t ne0 = (int32_t)(pl.vs1 - pl.vs0), ae0 = pl.as1;
 		for (int32_t i = pl.i0 + 1; i < r.cnt; ++i) {
@@ -753,52 +767,34 @@ static void emit_round1(mpa_batch_s *b)
 	});
 }
 
+// round 1 in (rst == nullptr: there was nothing to compute), round 2 out: the spans the two extensions accepted, re-aligned with
+// traceback (the first and the last mp_align_seq() call of align.c:297-300, 331)
 static void take_round1_emit_round2(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t *pool)
 {
 	const mpa_mapopt_t &opt = b->opt;
-	parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t qi) {
+	if (rst) parallel_for(b->n_threads, (int64_t)b->qs.size(), [&](int64_t qi) {
 		QueryState &qs = b->qs[qi];
-		qs.local2.clear();
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
-			const Region &r = qs.regs[pl.reg];
 			const mpa_dp_rst_t *mine = rst + qs.base1;                 // this query's slice of the round-1 results
 			for (Segment &g : pl.gaps) store_result(g, mine, pool);
 			pl.l_nt = mine[pl.t_left].nt_len, pl.l_aa = mine[pl.t_left].aa_len;
-			if (pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && opt.io > opt.io_end) {   // 5'-end exon: retry with a cheaper intron
-				const int64_t as_alt = pl.vs1 - pl.as > opt.max_ext ? pl.vs1 - opt.max_ext : pl.as;
-				pl.t_left2 = (int32_t)qs.local2.size();
-				qs.local2.push_back(make_task(qs, r, as_alt, pl.vs1 - as_alt, 0, pl.as1, MPA_F_EXT_LEFT | (as_alt == pl.as ? MPA_F_SS_SKIP0 : 0), opt.io_end));
-			}
+			// the terminal-exon repeat counts iff the reference would have made it AND it reaches the end of the protein (align.c:290-296)
+			if (pl.t_left2 >= 0 && pl.l_aa != pl.as1 && pl.l_nt < opt.max_ext && mine[pl.t_left2].aa_len == pl.as1)
+				pl.l_nt = mine[pl.t_left2].nt_len, pl.l_aa = mine[pl.t_left2].aa_len;
 			if (pl.has_right) {
 				pl.r_nt = mine[pl.t_right].nt_len, pl.r_aa = mine[pl.t_right].aa_len;
-				if (pl.r_aa < qs.qlen - pl.mid_qe && pl.r_nt < opt.max_ext && opt.io > opt.io_end) {
-					const int64_t l_ext = std::min<int64_t>(pl.ae - pl.mid_ve, opt.max_ext);
-					pl.t_right2 = (int32_t)qs.local2.size();
-					qs.local2.push_back(make_task(qs, r, pl.mid_ve, l_ext, pl.mid_qe, qs.qlen - pl.mid_qe, MPA_F_EXT_RIGHT, opt.io_end));
-				}
+				if (pl.t_right2 >= 0 && pl.r_aa < qs.qlen - pl.mid_qe && pl.r_nt < opt.max_ext && mine[pl.t_right2].aa_len == qs.qlen - pl.mid_qe)
+					pl.r_nt = mine[pl.t_right2].nt_len, pl.r_aa = mine[pl.t_right2].aa_len;
 			}
 		}
 	});
-	b->tasks.clear();
-	for (QueryState &qs : b->qs) {
-		qs.base2 = (int64_t)b->tasks.size();
-		b->tasks.insert(b->tasks.end(), qs.local2.begin(), qs.local2.end());
-		std::vector<mpa_dp_task_t>().swap(qs.local2);
-	}
-}
-
-static void take_round2_emit_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst)
-{
 	std::vector<mpa_dp_task_t> next;
 	for (size_t qi = 0; qi < b->qs.size(); ++qi) {
 		QueryState &qs = b->qs[qi];
 		for (size_t pi = 0; pi < qs.plans.size(); ++pi) {
 			AlignPlan &pl = qs.plans[pi];
 			Region &r = qs.regs[pl.reg];
-			const mpa_dp_rst_t *mine = rst ? rst + qs.base2 : nullptr;    // this query's slice of the round-2 results
-			if (pl.t_left2 >= 0 && mine[pl.t_left2].aa_len == pl.as1) pl.l_nt = mine[pl.t_left2].nt_len, pl.l_aa = mine[pl.t_left2].aa_len;
-			if (pl.t_right2 >= 0 && mine[pl.t_right2].aa_len == qs.qlen - pl.mid_qe) pl.r_nt = mine[pl.t_right2].nt_len, pl.r_aa = mine[pl.t_right2].aa_len;
 			// region start after the left extension (align.c:297-300); its span is the first mp_align_seq() call
 			r.vs = pl.vs1 - pl.l_nt;
 			r.qs = pl.as1 - pl.l_aa;
@@ -1253,12 +1249,8 @@ int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpop
 		b->round = 1;
 		if (b->tasks.empty()) { take_round3(b, nullptr, nullptr); b->round = 4; }   // nothing to align at all
 	}
-	// skip empty rounds (e.g. no retry needed anywhere)
-	while (b->round >= 1 && b->round <= 3 && b->tasks.empty()) {
-		if (b->round == 1) break;
-		if (b->round == 2) { take_round2_emit_round3(b, nullptr); b->round = 3; }
-		else { take_round3(b, nullptr, nullptr); b->round = 4; }
-	}
+	// (round 2 without tasks: every accepted span took the ungapped shortcut)
+	if (b->round == 2 && b->tasks.empty()) { take_round3(b, nullptr, nullptr); b->round = 4; }
 	if (b->round >= 4) { *tasks = nullptr; return 0; }
 	*tasks = b->tasks.data();
 	return (int64_t)b->tasks.size();
@@ -1268,8 +1260,7 @@ static int mpa_batch_dp_results_impl(mpa_batch_t *b, const mpa_dp_rst_t *rst, co
 {
 	double t0 = now_ms();
 	if (b->round == 1) { take_round1_emit_round2(b, rst, cigar_pool); b->round = 2; timing_note("take 1 / emit 2", now_ms() - t0); }
-	else if (b->round == 2) { take_round2_emit_round3(b, rst); b->round = 3; timing_note("take 2 / emit 3", now_ms() - t0); }
-	else if (b->round == 3) { take_round3(b, rst, cigar_pool); b->round = 4; b->tasks.clear(); timing_note("take 3 + finish", now_ms() - t0); }
+	else if (b->round == 2) { take_round3(b, rst, cigar_pool); b->round = 4; b->tasks.clear(); timing_note("take 2 + finish", now_ms() - t0); }
 	else { set_error("mpa_batch_dp_results called out of sequence"); return MPA_ERR_ARG; }
 	return MPA_OK;
 }

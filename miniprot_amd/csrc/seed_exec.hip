@@ -258,6 +258,14 @@ struct ExtractArgs {
 __device__ long long *g_extract_prof = nullptr;
 __device__ int g_extract_prof_n = 0;         // problems the buffer has room for (launches of other contexts may have more)
 
+// the team's fast scratch memory: 8 KB of LDS per wavefront (k_chain_extract is one wavefront per workgroup)
+#define EXTRACT_STAGE_WORDS 1024
+__device__ __forceinline__ uint64_t *g_extract_stage()
+{
+	__shared__ uint64_t stage[EXTRACT_STAGE_WORDS];
+	return stage;
+}
+
 // the team of chain_core.h on the device: the 64 lanes of one wavefront
 struct CoopWave {
 	static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
@@ -302,6 +310,7 @@ struct CoopWave {
 	}
 	static __device__ __forceinline__ int first_unset(uint64_t m) { return m == ~0ull ? 64 : __ffsll((long long)~m) - 1; }
 	static __device__ __forceinline__ int lowest(uint64_t m) { return __ffsll((long long)m) - 1; }
+	static __device__ __forceinline__ uint64_t *scratch(int64_t *cap) { *cap = EXTRACT_STAGE_WORDS; return g_extract_stage(); }
 	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
 };
 
