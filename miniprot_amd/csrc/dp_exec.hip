@@ -41,7 +41,18 @@ static thread_local bool tl_alloc_failed = false;         // the last pool reque
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
+	// high-water mark of this pool over all contexts that play the same part in the stream pipeline (DP lane, seeder, planner):
+	// the batches of a job are alike, so what one lane needed for its pool the others will need too -- a context that has to
+	// (re)allocate sizes the pool for the largest request any of them has seen, and the first batches of a stream do the growing
+	// once for everybody instead of once per context (a growth is a hipFree: it waits for the whole device)
+	std::atomic<size_t> *hint = nullptr;
 	int ensure(size_t bytes) {
+		if (hint) {
+			size_t h = hint->load(std::memory_order_relaxed);
+			while (bytes > h && !hint->compare_exchange_weak(h, bytes, std::memory_order_relaxed)) {}
+			if (bytes <= cap) return MPA_OK;
+			if (h > bytes) bytes = h;
+		}
 		if (bytes <= cap) return MPA_OK;
 		const double t0 = now_ms();
 		// (free, then allocate: measured -- round 3, call 18 -- a pool that keeps its old block until the stream is over and only
@@ -51,12 +62,9 @@ struct DevBuf {
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
-		// (tl_pool_scale: the stage thread is working on one of that many parts of a mini-batch -- the pool is sized for the whole
-		// batches the same context will meet later in the stream)
-		size_t want = bytes * (size_t)std::max(1, tl_pool_scale);
+		size_t want = bytes;
 		want += want / 3 + 4096;
 		hipError_t e = hipMalloc(&p, want);
-		if (e != hipSuccess && tl_pool_scale > 1) { (void)hipGetLastError(); want = bytes + bytes / 3 + 4096; e = hipMalloc(&p, want); }
 		if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr, tl_alloc_failed = true; set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
 		g_dev_bytes += (long long)cap;
@@ -93,7 +101,7 @@ struct HostPinned {
 		if (bytes <= cap) return MPA_OK;
 		if (p) (void)hipHostFree(p);
 		p = nullptr, cap = 0;
-		const size_t want = bytes * (size_t)std::max(1, tl_pool_scale) * 3 / 2 + 4096;   // (re-pinning host memory is slow: grow in big steps)
+		const size_t want = bytes * 3 / 2 + 4096;   // (re-pinning host memory is slow: grow in big steps)
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return MPA_ERR_HIP; }
 		cap = want;
 		return MPA_OK;
@@ -149,10 +157,27 @@ struct mpa_ctx_s {
 	bool no_split = false;                    // this mpa_dp_run() repeats a round whose workgroup hand-off timed out: 512/1024-column calls go to k_ext_huge
 	int64_t handoff_retries = 0;              // how often that has happened on this context (mpa_dp_handoff_retries)
 	std::vector<SeedHold*> holds;             // result holders of the stream pipeline's batches (owned; ctx_seed_hold)
+	struct PoolHints { std::atomic<size_t> dev[3][96]; };
+	PoolHints *hints = nullptr;               // (root context only, owned) high-water marks per pipeline role and pool
 	bool antidiag = false;                    // (measurement) the 32-column extension class runs on the anti-diagonal prototype, k_ext_antidiag (mpa_dbg_antidiag)
 };
 
 namespace mpa {
+
+// every device pool of a context, in a fixed order (the index is the pool's identity across contexts)
+template<typename F> static void ctx_each_devbuf(mpa_ctx_s *ctx, F f)
+{
+	SeedBufs &B = ctx->seed;
+	DevBuf *all[] = { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
+	                  &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
+	                  &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
+	                  &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
+	                  &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
+	                  &B.pf_qfirst2, &B.val64[0], &B.val64[1],
+	                  &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys };
+	int k = 0;
+	for (DevBuf *b : all) f(*b, k++);
+}
 
 // Wait for everything enqueued on a stream -- asleep.  hipStreamSynchronize() spins on the completion signal by default; a
 // pipeline keeps eight or nine host threads waiting for the device at any time (DP lanes, seeders, planners), and on a host
@@ -334,18 +359,13 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	SeedBufs &B = ctx->seed;
-	for (DevBuf *b : { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
-	                   &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
-	                   &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
-	                   &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
-	                   &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
-	                   &B.pf_qfirst2, &B.val64[0], &B.val64[1],
-	                   &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys }) b->release();
+	ctx_each_devbuf(ctx, [](DevBuf &b, int) { b.release(); });
 	for (HostPinned *h : { &B.h_jobs, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
 	auto drop_hold = [](SeedHold &H) { for (HostPinned *h : { &H.h_pos, &H.h_f, &H.h_pred, &H.h_a, &H.h_U, &H.h_A }) h->release(); };
 	drop_hold(B.own);
 	for (SeedHold *H : ctx->holds) { drop_hold(*H); delete H; }
 	ctx->holds.clear();
+	delete ctx->hints, ctx->hints = nullptr;
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->lev) if (e) (void)hipEventDestroy(e);
 	if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -380,6 +400,16 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 	return ctx->siblings[k - 1];
 }
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off) { ctx->side_off = off; }
+// `ctx` (the root itself or one of its siblings) plays part `role` of the root's stream pipeline: 0 DP lane, 1 seeder, 2 planner
+void ctx_set_role(mpa_ctx_t *root, mpa_ctx_t *ctx, int role)
+{
+	if (!root->hints) {
+		root->hints = new mpa_ctx_s::PoolHints();
+		for (auto &r : root->hints->dev) for (auto &h : r) h.store(0);
+	}
+	mpa_ctx_s::PoolHints *H = root->hints;
+	ctx_each_devbuf(ctx, [&](DevBuf &b, int k) { b.hint = k < 96 ? &H->dev[role][k] : nullptr; });
+}
 SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k)
 {
 	while ((int)ctx->holds.size() <= k) ctx->holds.push_back(new SeedHold());

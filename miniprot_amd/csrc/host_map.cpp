@@ -1442,6 +1442,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	n_lanes = std::max(1, std::min(n_lanes, 8));
 	std::vector<mpa_ctx_t*> lane_ctx((size_t)n_lanes, ctx);
 	for (int d = 1; d < n_lanes; ++d) if (!(lane_ctx[d] = ctx_sibling(ctx, d))) return MPA_ERR_HIP;
+	for (int d = 0; d < n_lanes; ++d) ctx_set_role(ctx, lane_ctx[d], 0);
 	// HIP maps streams to its hardware queues by creation order; with 17 streams per context the first side streams of the
 	// third context land on the queues of the second one's (measured, rocprofv3 queue ids), three further on they do not
 	if (n_lanes > 2) ctx_set_side_offset(lane_ctx[2], 3);
@@ -1468,6 +1469,8 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<mpa_ctx_t*> seed_dev((size_t)n_seed, nullptr), plan_dev((size_t)n_plan, nullptr);
 	for (int k = 0; k < n_seed; ++k) if (!(seed_dev[k] = ctx_sibling(ctx, n_lanes + k))) return MPA_ERR_HIP;
 	for (int k = 0; k < n_plan; ++k) if (!(plan_dev[k] = ctx_sibling(ctx, n_lanes + n_seed + k))) return MPA_ERR_HIP;
+	for (int k = 0; k < n_seed; ++k) ctx_set_role(ctx, seed_dev[k], 1);
+	for (int k = 0; k < n_plan; ++k) ctx_set_role(ctx, plan_dev[k], 2);
 	std::vector<SeedHold*> hold((size_t)n_seed_ctx, nullptr);
 	for (int k = 0; k < n_seed_ctx; ++k) hold[k] = ctx_seed_hold(ctx, k);
 	static const char *const kSeedName[4] = { "seed0", "seed1", "seed2", "seed3" };
@@ -1607,7 +1610,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (int d = 1; d < n_lanes; ++d) lanes.emplace_back(dp_lane, d, lane_ctx[d]);
 	dp_lane(0, ctx);
 	for (auto &t : lanes) t.join();
-	tl_thread_div = 1, tl_pool_lane = 0, tl_pool_scale = 1;   // (lane 0 ran on the caller's thread)
+	tl_thread_div = 1, tl_pool_lane = 0;                   // (lane 0 ran on the caller's thread)
 	finisher.join();
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();

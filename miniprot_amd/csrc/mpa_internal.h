@@ -83,8 +83,8 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi);           // k-mer table of 
 void dev_free_index(mpa_idx_s *mi);
 mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k);   // extra context on the same device (k >= 1), owned by ctx
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx);
-extern thread_local int tl_pool_scale;   // > 1 while this thread works on one of that many parts of a mini-batch: device / pinned pools that have to grow are sized for the whole batch
 void ctx_set_side_offset(mpa_ctx_t *ctx, int off);   // which of its side streams a DP round starts with
+void ctx_set_role(mpa_ctx_t *root, mpa_ctx_t *ctx, int role);   // ctx's pools share their high-water marks with the root's other contexts of that role (0 DP lane, 1 seeder, 2 planner)
 
 // ---- GPU seeding (seed_exec.hip + the driver in dp_exec.hip) --------------------------------------
 struct SeedJob { int64_t kb_off, dst; int32_t cnt, qpos, qid; };   // one kept seed: its occurrence list and where its anchors go

@@ -15,7 +15,6 @@
 #include "mpa_internal.h"
 
 namespace mpa {
-thread_local int tl_pool_scale = 1;
 
 
 const char *const kAA = "ARNDCQEGHILKMFPSTWYV*X";
