@@ -414,7 +414,7 @@ def main():
                    "rounds_in_flight_avg": st["ms_round"] * 1e-3 / elapsed / max(world, 1),
                    # wall clock of the pipeline stages per mini-batch (rank 0; stage threads run side by side: these are latencies)
                    "seeding_wall_ms_per_batch": per("seeding"), "planning_wall_ms_per_batch": per("planning"), "dp_wall_ms_per_batch": per("dp"),
-                   "output_wall_ms_per_batch": per("output"),
+                   "output_wall_ms_per_batch": per("output"), "sketch_wall_ms_per_batch": per("sketch"),
                    # HBM held through the library (resident index + all pools of all contexts), per GPU; pool re-allocations inside the timed region
                    "hbm_resident_gb": st["hbm_bytes"] / max(world, 1) / 1e9, "pool_growth_events_timed": st["pool_growths_timed"],
                    "pool_growth_events_total": st["pool_growths_total"], "cli_end_to_end": cli,
@@ -472,6 +472,7 @@ def main():
                "paf_identical": r["paf_identical"], "identity": r["identity"], "md5_first_pass": r["md5_first_pass"], "mini_batches_all_gpus": r["mini_batches_all_gpus"],
                "rounds_in_flight_avg": r["rounds_in_flight_avg"], "seeding_wall_ms_per_batch": r["seeding_wall_ms_per_batch"],
                "planning_wall_ms_per_batch": r["planning_wall_ms_per_batch"], "dp_wall_ms_per_batch": r["dp_wall_ms_per_batch"], "output_wall_ms_per_batch": r["output_wall_ms_per_batch"],
+               "sketch_wall_ms_per_batch": r["sketch_wall_ms_per_batch"],
                "hbm_resident_gb": r["hbm_resident_gb"], "pool_growth_events_timed": r["pool_growth_events_timed"], "pool_growth_events_total": r["pool_growth_events_total"],
                "cli_end_to_end": r["cli_end_to_end"],
                "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"], "host_throttled": r["host_throttled"],

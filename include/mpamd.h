@@ -199,8 +199,9 @@ int64_t mpa_device_bytes(void);
 int64_t mpa_pool_growths(void);
 /* Wall-clock milliseconds and calls of the stream pipeline's stages (mpa_map_batches) since the last reset, summed over the
  * stage's threads: [0] seeding (sketch, lookup, device seeding + both chaining rounds), [1] planning (regions, refinement, plans),
- * [2] the DP rounds of a batch, host round trips included, [3] output (statistics, flatten, text).  ms / calls may be NULL. */
-void mpa_stage_clocks(double ms[4], int64_t calls[4], int reset);
+ * [2] the DP rounds of a batch, host round trips included, [3] output (statistics, flatten, text), [4] sketch (the host half of
+ * seeding: protein sketch, bucket lookup, occurrence cut-off; [0] is then the device half).  ms / calls may be NULL. */
+void mpa_stage_clocks(double ms[5], int64_t calls[5], int reset);
 
 /* ---- boundary #1: batched mp_map() ------------------------------------------------------------------------ */
 /* mp_feat_t / mp_extra_t / mp_reg1_t (miniprot.h:108-145) flattened for a C ABI */

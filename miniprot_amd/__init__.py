@@ -196,9 +196,9 @@ class Context:
     @staticmethod
     def stage_clocks(reset=False):
         """{stage: (wall ms, calls)} of mpa_map_batches' stages since the last reset (mpa_stage_clocks)"""
-        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        ms, n = (C.c_double * 5)(), (C.c_int64 * 5)()
         lib().mpa_stage_clocks(ms, n, 1 if reset else 0)
-        return {k: (ms[i], int(n[i])) for i, k in enumerate(("seeding", "planning", "dp", "output"))}
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(("seeding", "planning", "dp", "output", "sketch"))}
 
     @staticmethod
     def pool_growths():

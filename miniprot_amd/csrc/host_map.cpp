@@ -86,6 +86,10 @@ struct mpa_batch_s {
 	std::vector<mpa_dp_task_t> tasks;
 	bool seeded_on_device = false;   // between the two seeding phases: `sparse` holds the device's pre-chain result
 	PrechainSparse sparse;
+	// between the host half of seeding (sketch, lookup, cut-off: batch_sketch_phase) and its device half: the kept seeds of every
+	// query as occurrence lists (one job per seed) and the first anchor of every query; empty = the batch is seeded on the host
+	std::vector<SeedJob> seed_jobs;
+	std::vector<int64_t> seed_qfirst;
 };
 
 namespace mpa {
@@ -171,8 +175,8 @@ template<typename F> static void parallel_for(int n_threads, int64_t n, F fn)
 // per-substage CPU-time accumulators of stage A (thread CPU time summed over the workers; printed with MPA_TIMING=1)
 static std::atomic<int64_t> g_acc[16];
 // wall-clock microseconds and calls of the stream pipeline's stages since the last reset (mpa_stage_clocks): 0 seeding, 1 planning,
-// 2 DP rounds of a batch (all of them, host round trips included), 3 output (flatten + text)
-static std::atomic<int64_t> g_stage_us[4], g_stage_n[4];
+// 2 DP rounds of a batch (all of them, host round trips included), 3 output (flatten + text), 4 sketch (host half of seeding)
+static std::atomic<int64_t> g_stage_us[5], g_stage_n[5];
 struct StageClock {
 	int k; double t0;
 	explicit StageClock(int k_) : k(k_), t0(now_ms()) {}
@@ -856,9 +860,9 @@ static int gpu_seeding_mode()
 // busy with DP rounds (measured: 2.7 M anchors at config 2 -> host, 25 M at 600 Mbp and 240 M at config 3 -> device).
 static const int64_t kDeviceSeedingMinAnchors = 8000000;
 
-// Phase 1 of a batch: seeds of every query; with a device context and a batch that is worth it, also the anchors, their
-// sort and the forward pass of the pre-chain (seed_exec.hip).
-static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, bool want_chains = true, SeedHold *hold = nullptr)
+// Phase 1a of a batch, host only: the seeds of every query (sketch, bucket lookup, occurrence cut-off: map.c:126-177 up to the
+// anchor loop) and, if the batch is worth seeding on the device, its seed jobs.  In the stream pipeline this is a stage of its own.
+static mpa_batch_t *batch_sketch_phase(bool have_device, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads)
 {
 	if (mi->kb.empty() && mi->n_kb == 0) { set_error("the index has no k-mer table (genome-only index): cannot map"); return nullptr; }
 	mpa_batch_s *b = new mpa_batch_s();
@@ -872,19 +876,15 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_seeds(b, b->qs[i]); });
 	timing_note("  A1: seeds of all queries", now_ms() - t0);
 	const int mode = gpu_seeding_mode();
-	if (!seed_ctx || mode == 0 || !prechain_enabled(*opt) || mi->opt.bbit <= 0 || q->n_seq == 0) return b;
-	// (buffers of the seeding thread, reused: fresh multi-MB vectors per batch mean page faults under an address space that
-	// the planner's workers are busy mapping and unmapping)
-	static thread_local std::vector<int64_t> qfirst;
-	static thread_local std::vector<size_t> jfirst;
-	static thread_local std::vector<SeedJob> jobs;
-	qfirst.assign((size_t)q->n_seq + 1, 0), jfirst.assign((size_t)q->n_seq + 1, 0);
+	if (!have_device || mode == 0 || !prechain_enabled(*opt) || mi->opt.bbit <= 0 || q->n_seq == 0) return b;
+	std::vector<int64_t> &qfirst = b->seed_qfirst;
+	std::vector<size_t> jfirst((size_t)q->n_seq + 1, 0);
+	qfirst.assign((size_t)q->n_seq + 1, 0);
 	for (int32_t i = 0; i < q->n_seq; ++i) qfirst[i + 1] = qfirst[i] + b->qs[i].n_anchor, jfirst[i + 1] = jfirst[i] + b->qs[i].seeds.size();
-	if (mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) return b;
-	if (jobs.size() < jfirst[q->n_seq]) jobs.resize(jfirst[q->n_seq]);
+	if ((mode < 0 && qfirst[q->n_seq] < kDeviceSeedingMinAnchors) || jfirst[q->n_seq] == 0) { qfirst.clear(); return b; }
+	b->seed_jobs.resize(jfirst[q->n_seq]);
 	const int64_t n_bucket = (int64_t)mi->ki.size();
-	// (pointers, not the thread_local vectors: the workers have their own, empty, instances of those)
-	SeedJob *const jobs_p = jobs.data();
+	SeedJob *const jobs_p = b->seed_jobs.data();
 	const int64_t *const qfirst_p = qfirst.data();
 	const size_t *const jfirst_p = jfirst.data();
 	parallel_for(b->n_threads, q->n_seq, [&, jobs_p, qfirst_p, jfirst_p](int64_t i) {
@@ -896,21 +896,38 @@ static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, c
 			dst += en - st;
 		}
 	});
+	timing_note("  A1: seed jobs", now_ms() - t0);
+	return b;
+}
+
+// Phase 1b: the anchors of the seed jobs, the pre-chain and the main chain on the device (seed_exec.hip).  false = error.
+static bool batch_device_seed_phase(mpa_ctx_t *seed_ctx, mpa_batch_s *b, bool want_chains, SeedHold *hold)
+{
+	if (!seed_ctx || b->seed_jobs.empty()) return true;
 	const double t1 = now_ms();
-	timing_note("  A1: seed jobs", t1 - t0);
-	// (with the main chain's parameters the device carries on through both chaining rounds, unless MPA_GPU_CHAIN=1 asks for the older
-	// arrangement -- forward passes on the device, extraction on the host -- or the caller only wants the pre-chain)
-	const ChainParams main_cp = main_chain_params(mi, *opt);
-	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, *opt), q->n_seq, qfirst.data(), jobs.data(), (int64_t)jfirst[q->n_seq], b->sparse,
-	                                    want_chains ? &main_cp : nullptr, hold);
+	const mpa_idx_t *mi = b->mi;
+	// (with the main chain's parameters the device carries on through both chaining rounds, unless the caller only wants the pre-chain)
+	const ChainParams main_cp = main_chain_params(mi, b->opt);
+	const int rc = dev_prechain_forward(seed_ctx, const_cast<mpa_idx_s*>(mi), prechain_params(mi, b->opt), b->q.n_seq, b->seed_qfirst.data(), b->seed_jobs.data(),
+	                                    (int64_t)b->seed_jobs.size(), b->sparse, want_chains ? &main_cp : nullptr, hold);
+	std::vector<SeedJob>().swap(b->seed_jobs);
+	std::vector<int64_t>().swap(b->seed_qfirst);
 	if (rc == MPA_ERR_UNSUPPORTED) {                    // e.g. the batch does not fit the device: seed on the host
 		if (timing_on()) fprintf(stderr, "[mpa-timing]   device seeding declined (%s): seeding on the host\n", mpa_last_error());
-		return b;
+		return true;
 	}
-	if (rc != MPA_OK) { delete b; return nullptr; }
+	if (rc != MPA_OK) return false;
 	b->seeded_on_device = true;
-	timing_note("  seeding on the GPU (gather+sort+pre-chain fwd)", now_ms() - t1);
-	timing_note("stage A1 (seeds, device seeding)", now_ms() - t0);
+	timing_note("  seeding on the GPU (sift + pre-chain + both chaining rounds)", now_ms() - t1);
+	return true;
+}
+
+// Phase 1 of a batch: seeds of every query; with a device context and a batch that is worth it, also the anchors, the pre-chain
+// and the main chain on the device.
+static mpa_batch_t *batch_seed_phase(mpa_ctx_t *seed_ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, bool want_chains = true, SeedHold *hold = nullptr)
+{
+	mpa_batch_t *b = batch_sketch_phase(seed_ctx != nullptr, mi, opt, q, n_threads);
+	if (b && !batch_device_seed_phase(seed_ctx, b, want_chains, hold)) { delete b; return nullptr; }
 	return b;
 }
 
@@ -1420,11 +1437,11 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		mpa_batch_t *b = nullptr;
 		int32_t g = 0, j = 0;                             // index into batches[]; ordinal of the batch among those this call maps
 		mpa_qbatch_t q{};                                 // the batch's queries
-		bool seeded = false, begun = false, dp_done = false;
+		bool sketched = false, seeded = false, begun = false, dp_done = false;
 	};
 	std::vector<Slot> slot((size_t)n_batches);
 	std::vector<uint8_t> taken((size_t)n_batches, 0);   // batches a claim has handed out already
-	std::mutex mu, claim_mu;
+	std::mutex mu;
 	std::condition_variable cv;
 	int32_t n_dp_done = 0, n_planned = 0, rc_all = MPA_OK, next_seed = 0, next_plan = 0;
 	int32_t n_total = (int32_t)slot.size();               // units this call maps: shrinks to the number created when the job runs out (guarded by mu)
@@ -1478,49 +1495,73 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> g(mu); if (rc_all == MPA_OK) rc_all = rc, err = msg; cv.notify_all(); };
 
 	// (an exception inside a stage thread -- out of memory, say -- must become an error code, not std::terminate)
+	// Sketcher: the host half of seeding (protein sketch, bucket lookup, occurrence cut-off, seed jobs: ~27 ms per 4 000 proteins)
+	// as a stage of its own, one or two batches ahead of the seeders, whose stage is then device work only -- it was the stage that
+	// bounded the stream (141 ms of wall per batch on two seeders, round 4).  It also claims the job's batches.
+	auto sketcher_body = [&]() { try {
+		tl_pool_lane = 20, tl_thread_div = 4;
+		WorkerPool::get(tl_pool_lane).label_ = "sketch: worker pool";
+		CpuSpan cs("sketch: stage thread");
+		for (;;) {
+			int32_t k;
+			{	// stay at most n_seed + 1 batches ahead of the seeders
+				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || n_created - next_seed <= n_seed; });
+				if (rc_all != MPA_OK) return;
+			}
+			{	// (a claim may be a round trip to another process: outside the pipeline's lock)
+				const int32_t want = claim ? claim(claim_user) : (next_own < n_batches ? next_own++ : -1);
+				std::lock_guard<std::mutex> g(mu);
+				if (want < 0 || want >= n_batches) { exhausted = true, n_total = n_created; cv.notify_all(); return; }   // the job has no batch left
+				// (a claim function that hands a batch out twice -- a counter that was not reset, a wrong job key -- would run the
+				// slots, results[] and order[] past the caller's arrays: an error, not heap corruption)
+				if (n_created >= n_batches || taken[(size_t)want]) {
+					if (rc_all == MPA_OK) rc_all = MPA_ERR_ARG, err = "mpa_map_batches_claim: claim() returned batch " + std::to_string(want) + " twice (or more batches than the job has)";
+					exhausted = true, n_total = n_created; cv.notify_all(); return;
+				}
+				taken[(size_t)want] = 1;
+				k = n_created;
+				Slot &u = slot[(size_t)k];
+				u.g = want, u.j = n_claimed, u.q = batches[want];
+				++n_created, ++n_claimed;
+			}
+			trace("sketch", k, "begin");
+			mpa_batch_t *b;
+			{ StageClock sc(4); b = batch_sketch_phase(true, mi, opt, &slot[k].q, n_threads); }
+			trace("sketch", k, "end");
+			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
+			std::lock_guard<std::mutex> g(mu);
+			slot[k].b = b, slot[k].sketched = true;
+			cv.notify_all();
+		}
+	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("sketch stage: ") + e.what()); } };
 	auto seeder_body = [&](int sd) { try {
 		tl_pool_lane = 10 + sd, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "seeding: worker pool";
-		CpuSpan cs("seeding: stage thread (host prep + waits)");
+		CpuSpan cs("seeding: stage thread (waits for the device)");
 		for (;;) {
 			int32_t k;
-			{	// (claims are serialised among the seeders, outside the pipeline's own lock: a claim may be a round trip to another process)
-				std::lock_guard<std::mutex> cl(claim_mu);
-				bool need_batch;
-				{ std::lock_guard<std::mutex> g(mu); if (rc_all != MPA_OK || (next_seed >= n_created && exhausted)) return; need_batch = next_seed >= n_created; }
-				if (need_batch) {                                     // no unit waiting: the next batch of the job, cut into its units
-					const int32_t want = claim ? claim(claim_user) : (next_own < n_batches ? next_own++ : -1);
-					std::lock_guard<std::mutex> g(mu);
-					if (want < 0 || want >= n_batches) { exhausted = true, n_total = n_created; cv.notify_all(); return; }   // the job has no batch left
-					// (a claim function that hands a batch out twice -- a counter that was not reset, a wrong job key -- would run the
-					// slots, results[] and order[] past the caller's arrays: an error, not heap corruption)
-					if (n_created >= n_batches || taken[(size_t)want]) {
-						if (rc_all == MPA_OK) rc_all = MPA_ERR_ARG, err = "mpa_map_batches_claim: claim() returned batch " + std::to_string(want) + " twice (or more batches than the job has)";
-						exhausted = true, n_total = n_created; cv.notify_all(); return;
-					}
-					taken[(size_t)want] = 1;
-					Slot &u = slot[(size_t)n_created];
-					u.g = want, u.j = n_claimed, u.q = batches[want];
-					++n_created, ++n_claimed;
-				}
-				std::lock_guard<std::mutex> g(mu);
-				k = next_seed++;                                      // (a free seeder takes the next unit in input order)
-			}
-			{	// its result lives in a seeding context until the batch is planned: wait for the batch that had this context before
+			{	// a free seeder takes the next sketched batch in input order; its result lives in a holder until the batch is planned:
+				// wait for the batch that had this holder before
 				std::unique_lock<std::mutex> g(mu);
+				cv.wait(g, [&] { return rc_all != MPA_OK || (next_seed < n_created && slot[next_seed].sketched) || (exhausted && next_seed >= n_total); });
+				if (rc_all != MPA_OK || !(next_seed < n_created && slot[next_seed].sketched)) return;
+				k = next_seed++;
+				cv.notify_all();                                      // (the sketcher may go one further)
 				cv.wait(g, [&] { return rc_all != MPA_OK || k < n_seed_ctx || slot[k - n_seed_ctx].begun; });
 				if (rc_all != MPA_OK) return;
 			}
 			trace(kSeedName[sd], k, "begin");
-			mpa_batch_t *b;
-			{ StageClock sc(0); b = batch_seed_phase(seed_dev[sd], mi, opt, &slot[k].q, n_threads, true, hold[k % n_seed_ctx]); }
+			bool ok;
+			{ StageClock sc(0); ok = batch_device_seed_phase(seed_dev[sd], slot[k].b, true, hold[k % n_seed_ctx]); }
 			trace(kSeedName[sd], k, "end");
-			if (!b) { fail(MPA_ERR_ARG, mpa_last_error()); return; }
+			if (!ok) { fail(MPA_ERR_HIP, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
-			slot[k].b = b, slot[k].seeded = true;
+			slot[k].seeded = true;
 			cv.notify_all();
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("seeding stage: ") + e.what()); } };
+	std::thread sketcher(sketcher_body);
 	std::vector<std::thread> seeders;
 	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
 	auto planner_body = [&](int pl) { try {
@@ -1612,6 +1653,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	for (auto &t : lanes) t.join();
 	tl_thread_div = 1, tl_pool_lane = 0;                   // (lane 0 ran on the caller's thread)
 	finisher.join();
+	sketcher.join();
 	for (auto &t : seeders) t.join();
 	for (auto &t : planners) t.join();
 	ctx_absorb_sibling_stats(ctx);
@@ -1631,9 +1673,9 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	return rc_all;
 }
 
-void mpa_stage_clocks(double ms[4], int64_t calls[4], int reset)
+void mpa_stage_clocks(double ms[5], int64_t calls[5], int reset)
 {
-	for (int k = 0; k < 4; ++k) {
+	for (int k = 0; k < 5; ++k) {
 		if (ms) ms[k] = (double)g_stage_us[k].load() / 1000.0;
 		if (calls) calls[k] = g_stage_n[k].load();
 		if (reset) g_stage_us[k] = 0, g_stage_n[k] = 0;
