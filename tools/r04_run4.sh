@@ -20,7 +20,7 @@ run s3l6p4 "MPA_SEEDERS=3 MPA_DP_LANES=6 MPA_PLANNERS=4" ""
 run b5000 "" "--batch 5000"
 ( MPA_TRACE=1 MPA_TIMING=1 python bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-cli --workload-cache $W ) > $O/trace.json 2> $O/trace.err
 python tools/gantt.py $O/trace.err > $O/pipeline_gantt.txt 2>&1; cat $O/pipeline_gantt.txt
-python tools/timing_agg.py $O/trace.err > $O/stage_clocks.txt 2>&1 || grep -E "mpa-timing|mpa-cpu" $O/trace.err | tail -80 > $O/stage_clocks.txt
+{ python tools/timing_agg.py < $O/trace.err; grep "mpa-cpu" $O/trace.err | tail -14; } > $O/stage_clocks.txt 2>&1
 tail -12 $O/stage_clocks.txt
 rm -f $O/trace.err
 rm -rf $W
