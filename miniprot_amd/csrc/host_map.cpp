@@ -550,7 +550,7 @@ static void stage_anchors_host(mpa_batch_s *b, QueryState &qs, std::vector<uint6
 		for (uint64_t kq : qs.seeds) {
 			const int64_t bkt = (int64_t)(uint32_t)kq, st = mi->ki[bkt], en = bkt + 1 < n_bucket ? mi->ki[bkt + 1] : mi->n_kb;
 			const uint64_t qpos = kq >> 32;
-			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb[j] << 32 | qpos);
+			for (int64_t j = st; j < en; ++j) a.push_back((uint64_t)mi->kb.at((size_t)j) << 32 | qpos);   // (at(): a mapped .mpi may leave kb misaligned)
 		}
 	}
 	g_acc[14] += (int64_t)a.size() * 1000;

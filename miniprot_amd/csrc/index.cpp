@@ -4,6 +4,10 @@
 // ntseq.c:89-114,163-205 (4-bit genome store) of the reference.  File layout:
 //   "MPI\3" | idxopt (20 B) | int64 n_kb | int32 n_ctg | int32 l_name | int64 l_seq | int64 len[n_ctg]
 //   | uint8 seq[(l_seq+1)/2] | char name[l_name] | int64 ki[1<<(4k-m)] | uint32 kb[n_kb]
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -94,15 +98,29 @@ using namespace mpa;
 
 extern "C" {
 
+// The file is MAPPED, not read: the packed genome and the occurrence lists (1.5 + 6 GB at 3 Gbp) are views into a private
+// read-only mapping -- nothing is copied, the pages come from the page cache, and the ranks of a multi-GPU job that restore
+// the same file share them (index.c:204-237 reads the file into malloc'd arrays).  Contig table, names and the bucket offsets
+// (64 MB, which the host stages index as aligned 64-bit integers) are copied out.
 mpa_idx_t *mpa_idx_restore(const char *fn)
 {
-	FILE *fp = fopen(fn, "rb");
-	if (!fp) { set_error(std::string("cannot open ") + fn); return nullptr; }
-	char magic[4];
+	const int fd = open(fn, O_RDONLY);
+	if (fd < 0) { set_error(std::string("cannot open ") + fn); return nullptr; }
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size < 44) { close(fd); set_error(std::string(fn) + " is not a valid .mpi index"); return nullptr; }
+	const size_t flen = (size_t)st.st_size;
+	// (MAP_PRIVATE + PROT_WRITE: callers of the reference's mp_idx_t get non-const pointers; a write would copy the page, never reach the file)
+	void *base = mmap(nullptr, flen, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (base == MAP_FAILED) { set_error(std::string("cannot map ") + fn); return nullptr; }
+	const char *f = (const char*)base;
+	size_t at = 0;
+	auto take = [&](void *dst, size_t bytes) -> bool { if (bytes > flen - at) return false; if (dst) memcpy(dst, f + at, bytes); at += bytes; return true; };
 	mpa_idx_s *mi = new mpa_idx_s();
+	char magic[4];
 	int32_t hdr[2];
-	bool ok = rd(fp, magic, 4) && memcmp(magic, kMagic, 4) == 0;
-	ok = ok && rd(fp, &mi->opt, 1) && rd(fp, &mi->n_kb, 1) && rd(fp, hdr, 2) && rd(fp, &mi->l_seq, 1);
+	bool ok = take(magic, 4) && memcmp(magic, kMagic, 4) == 0;
+	ok = ok && take(&mi->opt, sizeof(mi->opt)) && take(&mi->n_kb, 8) && take(hdr, 8) && take(&mi->l_seq, 8);
 	if (ok && set_trans_code((int)mi->opt.trans_code) < 0) ok = false;
 	// the header sizes come from a file: refuse nonsense before it turns into an allocation (and an exception across the C ABI)
 	if (ok) ok = hdr[0] >= 0 && hdr[1] >= 0 && mi->l_seq >= 0 && mi->n_kb >= 0 && mi->opt.kmer >= 1 && mi->opt.kmer <= 7 &&
@@ -113,12 +131,13 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 		mi->ctg.resize(n_ctg);
 		int64_t off = 0;
 		for (int32_t i = 0; i < n_ctg && ok; ++i) {
-			ok = rd(fp, &mi->ctg[i].len, 1);
+			ok = take(&mi->ctg[i].len, 8);
 			mi->ctg[i].off = off, off += mi->ctg[i].len;
 		}
-		mi->seq.resize((size_t)((mi->l_seq + 1) >> 1));
+		const size_t seq_bytes = (size_t)((mi->l_seq + 1) >> 1), seq_at = at;
+		ok = ok && take(nullptr, seq_bytes);
 		mi->names.resize(l_name);
-		ok = ok && rd(fp, mi->seq.data(), mi->seq.size()) && rd(fp, mi->names.data(), mi->names.size());
+		ok = ok && take(mi->names.data(), mi->names.size());
 		const char *p = mi->names.data(), *end = p + mi->names.size();
 		for (int32_t i = 0; i < n_ctg && ok; ++i) {
 			if (p >= end) { ok = false; break; }
@@ -127,12 +146,17 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 		}
 		const size_t n_bucket = (size_t)1 << (mi->opt.kmer * 4 - mi->opt.mod_bit);
 		mi->ki.resize(n_bucket);
-		mi->kb.resize((size_t)mi->n_kb);
-		ok = ok && rd(fp, mi->ki.data(), n_bucket) && rd(fp, mi->kb.data(), mi->kb.size());
+		ok = ok && take(mi->ki.data(), n_bucket * 8);
+		const size_t kb_at = at;
+		ok = ok && take(nullptr, (size_t)mi->n_kb * 4);
 		if (ok && off != mi->l_seq) ok = false;
+		if (ok) {
+			mi->seq.view((uint8_t*)base + seq_at, seq_bytes);
+			mi->kb.view((uint32_t*)((char*)base + kb_at), (size_t)mi->n_kb);
+		}
 	} catch (const std::exception&) { ok = false; }
-	fclose(fp);
-	if (!ok) { set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
+	if (!ok) { munmap(base, flen); set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
+	mi->map_base = base, mi->map_len = flen;
 	compute_block_offsets(mi);
 	return mi;
 }
@@ -244,7 +268,7 @@ static int mpa_idx_build_kmers_impl(mpa_idx_t *mi, int n_threads)
 	for (size_t b = 0; b < n_bucket; ++b) { const int64_t c = mi->ki[b]; mi->ki[b] = acc, acc += c; }
 	mi->n_kb = acc;
 	mi->kb.assign((size_t)acc, 0);
-	std::vector<int64_t> fill(mi->ki);
+	std::vector<int64_t> fill(mi->ki.data(), mi->ki.data() + mi->ki.size());
 	for (const auto &v : sk) for (uint64_t x : v) mi->kb[fill[x >> 32]++] = (uint32_t)x;
 	return MPA_OK;
 }
@@ -258,6 +282,7 @@ void mpa_idx_destroy(mpa_idx_t *mi)
 {
 	if (!mi) return;
 	dev_free_index(mi);
+	if (mi->map_base) munmap(mi->map_base, mi->map_len);
 	delete mi;
 }
 

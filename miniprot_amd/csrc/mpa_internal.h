@@ -7,6 +7,7 @@
 #include <new>
 #include <exception>
 #include <vector>
+#include <cstring>
 #include "../../include/mpamd.h"
 #include "chain_core.h"
 
@@ -52,6 +53,33 @@ struct Contig { int64_t off, len; std::string name; };
 
 struct DeviceIndex;                  // opaque, owned by dp executor (mpa_dp.hip)
 
+// The big arrays of an index (packed genome, bucket offsets, occurrence lists): either owned (an index that was built or read
+// into memory) or a VIEW into a read-only mapping of the .mpi file (mpa_idx_restore), so that the processes of a multi-GPU job --
+// one per GPU, each restoring the same file -- share ONE copy in the page cache instead of holding 7.6 GB each at 3 Gbp.
+// The interface is the subset of std::vector the library uses.  A view may be misaligned for T (the .mpi packs its sections back
+// to back): at() reads through memcpy; data() is for byte copies (upload, dump) and for callers of the reference's mp_idx_t.
+template<class T> struct IdxArray {
+	std::vector<T> own;
+	T *p = nullptr;
+	size_t n = 0;
+	T *data() { return p; }
+	const T *data() const { return p; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	T &operator[](size_t i) { return p[i]; }
+	const T &operator[](size_t i) const { return p[i]; }
+	T at(size_t i) const { T v; memcpy(&v, (const char*)p + i * sizeof(T), sizeof(T)); return v; }
+	void resize(size_t k) { adopt(); own.resize(k); sync(); }
+	void resize(size_t k, T v) { adopt(); own.resize(k, v); sync(); }
+	void assign(size_t k, T v) { own.assign(k, v); sync(); }
+	void clear() { own.clear(); sync(); }
+	void swap(std::vector<T> &o) { own.swap(o); sync(); }
+	void view(T *q, size_t k) { std::vector<T>().swap(own); p = q, n = k; }
+private:
+	void sync() { p = own.data(), n = own.size(); }
+	void adopt() { if (n && p != own.data()) { std::vector<T> c(n); memcpy(c.data(), p, n * sizeof(T)); own.swap(c); sync(); } }
+};
+
 } // namespace mpa
 
 struct mpa_idx_s {
@@ -59,14 +87,16 @@ struct mpa_idx_s {
 	int64_t n_kb = 0;
 	int64_t l_seq = 0;
 	std::vector<mpa::Contig> ctg;
-	std::vector<uint8_t> seq;        // 4-bit packed, low nibble = even offset (ntseq.c:64-67)
+	mpa::IdxArray<uint8_t> seq;      // 4-bit packed, low nibble = even offset (ntseq.c:64-67)
 	std::vector<char> names;         // NUL separated, exactly as stored in the .mpi
-	std::vector<int64_t> ki;         // bucket offsets, 1<<(4*kmer-mod_bit) entries
-	std::vector<uint32_t> kb;        // global block ids
+	mpa::IdxArray<int64_t> ki;       // bucket offsets, 1<<(4*kmer-mod_bit) entries
+	mpa::IdxArray<uint32_t> kb;      // global block ids
 	std::vector<uint32_t> bo;        // per (contig,strand) block offset, 2*n_ctg+1 entries (index.c:11-26)
 	uint32_t n_block = 0;
 	std::vector<uint8_t> spsc;       // splice-score track (--spsc), empty if none: [strand][l_seq], indexed by contig offset + strand-local position
 	mpa::DeviceIndex *dev = nullptr; // genome resident in HBM (set by mpa_idx_to_device)
+	void *map_base = nullptr;        // the .mpi file mapped by mpa_idx_restore (seq / kb are views into it), or null
+	size_t map_len = 0;
 };
 
 namespace mpa {
