@@ -246,8 +246,9 @@ def roofline_record(st, elapsed, world):
     wall_ops = (OPS_PER_CELL_EXT * st["cells_ext"] + OPS_PER_CELL_GLOB * st["cells_glob"]) / elapsed
     traffic, src = None, None
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_round.sh): a
-    # profile constant measured on this workload at this mini-batch size (round 3), NOT collected in this run
-    for name, what in (("r03_pmc_summary.json", "config 3 at full size, this mini-batch size"), ("r02_pmc_summary.json", "config 3 scaled x0.1: not this run's launch size")):
+    # profile constant measured on this workload at this mini-batch size, NOT collected in this run
+    for name, what in (("r04_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch"),
+                       ("r03_pmc_summary.json", "config 3 at full size, this mini-batch size (round 3: three DP rounds per batch)")):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:

@@ -73,7 +73,7 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD void atomic_min(int32_t *slot, int32_t v) { if (v < *slot) *slot = v; }
 	static MPA_HD int64_t scan_excl(int64_t v, int64_t *total) { *total = v; return 0; }   // sum of v over the lanes below this one; the team's total
 	static MPA_HD int64_t scan_max_excl(int64_t v, int64_t *total) { *total = v; return INT64_MIN; }   // maximum over the lanes below (INT64_MIN: none); the team's
-	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_EXTRACT_PROF)
+	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_TIMING=2)
 	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
 	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
 	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }

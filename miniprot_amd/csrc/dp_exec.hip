@@ -605,8 +605,8 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	xa.kept = (uint8_t*)(X + o_kept), xa.stack = (SortRange*)(X + o_stack);
 	xa.a_out = (uint64_t*)(X + o_pre_a), xa.u_out = (uint64_t*)(X + o_pre_u), xa.n_a = (int64_t*)(X + o_pre_na), xa.n_u = (int64_t*)(X + o_pre_nu);
 	xa.status = (int32_t*)(X + o_status), xa.p = pre, xa.set_only = 1;
-	// MPA_EXTRACT_PROF=1 (debug): per-phase wall clock of the extraction kernel, averaged over the problems of the launch
-	static const bool prof = [] { const char *e = getenv("MPA_EXTRACT_PROF"); return e && atoi(e) != 0; }();
+	// MPA_TIMING=2 (debug): per-phase wall clock of the extraction kernel, averaged over the problems of the launch
+	static const bool prof = [] { const char *e = getenv("MPA_TIMING"); return e && atoi(e) >= 2; }();
 	long long *d_prof = nullptr;
 	auto prof_begin = [&]() -> int {
 		if (!prof) return MPA_OK;
@@ -1292,16 +1292,6 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	};
 	std::sort(ext_ids.begin(), ext_ids.end(), by_class_then_len);
 	std::sort(glob_ids.begin(), glob_ids.end(), by_class_then_len);
-	if (getenv("MPA_CLASS_HIST")) {                         // diagnostics: rows (and calls) per kernel class of this DP round
-		int64_t er[8] = { 0 }, gr[8] = { 0 }, ec[8] = { 0 }, gc[8] = { 0 };
-		for (int32_t id : ext_ids) er[T[id].pad_] += T[id].nl, ec[T[id].pad_]++;
-		for (int32_t id : glob_ids) gr[T[id].pad_] += T[id].nl, gc[T[id].pad_]++;
-		std::string l = "[mpamd] class-hist";
-		for (int k = 0; k < 8; ++k) l += " e" + std::to_string(k) + "=" + std::to_string(ec[k]) + "/" + std::to_string(er[k]);
-		for (int k = 0; k < 8; ++k) l += " g" + std::to_string(k) + "=" + std::to_string(gc[k]) + "/" + std::to_string(gr[k]);
-		fprintf(stderr, "%s\n", l.c_str());
-	}
-
 	int64_t rec_total = 0, prof_total = 0, cig_total = 0, bnd_total = 0;
 	int32_t max_nl = 0;
 	std::vector<PrepChunk> chunks;
@@ -1541,17 +1531,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		wa.waves = ctx->waves.as<ExtWave>();                // absolute descriptor indices: the rowkey slot of group g is g - first wide group
 		wa.rowkey = ctx->rowkey.as<uint32_t>() - (int64_t)ewave_first[3] * 2 * key_stride;
 		ga.waves = d_gw;
-		// MPA_ROUND_WG_PER_CU (default 4): workgroups of the round kernel per CU, enforced through the LDS it asks for.  Five fit
-		// (30.4 KB, 94 VGPRs), but then the 20 DP waves of a CU hold 480 of each SIMD's 512 registers and the seeding kernels of the
-		// next batches (radix sort passes, pre-chain) cannot be co-resident: they wait for whole workgroups to retire.
+		// Four workgroups of the round kernel per CU, enforced through the LDS it asks for.  Five fit (30.4 KB, 94 VGPRs), but then the
+		// 20 DP waves of a CU hold 480 of each SIMD's 512 registers and the seeding kernels of the next batches cannot be co-resident:
+		// they wait for whole workgroups to retire (measured again in round 4: 5 -> 18.8 M residues/s, 3 -> 18.7 M, 4 -> 19.8 M).
+		// One more workgroup than wanted must NOT fit; what is left (160 KB / 5, less the rounding) stays free for the LDS of the
+		// seeding kernels -- dividing the whole LDS by four would starve them.
 		static const size_t round_lds = [] {
-			const char *e = getenv("MPA_ROUND_WG_PER_CU");
-			int w = e ? atoi(e) : 4;
-			w = w < 1 ? 1 : w > 5 ? 5 : w;
-			// one more workgroup than wanted must NOT fit; what is left (160 KB / (w + 1), less the rounding) stays free for the
-			// LDS of the seeding kernels (radix-sort passes, refinement scan) -- dividing the whole LDS by w would starve them
-			size_t pad = (((size_t)160 * 1024 / (w + 1)) + 256) & ~(size_t)255;
-			if (const char *k = getenv("MPA_ROUND_LDS_KB")) pad = (size_t)atoi(k) * 1024;
+			const size_t pad = (((size_t)160 * 1024 / 5) + 256) & ~(size_t)255;
 			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
 		}();
 		if (round_lds > 48 * 1024) HIP_TRY(ensure_dynamic_lds((const void*)k_dp_round, ctx->device, round_lds));

@@ -206,7 +206,7 @@ __device__ __forceinline__ int32_t s_add(int32_t a, int32_t b) { return sat16(a 
 struct PrepChunk { int32_t task; int32_t row0; };
 #define PROF_AA_STRIDE_REC 2   /* byte0 of a record = amino acid * 2 = byte offset into an int16 profile column (k_ext) */
 
-// base of the strand-oriented contig at strand-local position x (ntseq.c:89-106 folded into addressing)
+// base of the strand-oriented contig at strand-local position x (ntseq.c:89-106 folded into addressing; the scans of seed_exec.hip)
 __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off, int64_t len, int rev, int64_t x)
 {
 	int64_t p = rev ? off + len - 1 - x : off + x;
@@ -214,7 +214,8 @@ __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off,
 	return rev && b < 4 ? 3 - b : b;
 }
 
-// donor/acceptor/nas of window row i.  Forward: ns_prep_seq (nasw-sse.c:106-155); left extension:
+// donor/acceptor/nas of window row i (the window fetch, ntseq.c:89-114 -- 4-bit unpack, reverse complement -- is folded into the
+// addressing).  Forward: ns_prep_seq (nasw-sse.c:106-155); left extension:
 // ns_prep_seq_left (nasw-sse.c:157-210).  int8 wrap-around of the reference's arrays is preserved.
 __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tasks, const PrepChunk *chunks, uint32_t *rec, DpConst c, DevTables tb)
 {
@@ -225,13 +226,46 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 	if (i >= nl) return;
 	const int cid = t.vid >> 1, rev = t.vid & 1, left = (t.flag & 2) != 0;
 	const int64_t off = g.ctg_off[cid], len = g.ctg_len[cid];
-	// w[j] = b[i-6+j], j=0..15, where b[] is the (possibly reversed) window; 15 = outside the window
+	// w[j] = b[i-6+j], j=0..15, where b[] is the (possibly reversed) window; 15 = outside the window.
+	// The sixteen bases are consecutive in the packed genome (ascending, or descending for a reversed window / the minus strand):
+	// three aligned words cover them, and the sixteen nibbles are shifted out of those -- instead of sixteen dependent byte loads
+	// with 64-bit address arithmetic each (round 4: this kernel sits on the critical path of every DP round and ran 10 x longer
+	// next to the round kernels of the other lanes than alone).  The genome buffer is padded by 16 bytes; what lies outside the
+	// window is masked to 15 whatever was read for it.
+	uint64_t nib;
+	{
+		const int64_t x0 = t.nt_off + (left ? nl - 1 : 0);             // strand position of window position 0
+		const int64_t p0 = rev ? off + len - 1 - x0 : off + x0;        // ... its position in the packed genome
+		const int dir = (left != (rev != 0)) ? -1 : 1;
+		const int64_t pa = p0 + (int64_t)dir * (i - 6);                // genome position of w[0]
+		const int64_t lo = dir > 0 ? pa : pa - 15;
+		const int64_t seq_bytes = (g.l_seq + 1) >> 1, amax = (seq_bytes + 4) & ~(int64_t)3;
+		int64_t a0 = (lo >> 1) & ~(int64_t)3;
+		a0 = a0 < 0 ? 0 : a0 > amax ? amax : a0;
+		const uint32_t *wp = (const uint32_t*)(g.seq + a0);
+		const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2];
+		const int64_t n0 = lo - 2 * a0;                                // first nibble (0..7 unless the address was clamped)
+		const uint64_t lo64 = (uint64_t)W0 | (uint64_t)W1 << 32;
+		if (n0 >= 0 && n0 <= 7) nib = n0 ? (lo64 >> (4 * n0)) | ((uint64_t)W2 << (64 - 4 * n0)) : lo64;
+		else if (n0 < 0 && n0 >= -15) nib = lo64 << (4 * (-n0));
+		else nib = 0;
+		if (dir < 0) {                                                 // descending: reverse the sixteen nibbles
+			nib = ((nib & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((nib >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+			nib = __builtin_bswap64(nib);
+		}
+		if (rev) {                                                     // minus strand: complement the codes below 4 (3 - b = b ^ 3)
+			const uint64_t m = ~((nib >> 2) | (nib >> 3)) & 0x1111111111111111ULL;
+			nib ^= m * 3;
+		}
+		const int32_t jlo = 6 - i > 0 ? (6 - i > 16 ? 16 : 6 - i) : 0;                        // w[j], j < jlo: before the window
+		const int32_t jhi = nl - i + 6 < 16 ? (nl - i + 6 < 0 ? 0 : nl - i + 6) : 16;       // w[j], j >= jhi: behind it
+		uint64_t valid = jhi >= 16 ? ~0ULL : ((1ULL << (4 * jhi)) - 1);
+		valid &= jlo >= 16 ? 0ULL : ~((1ULL << (4 * jlo)) - 1);
+		nib = (nib & valid) | ~valid;
+	}
 	uint32_t w[16];
 #pragma unroll
-	for (int j = 0; j < 16; ++j) {
-		int32_t k = i - 6 + j;
-		w[j] = (k < 0 || k >= nl) ? 15u : strand_base(g.seq, off, len, rev, t.nt_off + (left ? nl - 1 - k : k));
-	}
+	for (int j = 0; j < 16; ++j) w[j] = (uint32_t)(nib >> (4 * j)) & 15u;
 #define B_(d) w[6 + (d)]   /* b[i+d] */
 	uint32_t nas = 21;
 	int32_t don, acc;

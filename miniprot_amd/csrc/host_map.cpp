@@ -1359,55 +1359,6 @@ static int run_dp_rounds(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_qbatch_t
 	return MPA_OK;
 }
 
-// The DP rounds of SEVERAL planned batches as one sequence of launches: round r of every batch goes to the device in one
-// mpa_dp_run() -- one k_dp_round launch whose longest unit bounds it ONCE for all of them (a round lasts as long as its longest
-// window; the other units of two batches fit under that tail as well as those of one).  The batches' queries are laid end to
-// end, query ids of the tasks shifted accordingly; results and CIGAR pool are shared, each batch takes its slice.
-struct DpJob { const mpa_qbatch_t *q; mpa_batch_t *b; };
-static int run_dp_rounds_merged(mpa_ctx_t *ctx, const mpa_idx_t *mi, const std::vector<DpJob> &jobs)
-{
-	if (jobs.size() == 1) return run_dp_rounds(ctx, mi, jobs[0].q, jobs[0].b);
-	std::string seqs;
-	std::vector<int64_t> q_off(1, 0);
-	std::vector<int32_t> qbase;
-	for (const DpJob &j : jobs) {
-		qbase.push_back((int32_t)q_off.size() - 1);
-		const int64_t base = (int64_t)seqs.size() - j.q->q_off[0];
-		seqs.append(j.q->seqs + j.q->q_off[0], (size_t)(j.q->q_off[j.q->n_seq] - j.q->q_off[0]));
-		for (int32_t i = 1; i <= j.q->n_seq; ++i) q_off.push_back(j.q->q_off[i] + base);
-	}
-	const mpa_qbatch_t qm{ (int32_t)q_off.size() - 1, seqs.data(), q_off.data() };
-	std::vector<mpa_dp_task_t> merged;
-	std::vector<mpa_dp_rst_t> rst;
-	std::vector<int64_t> first(jobs.size() + 1);
-	for (;;) {
-		mpa_dpopt_t dpopt, one;
-		merged.clear();
-		bool have_opt = false;
-		for (size_t k = 0; k < jobs.size(); ++k) {
-			const mpa_dp_task_t *t = nullptr;
-			const int64_t n = mpa_batch_dp_tasks(jobs[k].b, &t, &one);
-			first[k] = (int64_t)merged.size();
-			if (n <= 0) continue;
-			if (!have_opt) dpopt = one, have_opt = true;
-			merged.insert(merged.end(), t, t + n);
-			for (int64_t i = first[k]; i < (int64_t)merged.size(); ++i) merged[(size_t)i].qid += qbase[k];
-		}
-		first[jobs.size()] = (int64_t)merged.size();
-		if (merged.empty()) return MPA_OK;
-		uint32_t *pool = nullptr;
-		int64_t n_pool = 0;
-		rst.resize(merged.size());
-		const double t0 = now_ms();
-		int rc = mpa_dp_run(ctx, mi, &dpopt, &qm, (int64_t)merged.size(), merged.data(), rst.data(), &pool, &n_pool);
-		timing_note("mpa_dp_run (total)", now_ms() - t0);
-		for (size_t k = 0; k < jobs.size() && rc == MPA_OK; ++k)
-			if (first[k + 1] > first[k]) rc = mpa_batch_dp_results(jobs[k].b, rst.data() + first[k], pool);
-		free(pool);
-		if (rc != MPA_OK) return rc;
-	}
-}
-
 static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)
 {
 	*out = nullptr;
@@ -1615,35 +1566,27 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// idle; the next batch's rounds fill that space.
 	// a lane that is free takes the next batch in input order (a static deal would leave lanes idle behind a slow batch)
 	int32_t next_dp = 0;
-	// how many planned batches a lane may take at once (their DP rounds are merged into one launch per round); 1 = off
-	const int32_t dp_merge = [] { const char *e = getenv("MPA_DP_MERGE"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 4 ? 4 : v; }();
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
 		tl_pool_lane = 2 + d, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "DP lanes: worker pool";
 		CpuSpan cs("DP lanes: lane thread (round bookkeeping + waits)");
 		for (;;) {
-			int32_t k, k_end;
+			int32_t k;
 			{
 				std::unique_lock<std::mutex> g(mu);
 				if (next_dp >= n_total) return;
 				k = next_dp++;
 				cv.wait(g, [&] { return rc_all != MPA_OK || k >= n_total || slot[k].begun; });
 				if (rc_all != MPA_OK || k >= n_total) return;
-				// (MPA_DP_MERGE) planned batches that are waiting for a lane ride along: their rounds go out with this batch's.  Only the
-				// batches right behind this one that nobody has claimed yet (the wait above released the lock: other lanes may have moved
-				// next_dp on, and what they claimed is theirs)
-				k_end = k + 1;
-				while (dp_merge > 1 && next_dp == k_end && k_end < n_total && k_end - k < dp_merge && slot[k_end].begun) ++next_dp, ++k_end;
 			}
 			static const char *const lane_name[8] = { "dp0", "dp1", "dp2", "dp3", "dp4", "dp5", "dp6", "dp7" };
-			std::vector<DpJob> jobs;
-			for (int32_t j = k; j < k_end; ++j) { trace(lane_name[d], j, "begin"); jobs.push_back(DpJob{ &slot[j].q, slot[j].b }); }
+			trace(lane_name[d], k, "begin");
 			int rc;
-			{ StageClock sc(2); rc = run_dp_rounds_merged(cd, mi, jobs); }
-			for (int32_t j = k; j < k_end; ++j) trace(lane_name[d], j, "end");
+			{ StageClock sc(2); rc = run_dp_rounds(cd, mi, &slot[k].q, slot[k].b); }
+			trace(lane_name[d], k, "end");
 			if (rc != MPA_OK) { fail(rc, mpa_last_error()); return; }
 			std::lock_guard<std::mutex> g(mu);
-			for (int32_t j = k; j < k_end; ++j) slot[j].dp_done = true, ++n_dp_done;
+			slot[k].dp_done = true, ++n_dp_done;
 			cv.notify_all();
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("DP lane: ") + e.what()); } };

@@ -254,7 +254,7 @@ struct ExtractArgs {
 	int32_t set_only;
 };
 
-// MPA_EXTRACT_PROF: wall-clock stamps of k_chain_extract's phases, 8 per problem (start, chain ends sorted, trees, extraction, end)
+// MPA_TIMING=2: wall-clock stamps of k_chain_extract's phases, 8 per problem (start, chain ends sorted, trees, extraction, end)
 __device__ long long *g_extract_prof = nullptr;
 __device__ int g_extract_prof_n = 0;         // problems the buffer has room for (launches of other contexts may have more)
 
