@@ -242,7 +242,9 @@ int mpa_map_batch(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, 
 /* The same computation as an explicit stage machine (used by mpa_map_batch itself). */
 typedef struct mpa_batch_s mpa_batch_t;
 mpa_batch_t *mpa_batch_begin(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads);
-/* Returns the DP tasks of the next round (0 when mapping is complete); the array stays owned by the batch. */
+/* Returns the DP tasks of the next round (0 when mapping is complete); the array stays owned by the batch.  A batch has two
+ * rounds: extensions (with the terminal-exon repeats of align.c:290-296,324-331 issued speculatively) + the gaps between anchors,
+ * then the spans the extensions accepted. */
 int64_t mpa_batch_dp_tasks(mpa_batch_t *b, const mpa_dp_task_t **tasks, mpa_dpopt_t *opt);
 int mpa_batch_dp_results(mpa_batch_t *b, const mpa_dp_rst_t *rst, const uint32_t *cigar_pool);
 mpa_result_t *mpa_batch_finish(mpa_batch_t *b);                 /* destroys the batch */
@@ -265,8 +267,9 @@ int64_t mpa_format_output(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mp
 int64_t mpa_result_n_output(const mpa_mapopt_t *opt, const mpa_qbatch_t *q, const mpa_result_t *r);
 
 /* A stream of mini-batches (the loop of mp_map_file()'s kt_pipeline, map.c:273-345, which overlaps only file I/O with
- * mapping): a three-stage software pipeline in which the host seeding/chaining of batch k+1 and the flattening +
- * formatting of batch k-1 overlap the GPU DP rounds of batch k.  results[k] is what mpa_map_batch() returns for
+ * mapping) as a software pipeline: sketch (host) | seeding + both chaining rounds (device) | regions, refinement (device), DP
+ * plans | the two DP rounds of a batch (device; several batches at once on sibling contexts) | statistics + text (host), each
+ * stage its own host thread(s).  results[k] is what mpa_map_batch() returns for
  * batches[k].  With names != NULL (names[k][q] = name of query q of batch k) the output text of every batch is produced
  * as well, as by mpa_format_output() with *id_io threaded through the batches in order: text[k] (mpa_free) / text_len[k]. */
 int mpa_map_batches(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
