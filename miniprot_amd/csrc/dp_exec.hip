@@ -1105,7 +1105,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	char *R = B.rx_all.as<char>();
 	uint32_t *d_wcnt = (uint32_t*)(R + o_wcnt), *d_wpairs = (uint32_t*)(R + o_wpairs);
 	int64_t *d_first = (int64_t*)(R + o_first);
-	const size_t lds = ((size_t)8 << hs_log2) + REFINE_CHUNK + 2 * REFINE_HALO;
+	const size_t lds = ((size_t)8 << hs_log2) + 2 * (REFINE_CHUNK + 2 * REFINE_HALO);   // k-mer map, bases, codons
 	HIP_TRY(ensure_dynamic_lds((const void*)k_refine_scan_map, ctx->device, lds > 48 * 1024 ? lds : 48 * 1024));
 	hipLaunchKernelGGL(k_refine_scan_map, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk), gr, d_wg, rt,
 	                   kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt);

@@ -214,6 +214,34 @@ __device__ __forceinline__ uint32_t strand_base(const uint8_t *seq, int64_t off,
 	return rev && b < 4 ? 3 - b : b;
 }
 
+// Sixteen consecutive bases of the packed genome as the nibbles of one word: nibble j = the base at genome position
+// p_first + dir * j (dir = +1 / -1), complemented (3 - b for the codes below 4) when `comp`.  Three aligned words cover them;
+// positions outside the genome buffer (which is padded by 16 bytes) read as garbage -- the caller masks what it does not own.
+__device__ __forceinline__ uint64_t packed_window16(const uint8_t *seq, int64_t l_seq, int64_t p_first, int dir, int comp)
+{
+	const int64_t lo = dir > 0 ? p_first : p_first - 15;
+	const int64_t seq_bytes = (l_seq + 1) >> 1, amax = (seq_bytes + 4) & ~(int64_t)3;
+	int64_t a0 = (lo >> 1) & ~(int64_t)3;
+	a0 = a0 < 0 ? 0 : a0 > amax ? amax : a0;
+	const uint32_t *wp = (const uint32_t*)(seq + a0);
+	const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2];
+	const int64_t n0 = lo - 2 * a0;                                // first nibble (0..7 unless the address was clamped)
+	const uint64_t lo64 = (uint64_t)W0 | (uint64_t)W1 << 32;
+	uint64_t nib;
+	if (n0 >= 0 && n0 <= 7) nib = n0 ? (lo64 >> (4 * n0)) | ((uint64_t)W2 << (64 - 4 * n0)) : lo64;
+	else if (n0 < 0 && n0 >= -15) nib = lo64 << (4 * (-n0));
+	else nib = 0;
+	if (dir < 0) {                                                 // descending: reverse the sixteen nibbles
+		nib = ((nib & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((nib >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+		nib = __builtin_bswap64(nib);
+	}
+	if (comp) {                                                    // minus strand: complement the codes below 4 (3 - b = b ^ 3)
+		const uint64_t m = ~((nib >> 2) | (nib >> 3)) & 0x1111111111111111ULL;
+		nib ^= m * 3;
+	}
+	return nib;
+}
+
 // donor/acceptor/nas of window row i (the window fetch, ntseq.c:89-114 -- 4-bit unpack, reverse complement -- is folded into the
 // addressing).  Forward: ns_prep_seq (nasw-sse.c:106-155); left extension:
 // ns_prep_seq_left (nasw-sse.c:157-210).  int8 wrap-around of the reference's arrays is preserved.
@@ -237,26 +265,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 		const int64_t x0 = t.nt_off + (left ? nl - 1 : 0);             // strand position of window position 0
 		const int64_t p0 = rev ? off + len - 1 - x0 : off + x0;        // ... its position in the packed genome
 		const int dir = (left != (rev != 0)) ? -1 : 1;
-		const int64_t pa = p0 + (int64_t)dir * (i - 6);                // genome position of w[0]
-		const int64_t lo = dir > 0 ? pa : pa - 15;
-		const int64_t seq_bytes = (g.l_seq + 1) >> 1, amax = (seq_bytes + 4) & ~(int64_t)3;
-		int64_t a0 = (lo >> 1) & ~(int64_t)3;
-		a0 = a0 < 0 ? 0 : a0 > amax ? amax : a0;
-		const uint32_t *wp = (const uint32_t*)(g.seq + a0);
-		const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2];
-		const int64_t n0 = lo - 2 * a0;                                // first nibble (0..7 unless the address was clamped)
-		const uint64_t lo64 = (uint64_t)W0 | (uint64_t)W1 << 32;
-		if (n0 >= 0 && n0 <= 7) nib = n0 ? (lo64 >> (4 * n0)) | ((uint64_t)W2 << (64 - 4 * n0)) : lo64;
-		else if (n0 < 0 && n0 >= -15) nib = lo64 << (4 * (-n0));
-		else nib = 0;
-		if (dir < 0) {                                                 // descending: reverse the sixteen nibbles
-			nib = ((nib & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((nib >> 4) & 0x0f0f0f0f0f0f0f0fULL);
-			nib = __builtin_bswap64(nib);
-		}
-		if (rev) {                                                     // minus strand: complement the codes below 4 (3 - b = b ^ 3)
-			const uint64_t m = ~((nib >> 2) | (nib >> 3)) & 0x1111111111111111ULL;
-			nib ^= m * 3;
-		}
+		nib = packed_window16(g.seq, g.l_seq, p0 + (int64_t)dir * (i - 6), dir, rev);
 		const int32_t jlo = 6 - i > 0 ? (6 - i > 16 ? 16 : 6 - i) : 0;                        // w[j], j < jlo: before the window
 		const int32_t jhi = nl - i + 6 < 16 ? (nl - i + 6 < 0 ? 0 : nl - i + 6) : 16;       // w[j], j >= jhi: behind it
 		uint64_t valid = jhi >= 16 ? ~0ULL : ((1ULL << (4 * jhi)) - 1);

@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	const int32_t HS = 1 << hs_log2;
 	uint32_t *tkey = lds_refine, *tval = tkey + HS;               // open addressing: word -> group (0xffffffff = empty)
 	uint8_t *base = (uint8_t*)(tval + HS);                          // [REFINE_CHUNK + 2 * REFINE_HALO] nt4 codes, 15 = outside the window
+	uint8_t *cod = base + REFINE_CHUNK + 2 * REFINE_HALO;           // [same] reduced-alphabet code of the codon ENDING at each position, 0xff = none
 	__shared__ uint8_t tab[64];
 	const RefineChunk ch = chunks[blockIdx.x];
 	const RefineWindowDev w = wins[ch.win];
@@ -904,11 +905,38 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	const int64_t off = g.ctg_off[cid], clen = g.ctg_len[cid];
 	if (threadIdx.x < 64) tab[threadIdx.x] = rt.t[threadIdx.x];
 	for (int k = threadIdx.x; k < HS; k += 256) tkey[k] = 0xffffffffu;
-	for (int k = threadIdx.x; k < REFINE_CHUNK + 2 * REFINE_HALO; k += 256) {
-		const int64_t p = (int64_t)ch.start - REFINE_HALO + k;
-		base[k] = (p < 0 || p >= w.len) ? 15 : (uint8_t)strand_base(g.seq, off, clen, rev, w.as + p);
+	// the chunk's bases and its halo, sixteen per thread from three aligned words of the packed genome (a byte load per base before)
+	static_assert((REFINE_CHUNK + 2 * REFINE_HALO) % 16 == 0, "chunk + halo must be a multiple of 16");
+	for (int k = threadIdx.x * 16; k < REFINE_CHUNK + 2 * REFINE_HALO; k += 256 * 16) {
+		const int64_t p = (int64_t)ch.start - REFINE_HALO + k;         // window position of base[k]
+		const int64_t x = w.as + p;                                    // strand position
+		const uint64_t nib = packed_window16(g.seq, g.l_seq, rev ? off + clen - 1 - x : off + x, rev ? -1 : 1, rev);
+		uint32_t o[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			uint32_t v = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int64_t pj = p + 4 * q + j;
+				const uint32_t bb = (pj < 0 || pj >= w.len) ? 15u : (uint32_t)(nib >> (4 * (4 * q + j))) & 15u;
+				v |= bb << (8 * j);
+			}
+			o[q] = v;
+		}
+		uint32_t *dst = (uint32_t*)(base + k);                       // (k is a multiple of 16, base of 4)
+		dst[0] = o[0], dst[1] = o[1], dst[2] = o[2], dst[3] = o[3];
 	}
 	__syncthreads();
+	// the codon ending at every position, once (every k-mer and every reading-frame walk below reads these instead of three bases
+	// and the table per codon)
+	for (int e = threadIdx.x; e < REFINE_CHUNK + 2 * REFINE_HALO; e += 256) {
+		uint32_t c = 0xffu;
+		if (e >= 2) {
+			const uint32_t b0 = base[e - 2], b1 = base[e - 1], b2 = base[e];
+			if ((b0 | b1 | b2) <= 3) c = tab[b0 << 4 | b1 << 2 | b2];
+		}
+		cod[e] = (uint8_t)c;
+	}
 	const int64_t G0 = gr.qg_first[w.qid], G1 = gr.qg_first[w.qid + 1];
 	for (int64_t k = G0 + threadIdx.x; k < G1; k += 256) {
 		const uint32_t word = gr.gword[k];
@@ -921,11 +949,7 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	}
 	__syncthreads();
 	const uint32_t mask = (1u << (4 * kmer)) - 1;
-	auto codon_at = [&](int e) -> uint32_t {
-		const uint32_t b0 = base[e - 2], b1 = base[e - 1], b2 = base[e];
-		if ((b0 | b1 | b2) > 3) return 0xffu;
-		return tab[b0 << 4 | b1 << 2 | b2];
-	};
+	auto codon_at = [&](int e) -> uint32_t { return cod[e]; };
 	const int64_t wc0 = wg_first[ch.win];
 	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
 		const int32_t pos = ch.start + t * 256 + (int32_t)threadIdx.x;

@@ -54,6 +54,17 @@ def job_counter(n_batches, world):
     return claim
 
 
+def any_rank_failed(failed, world, device):
+    """True on every rank iff `failed` is true on at least one (one small all_reduce; no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return bool(failed)
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
 def exchange_values(mine, values, n_batches, world, device):
     """Every rank contributes (batch index, value) for the batches it mapped, in the order it mapped them.  Returns
     (int64[n_batches] of the values, [batch list of rank 0, of rank 1, ...]) on every rank."""
@@ -138,12 +149,20 @@ def run_sharded(n_batches, rank, world, device, needs_ids, map_mine, count_fn, f
     count_fn(k, res)     -> hit records the output of batch k prints (only with needs_ids)
     format_fn(k, res, id0) -> text of batch k whose first printed hit gets id0 + 1 (only with needs_ids)
     Returns (texts on rank 0 | None, ids consumed by the whole job)."""
-    if map_claimed is not None:
-        mine, res = map_claimed(job_counter(n_batches, world))
-        mine = list(mine)
-    else:
-        mine = my_batches(n_batches, rank, world)
-        res = map_mine(mine)
+    err = None
+    try:
+        if map_claimed is not None:
+            mine, res = map_claimed(job_counter(n_batches, world))
+            mine = list(mine)
+        else:
+            mine = my_batches(n_batches, rank, world)
+            res = map_mine(mine)
+    except Exception as e:                                       # (a failed claim callback, a mapping error: this rank has nothing to gather)
+        err, mine, res = e, [], []
+    # every rank learns whether ANY rank failed before the first collective of the gather: a rank that raised alone would leave
+    # the others waiting in all_gather for ever
+    if any_rank_failed(err is not None, world, device):
+        raise RuntimeError("run_sharded: mapping failed on %s" % ("this rank: %r" % (err,) if err is not None else "another rank"))
     if not needs_ids:
         return gather_texts(mine, res, n_batches, rank, world, device), None
     counts = exchange_counts(mine, [count_fn(k, r) for k, r in zip(mine, res)], n_batches, world, device)

@@ -50,6 +50,20 @@ for tag, flag in (("paf", 0x4), ("gff", 0x4 | 0x8), ("gtf", 0x4 | 0x20)):
                                      map_claimed=map_claimed)
     if rank == 0:
         open(sys.argv[2] + "." + tag + ".dyn", "wb").write(b"".join(texts))
+# a rank whose mapping fails (here: rank 1's claim callback raises) must not leave the others waiting in the gather: every rank raises
+def map_broken(claim):
+    if rank == 1:
+        raise ValueError("boom")
+    ks = []
+    while claim() >= 0:
+        ks.append(0)
+    return [], []
+try:
+    mdist.run_sharded(len(batches), rank, world, torch.device("cpu"), False, None, None, None, map_claimed=map_broken)
+    raised = False
+except RuntimeError as e:
+    raised = "mapping failed" in str(e)
+open(sys.argv[2] + ".raised.%d" % rank, "w").write("1" if raised else "0")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -75,6 +89,7 @@ def test_two_rank_gloo_job_equals_single_process(tmp_path, oracle_built):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29617", str(script), refbind.ROOT, out], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out + ".raised.0").read() == "1" and open(out + ".raised.1").read() == "1", "a failure on one rank did not reach every rank"
     case = golden.SYNTH_CASES[0]
     contigs, prots, names = golden.synth_inputs(case)
     idx = mpa.Index.from_nt4(contigs, ["chr1"])
