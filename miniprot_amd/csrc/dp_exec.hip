@@ -116,10 +116,10 @@ struct HostPinned {
 struct SeedHold { HostPinned h_pos, h_f, h_pred, h_a, h_U, h_A; };
 
 struct SeedBufs {
-	DevBuf jobs, key[2], f, pred, mark, flag, idx, tmp, qfirst, cfirst;
+	DevBuf jobs, key[2], f, pred, mark, flag, idx, tmp, cfirst;
 	HostPinned h_jobs;
 	SeedHold own;                                                          // results of a call without a holder of its own (blocking path, refinement)
-	DevBuf r_win, r_chunk, r_qfirst, r_words, r_hits, r_count;      // refinement scan
+	DevBuf r_win, r_chunk, r_words, r_hits, r_count;      // refinement scan
 	HostPinned h_rhits;
 	DevBuf pf_qfirst2, val64[2];                                            // first kept anchor of every query; the kept anchors' values
 	DevBuf s_meta, s_cur, s_cur2, s_kept, s_base, s_out, s_flag, dkey;      // k_seed_sift: segments + per-query tables, list cursors, per-segment results, dense keys
@@ -170,8 +170,8 @@ template<typename F> static void ctx_each_devbuf(mpa_ctx_s *ctx, F f)
 	SeedBufs &B = ctx->seed;
 	DevBuf *all[] = { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
 	                  &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
-	                  &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.qfirst, &B.cfirst,
-	                  &B.r_win, &B.r_chunk, &B.r_qfirst, &B.r_words, &B.r_hits, &B.r_count,
+	                  &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.cfirst,
+	                  &B.r_win, &B.r_chunk, &B.r_words, &B.r_hits, &B.r_count,
 	                  &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
 	                  &B.pf_qfirst2, &B.val64[0], &B.val64[1],
 	                  &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys };
