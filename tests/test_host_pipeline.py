@@ -154,3 +154,34 @@ def test_threads_do_not_change_output(oracle_built):
     a = map_batch(idx, golden.mapopt_for(case), q, oracle_executor, n_threads=1)
     b = map_batch(idx, golden.mapopt_for(case), q, oracle_executor, n_threads=5)
     assert a == b
+
+
+def test_mapped_index_with_misaligned_sections_maps_like_the_one_in_memory(tmp_path, oracle_built):
+    """mpa_idx_restore() maps the .mpi instead of reading it: genome and occurrence lists are views into the mapping, and since the
+    file packs its sections back to back the 32-bit occurrence lists start at ANY byte offset (contig names of different lengths
+    shift them).  Four name lengths = four alignments: every restored index must map exactly like the index it was dumped from,
+    byte for byte, and dump to the same file again."""
+    import hashlib
+    import gen_synth
+    from hostpipe import map_batch_result, oracle_executor
+    contigs, prots, names = gen_synth.generate(400000, 1, 6, 61)
+    q = mpa.Queries(prots, names)
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    seen = set()
+    for nm in ("c", "ch", "chr", "chr1"):
+        idx = mpa.Index.from_nt4(contigs, [nm])
+        mpa._check(mpa.lib().mpa_idx_build_kmers(idx.h, 2))
+        want = mpa.format_output(idx, mo, q, map_batch_result(idx, mo, q, oracle_executor))[0]
+        path = str(tmp_path / ("g_%s.mpi" % nm))
+        idx.dump(path)
+        idx.close()
+        seen.add((44 + 8 + (len(contigs[0]) + 1) // 2 + len(nm) + 1 + 8 * (1 << 23)) % 4)     # byte offset of kb[] in the file, mod 4
+        back = mpa.Index.restore(path)
+        got = mpa.format_output(back, mo, q, map_batch_result(back, mo, q, oracle_executor))[0]
+        assert got == want and want.count(b"\n") >= len(prots), nm
+        again = str(tmp_path / ("again_%s.mpi" % nm))
+        back.dump(again)
+        back.close()
+        assert hashlib.md5(open(again, "rb").read()).hexdigest() == hashlib.md5(open(path, "rb").read()).hexdigest(), nm
+    assert len(seen) == 4, "the four name lengths were meant to give four alignments of the occurrence lists"
