@@ -430,7 +430,8 @@ def main():
                    "host_threads_per_rank": n_threads, "host_cpus_visible": ncpu, "host_cpu_quota": ncpu_eff,
                    # CPU seconds (user + system, getrusage) all ranks' processes spent inside the timed region, per step and as a share of
                    # the host: what one GPU's pipeline costs the host it shares with the other ranks
-                   "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1), "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9),
+                   "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1) * nb, "host_cpu_s_per_mini_batch": st["host_cpu_s"] / max(len(texts), 1),
+                   "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9),
                    # (rank 0's cgroup: 100 ms scheduler periods in which the quota ran out, and thread-seconds spent frozen because of it)
                    "host_throttled": {"periods": st.get("throttled_periods"), "thread_seconds": st.get("throttled_s")}}
         ctx.close()
@@ -492,7 +493,8 @@ def main():
                "sketch_wall_ms_per_batch": r["sketch_wall_ms_per_batch"],
                "hbm_resident_gb": r["hbm_resident_gb"], "pool_growth_events_timed": r["pool_growth_events_timed"], "pool_growth_events_total": r["pool_growth_events_total"],
                "cli_end_to_end": r["cli_end_to_end"],
-               "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cores_busy": r["host_cores_busy"], "host_throttled": r["host_throttled"],
+               "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cpu_s_per_mini_batch": r["host_cpu_s_per_mini_batch"], "host_cores_busy": r["host_cores_busy"],
+               "host_throttled": r["host_throttled"],
                "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
         out.update(extra)
         print(json.dumps(out))
