@@ -512,6 +512,9 @@ __device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, u
 // ------------------------------------------------------------------------------------------------
 #define SIFT_THREADS 256
 #define SIFT_CARRY_MAX 1024                               /* anchors that may wait for the next range */
+#define SIFT_NBK_LOG2 9                                   /* buckets of the in-LDS sort */
+#define SIFT_NBK (1 << SIFT_NBK_LOG2)
+#define SIFT_BUCKET_MAX 512u                              /* a larger bucket sends the range to the bitonic network */
 // SIFT_CAP (template parameter CAP): anchors per LDS buffer -- 2048 (8 KB) or 4096 (16 KB); a range is sized for 5/8 of it
 struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t cur_off; }; // blocks [lo, hi) of query qid; cur_off: the segment's own cursors (one per list of the query)
 
@@ -529,6 +532,23 @@ __device__ __forceinline__ uint32_t sift_block_sum(uint32_t v, volatile uint32_t
 	if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
 	__syncthreads();
 	return scr[0] + scr[1] + scr[2] + scr[3];
+}
+// exclusive prefix of v over the workgroup's threads; scr = 4 words of LDS
+__device__ __forceinline__ uint32_t sift_block_scan(uint32_t v, volatile uint32_t *scr)
+{
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t n = __shfl_up(inc, o);
+		if (lane >= (uint32_t)o) inc += n;
+	}
+	__syncthreads();                                        // (scr may still be read from the previous call)
+	if (lane == 63) scr[wv] = inc;
+	__syncthreads();
+	uint32_t ex = inc - v;
+	for (uint32_t w = 0; w < wv; ++w) ex += scr[w];
+	return ex;
 }
 // first index c in [c0, cnt) with list[c] >= hi (list ascending), reading eight entries per dependent step
 __device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0, int32_t cnt, uint32_t hi)
@@ -562,7 +582,9 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 {
 	MPA_SHORT_KERNEL();
 	constexpr uint32_t SIFT_TARGET = (uint32_t)SIFT_CAP * 5u / 8u;      // anchors a range is sized for
-	__shared__ uint32_t keys[SIFT_CAP];
+	__shared__ uint32_t keys[SIFT_CAP], kbuf[SIFT_CAP];        // a range's anchors; the same in bucket order
+	__shared__ uint32_t bcnt[SIFT_NBK];                        // bucket sizes, then starts / ends
+	__shared__ uint32_t bmax;
 	__shared__ uint32_t scr[4];
 	__shared__ uint32_t wtot[4];
 	__shared__ uint32_t fill;                                  // slots of `keys` taken while a range is loaded
@@ -647,21 +669,57 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 			}
 		}
 		const uint32_t n = n_carry + total;
-		uint32_t P = 64;
-		while (P < n) P <<= 1;
 		__syncthreads();
-		for (uint32_t i = n + t; i < P; i += SIFT_THREADS) keys[i] = 0xffffffffu;
-		__syncthreads();
-		// ---- bitonic sort of keys[0, P)
-		for (uint32_t k = 2; k <= P; k <<= 1)
-			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-				for (uint32_t i = t; i < (P >> 1); i += SIFT_THREADS) {
-					const uint32_t a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
-					const uint32_t x = keys[a], y = keys[b];
-					if ((x > y) == ((a & k) == 0u)) keys[a] = y, keys[b] = x;
+		// ---- sort keys[0, n): into buckets by the leading bits (in arrival order), then every key counts the smaller keys of its
+		// bucket -- a dozen instructions per key where a bitonic network spends a few hundred (keys are unique: no ties)
+		{
+			int sh = 32 - __clz((int)(((hi - lo + 1u) << LB) - 1u)) - SIFT_NBK_LOG2;      // every key is below (hi - lo + 1) << LB
+			if (sh < 0) sh = 0;
+			constexpr int BPT = SIFT_NBK / SIFT_THREADS;           // counters a thread owns in the scan
+#pragma unroll
+			for (int k = 0; k < BPT; ++k) bcnt[t * BPT + k] = 0u;
+			if (t == 0) bmax = 0u;
+			__syncthreads();
+			for (uint32_t i = t; i < n; i += SIFT_THREADS) atomicAdd(&bcnt[keys[i] >> sh], 1u);
+			__syncthreads();
+			uint32_t c[BPT], mine = 0, big = 0;
+#pragma unroll
+			for (int k = 0; k < BPT; ++k) c[k] = bcnt[t * BPT + k], mine += c[k], big = c[k] > big ? c[k] : big;
+			if (big > SIFT_BUCKET_MAX) atomicMax(&bmax, big);
+			uint32_t at = sift_block_scan(mine, scr);               // (barriers inside)
+#pragma unroll
+			for (int k = 0; k < BPT; ++k) bcnt[t * BPT + k] = at, at += c[k];
+			__syncthreads();
+			if (bmax <= SIFT_BUCKET_MAX) {
+				for (uint32_t i = t; i < n; i += SIFT_THREADS) {
+					const uint32_t key = keys[i];
+					kbuf[atomicAdd(&bcnt[key >> sh], 1u)] = key;       // (the counter ends up at the bucket's end = the next one's start)
 				}
 				__syncthreads();
+				for (uint32_t p = t; p < n; p += SIFT_THREADS) {
+					const uint32_t key = kbuf[p], bk = key >> sh;
+					const uint32_t b0 = bk ? bcnt[bk - 1] : 0u, b1 = bcnt[bk];
+					uint32_t r = b0;
+					for (uint32_t j = b0; j < b1; ++j) r += kbuf[j] < key ? 1u : 0u;
+					keys[r] = key;
+				}
+				__syncthreads();
+			} else {                                               // a bucket of hundreds (a repeat cluster inside a wide range): bitonic network
+				uint32_t P = 64;
+				while (P < n) P <<= 1;
+				for (uint32_t i = n + t; i < P; i += SIFT_THREADS) keys[i] = 0xffffffffu;
+				__syncthreads();
+				for (uint32_t k = 2; k <= P; k <<= 1)
+					for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+						for (uint32_t i = t; i < (P >> 1); i += SIFT_THREADS) {
+							const uint32_t a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
+							const uint32_t x = keys[a], y = keys[b];
+							if ((x > y) == ((a & k) == 0u)) keys[a] = y, keys[b] = x;
+						}
+						__syncthreads();
+					}
 			}
+		}
 		// ---- which anchors are decided now: all of them in the segment's last range, else all below block hi - 1
 		const bool last = hi == hi0;
 		uint32_t right_nb = 0;

@@ -1,5 +1,5 @@
 """CPU model of k_seed_sift (miniprot_amd/csrc/seed_exec.hip): the range walk with one cursor per occurrence list, the carry of
-a range's last block, the halving of ranges that do not fit the buffer, the rank base and the neighbour tests at segment
+a range's last block, the bucket sort of a range's keys, the halving of ranges that do not fit the buffer, the rank base and the neighbour tests at segment
 boundaries -- step for step as the kernel does them, checked against the definition: sort all anchors of the query by
 (block, seed), keep those that have another anchor in the same or an adjacent block (the only ones the pre-chain of
 map.c:186-192 can link), rank = index in the full sorted list.  The HIP kernel itself is checked on the GPU against the host
@@ -10,6 +10,28 @@ import pytest
 
 class Overflow(Exception):
     pass
+
+
+def bucket_sort(keys, key_max, nbk_log2=9, bucket_max=512):
+    """The kernel's in-LDS sort: buckets by the leading bits of the key range (arrival order inside a bucket is arbitrary: here
+    reversed), then each key's place = its bucket's start + the smaller keys of the bucket; the bitonic network (here: sorted)
+    takes ranges with a bucket of more than bucket_max keys."""
+    sh = max(int(key_max).bit_length() - nbk_log2, 0)
+    buckets = [[] for _ in range(1 << nbk_log2)]
+    for k in reversed(keys):
+        buckets[k >> sh].append(k)
+    if max(len(b) for b in buckets) > bucket_max:
+        return sorted(keys)
+    out = [None] * len(keys)
+    start = 0
+    for b in buckets:
+        for k in b:
+            r = start + sum(1 for x in b if x < k)
+            assert out[r] is None                                  # keys are unique ((block, list): a list holds a block once)
+            out[r] = k
+        start += len(b)
+    assert out == sorted(keys)
+    return out
 
 
 def sift_segment(lists, lo0, hi0, n_block, cap=2048, carry_max=1024, target=1280):
@@ -43,7 +65,7 @@ def sift_segment(lists, lo0, hi0, n_block, cap=2048, carry_max=1024, target=1280
             keys += [((int(b) - lo + 1) << LB) | l for b in x[c0:c1]]
         cur = cur2
         n = len(keys)
-        keys.sort()
+        keys = bucket_sort(keys, ((hi - lo + 1) << LB) - 1)
         assert all(k < 0xFFFFFFFF for k in keys)
         last = hi == hi0
         right_nb = last and hi0 < n_block and any(c < len(x) and x[c] == hi0 for x, c in zip(lists, cur))
