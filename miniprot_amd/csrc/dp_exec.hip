@@ -494,7 +494,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	const int64_t *d_qfirst = (const int64_t*)dm, *d_jfirst = (const int64_t*)(dm + off_jf), *d_sfirst = (const int64_t*)(dm + off_sf);
 	const SiftSeg *d_segs = (const SiftSeg*)(dm + off_seg);
 	const int32_t *d_qseg = (const int32_t*)(dm + off_qs);
-	hipLaunchKernelGGL(k_seed_sift<2048>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
+	hipLaunchKernelGGL(k_seed_sift<4096>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
 	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
 	                   B.s_flag.as<int32_t>());
 	hipLaunchKernelGGL(k_sift_offsets, dim3(1), dim3(256), 0, s, d_segs, n_seg, n_query, d_qseg, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_out.as<int64_t>(),

@@ -512,8 +512,7 @@ __device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, u
 // ------------------------------------------------------------------------------------------------
 #define SIFT_THREADS 256
 #define SIFT_CARRY_MAX 1024                               /* anchors that may wait for the next range */
-#define SIFT_NBK_LOG2 9                                   /* buckets of the in-LDS sort */
-#define SIFT_NBK (1 << SIFT_NBK_LOG2)
+/* buckets of the in-LDS sort: SIFT_CAP / 4 */
 #define SIFT_BUCKET_MAX 512u                              /* a larger bucket sends the range to the bitonic network */
 // SIFT_CAP (template parameter CAP): anchors per LDS buffer -- 2048 (8 KB) or 4096 (16 KB); a range is sized for 5/8 of it
 struct SiftSeg { int32_t qid; uint32_t lo, hi; int32_t cur_off; }; // blocks [lo, hi) of query qid; cur_off: the segment's own cursors (one per list of the query)
@@ -550,24 +549,6 @@ __device__ __forceinline__ uint32_t sift_block_scan(uint32_t v, volatile uint32_
 	for (uint32_t w = 0; w < wv; ++w) ex += scr[w];
 	return ex;
 }
-// first index c in [c0, cnt) with list[c] >= hi (list ascending), reading eight entries per dependent step
-__device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0, int32_t cnt, uint32_t hi)
-{
-	int32_t c = c0;
-	while (c < cnt) {
-		const int32_t m = cnt - c < 8 ? cnt - c : 8;
-		uint32_t v[8];
-#pragma unroll
-		for (int k = 0; k < 8; ++k) v[k] = list[c + (k < m ? k : m - 1)];
-		int32_t below = 0;
-#pragma unroll
-		for (int k = 0; k < 8; ++k) below += (k < m && v[k] < hi) ? 1 : 0;
-		c += below;
-		if (below < 8) break;
-	}
-	return c;
-}
-
 // skey/sval: staging.  A query with few anchors owns as many slots as it has anchors (a segment writes its kept anchors from
 // sfirst[q] + rank base on: the kept ones can never outnumber the anchors below them); a query with more than SIFT_FULL_STAGE
 // anchors owns HALF as many -- at genome scale one anchor in eight is kept -- laid out the same way with every offset halved, and
@@ -576,12 +557,13 @@ __device__ __forceinline__ int32_t sift_advance(const uint32_t *list, int32_t c0
 #define SIFT_FULL_STAGE 16384
 __host__ __device__ inline int64_t sift_stage_slots(int64_t n_anchor) { return n_anchor > SIFT_FULL_STAGE ? (n_anchor + 1) / 2 : n_anchor; }
 template<int SIFT_CAP>
-__global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const int64_t *sfirst, const uint32_t *kb,
+__global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const int64_t *sfirst, const uint32_t *kb,
                                                             uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
                                                             int64_t *seg_base, int32_t *qflag)
 {
 	MPA_SHORT_KERNEL();
 	constexpr uint32_t SIFT_TARGET = (uint32_t)SIFT_CAP * 5u / 8u;      // anchors a range is sized for
+	constexpr int SIFT_NBK_LOG2 = SIFT_CAP >= 4096 ? 10 : 9, SIFT_NBK = 1 << SIFT_NBK_LOG2;
 	__shared__ uint32_t keys[SIFT_CAP], kbuf[SIFT_CAP];        // a range's anchors; the same in bucket order
 	__shared__ uint32_t bcnt[SIFT_NBK];                        // bucket sizes, then starts / ends
 	__shared__ uint32_t bmax;
@@ -636,40 +618,49 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 		width = (uint32_t)(wv < 1 ? 1 : wv > w_max ? w_max : wv);
 	}
 	while (lo < hi0) {
-		// ---- the range [lo, hi): count its anchors, halve it until they fit
-		uint32_t hi, total;
+		// ---- the range [lo, hi): its anchors go to LDS as (block - lo + 1) << LB | list, behind the carry (keys[0, n_carry), local
+		// block 0), in ONE pass over the lists -- eight entries per dependent step, one slot request per step; a range whose
+		// anchors do not fit is halved and read again (rare: the width follows the density)
+		uint32_t hi, n;
 		for (;;) {
 			hi = hi0 - lo > width ? lo + width : hi0;
-			uint32_t mine = 0;
+			if (t == 0) fill = n_carry;
+			__syncthreads();
 			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
 				const SeedJobDev s = jobs[j0 + l];
-				const int32_t c0 = cur[c0s + l];
-				const int32_t c1 = sift_advance(kb + s.kb_off, c0, s.cnt, hi);
-				cur2[c0s + l] = c1;
-				mine += (uint32_t)(c1 - c0);
+				const uint32_t *list = kb + s.kb_off;
+				int32_t c = cur[c0s + l];
+				while (c < s.cnt) {
+					const int32_t m = s.cnt - c < 8 ? s.cnt - c : 8;
+					uint32_t v[8];
+#pragma unroll
+					for (int k = 0; k < 8; ++k) v[k] = list[c + (k < m ? k : m - 1)];
+					int32_t below = 0;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) below += (k < m && v[k] < hi) ? 1 : 0;
+					if (below > 0) {
+						const uint32_t slot = atomicAdd(&fill, (uint32_t)below);
+#pragma unroll
+						for (int k = 0; k < 8; ++k)
+							if (k < below && slot + k < (uint32_t)SIFT_CAP) keys[slot + k] = ((v[k] - lo + 1u) << LB) | (uint32_t)l;
+					}
+					c += below;
+					if (below < 8) break;
+				}
+				cur2[c0s + l] = c;
 			}
-			total = sift_block_sum(mine, scr);
-			if (n_carry + total <= SIFT_CAP) break;
+			__syncthreads();
+			n = fill;
+			if (n <= (uint32_t)SIFT_CAP) break;
 			if (hi - lo <= 1) {                                    // one block alone does not fit: the host seeds this query
 				if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
 				return;
 			}
 			width = (hi - lo) >> 1;
+			__syncthreads();                                       // (fill has been read)
 		}
-		// ---- load: (block - lo + 1) << LB | list; the carry sits in keys[0, n_carry) with local block 0
-		if (t == 0) fill = n_carry;
-		__syncthreads();
-		for (int32_t l = t; l < nl; l += SIFT_THREADS) {
-			const int32_t c0 = cur[c0s + l], c1 = cur2[c0s + l];
-			if (c1 > c0) {
-				const uint32_t *list = kb + jobs[j0 + l].kb_off;
-				uint32_t slot = atomicAdd(&fill, (uint32_t)(c1 - c0));
-				for (int32_t c = c0; c < c1; ++c) keys[slot++] = ((list[c] - lo + 1u) << LB) | (uint32_t)l;
-				cur[c0s + l] = c1;
-			}
-		}
-		const uint32_t n = n_carry + total;
-		__syncthreads();
+		for (int32_t l = t; l < nl; l += SIFT_THREADS) cur[c0s + l] = cur2[c0s + l];
+		const uint32_t total = n - n_carry;
 		// ---- sort keys[0, n): into buckets by the leading bits (in arrival order), then every key counts the smaller keys of its
 		// bucket -- a dozen instructions per key where a bitonic network spends a few hundred (keys are unique: no ties)
 		{
