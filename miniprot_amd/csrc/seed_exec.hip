@@ -500,8 +500,9 @@ __device__ __forceinline__ int32_t d_lower_bound(const uint32_t *a, int32_t n, u
 // id, and the order the reference sorts them into (map.c:178, radix_sort_mp64 on block << 32 | query position) is (block, seed)
 // with the seeds in ascending query position -- the order of the query's jobs.  One workgroup owns a SEGMENT of a query's block
 // space (a whole query when it has fewer than ~64 k anchors) and walks it in ascending ranges with one cursor per list: the
-// anchors of a range -- at most SIFT_CAP, the range is halved until they fit -- go to LDS as (block - range start + 1) << LB |
-// list, are sorted there (bitonic), and every anchor that has another one in its own or in an adjacent block (the only ones the
+// anchors of a range -- at most SIFT_CAP, the range is halved and read again when they do not fit -- go to LDS as
+// (block - range start + 1) << LB | list in one pass over the lists, are sorted there (buckets by the key's leading bits, then
+// each key counts the smaller keys of its bucket), and every anchor that has another one in its own or in an adjacent block (the only ones the
 // pre-chain, map.c:186-192 with max_dist_x = one block, can link) is written out at its final sorted position together with
 // its rank in the query's FULL sorted list (which the host's replay of the reference's unstable chain-end sort needs,
 // host_core.cpp sorted_chain_ends_sparse).  Anchors in the last block of a range wait for the next range (the "carry"): whether
@@ -556,6 +557,38 @@ __device__ __forceinline__ uint32_t sift_block_scan(uint32_t v, volatile uint32_
 // writing past its share.  seg_kept[seg] / seg_base[seg]: how many and from where.
 #define SIFT_FULL_STAGE 16384
 __host__ __device__ inline int64_t sift_stage_slots(int64_t n_anchor) { return n_anchor > SIFT_FULL_STAGE ? (n_anchor + 1) / 2 : n_anchor; }
+// One step of a list's cursor: the next W entries (fewer at the list's end: m of them, the last one repeated) are read at once
+// (sift_fetch); those below block hi take slots of the range's buffer as (block - lo + 1) << LB | l (sift_place, which returns
+// how many there were -- W: the list may hold more of them).
+template<int W>
+__device__ __forceinline__ void sift_fetch(uint32_t (&v)[W], const uint32_t *list, int32_t c, int32_t cnt)
+{
+	const int32_t m = cnt - c < W ? cnt - c : W;
+#pragma unroll
+	for (int k = 0; k < W; ++k) v[k] = list[c + (k < m ? k : m - 1)];
+}
+template<int W>
+__device__ __forceinline__ int32_t sift_place(const uint32_t (&v)[W], int32_t c, int32_t cnt, uint32_t lo, uint32_t hi, int LB, uint32_t l, uint32_t *keys, uint32_t *fill, uint32_t cap)
+{
+	const int32_t m = cnt - c < W ? cnt - c : W;
+	int32_t below = 0;
+#pragma unroll
+	for (int k = 0; k < W; ++k) below += (k < m && v[k] < hi) ? 1 : 0;
+	if (below > 0) {
+		const uint32_t slot = atomicAdd(fill, (uint32_t)below);
+#pragma unroll
+		for (int k = 0; k < W; ++k)
+			if (k < below && slot + k < cap) keys[slot + k] = ((v[k] - lo + 1u) << LB) | l;
+	}
+	return below;
+}
+template<int W>
+__device__ __forceinline__ int32_t sift_take(const uint32_t *list, int32_t c, int32_t cnt, uint32_t lo, uint32_t hi, int LB, uint32_t l, uint32_t *keys, uint32_t *fill, uint32_t cap)
+{
+	uint32_t v[W];
+	sift_fetch<W>(v, list, c, cnt);
+	return sift_place<W>(v, c, cnt, lo, hi, LB, l, keys, fill, cap);
+}
 template<int SIFT_CAP>
 __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const int64_t *sfirst, const uint32_t *kb,
                                                             uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
@@ -568,7 +601,7 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 	__shared__ uint32_t bcnt[SIFT_NBK];                        // bucket sizes, then starts / ends
 	__shared__ uint32_t bmax;
 	__shared__ uint32_t scr[4];
-	__shared__ uint32_t wtot[4];
+	__shared__ uint32_t wtot[SIFT_CAP / SIFT_THREADS * 4];      // kept keys per chunk of 256 and wave
 	__shared__ uint32_t fill;                                  // slots of `keys` taken while a range is loaded
 	const int t = threadIdx.x;
 	const SiftSeg sg = segs[blockIdx.x];
@@ -585,6 +618,13 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 
 	// ---- cursors at the segment's first block; rank base; is there an anchor in block lo0 - 1?
 	const bool half_stage = n_anchor > SIFT_FULL_STAGE;      // (see sift_stage_slots)
+	// The first 256 lists (all of them for most queries) live in their threads' registers: the job, the cursor, and the NEXT eight
+	// entries, fetched as soon as the cursor is known -- a list sits at a random place of a multi-GB array, and the round trip of
+	// its first touch in a range (TLB miss included) then runs behind the sort and the output of the range before.
+	SeedJobDev s0;
+	s0.kb_off = 0, s0.cnt = 0;
+	int32_t c_reg = 0;
+	uint32_t pre[8];
 	uint32_t below = 0, left_nb = 0, inside = 0;
 	for (int32_t l = t; l < nl; l += SIFT_THREADS) {
 		const SeedJobDev s = jobs[j0 + l];
@@ -595,6 +635,7 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 			if (c > 0 && list[c - 1] == lo0 - 1) left_nb = 1;
 		}
 		cur[c0s + l] = c;
+		if (l == t) s0 = s, c_reg = c;
 		below += (uint32_t)c;
 		if (half_stage) inside += (uint32_t)((hi0 < n_block ? d_lower_bound(list, s.cnt, (uint64_t)hi0) : s.cnt) - c);
 	}
@@ -609,6 +650,7 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 		stage_cap = ((pos_base + seg_total) >> 1) - (pos_base >> 1);
 	}
 
+	if (c_reg < s0.cnt) sift_fetch<8>(pre, kb + s0.kb_off, c_reg, s0.cnt);
 	uint32_t lo = lo0, n_carry = 0, kept_total = 0, emitted = pos_base;
 	uint32_t prev_blk = left_nb ? lo0 - 1 : 0xffffffffu;      // block of the last anchor below the buffer (0xffffffff: none that matters)
 	// width of the first range: SIFT_TARGET anchors if the query's anchors were spread evenly over the genome
@@ -622,32 +664,39 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 		// block 0), in ONE pass over the lists -- eight entries per dependent step, one slot request per step; a range whose
 		// anchors do not fit is halved and read again (rare: the width follows the density)
 		uint32_t hi, n;
+		int32_t c_new0 = c_reg;
 		for (;;) {
 			hi = hi0 - lo > width ? lo + width : hi0;
 			if (t == 0) fill = n_carry;
 			__syncthreads();
-			for (int32_t l = t; l < nl; l += SIFT_THREADS) {
-				const SeedJobDev s = jobs[j0 + l];
-				const uint32_t *list = kb + s.kb_off;
-				int32_t c = cur[c0s + l];
-				while (c < s.cnt) {
-					const int32_t m = s.cnt - c < 8 ? s.cnt - c : 8;
-					uint32_t v[8];
-#pragma unroll
-					for (int k = 0; k < 8; ++k) v[k] = list[c + (k < m ? k : m - 1)];
-					int32_t below = 0;
-#pragma unroll
-					for (int k = 0; k < 8; ++k) below += (k < m && v[k] < hi) ? 1 : 0;
-					if (below > 0) {
-						const uint32_t slot = atomicAdd(&fill, (uint32_t)below);
-#pragma unroll
-						for (int k = 0; k < 8; ++k)
-							if (k < below && slot + k < (uint32_t)SIFT_CAP) keys[slot + k] = ((v[k] - lo + 1u) << LB) | (uint32_t)l;
-					}
-					c += below;
-					if (below < 8) break;
+			for (int32_t l0 = 0; l0 < nl; l0 += SIFT_THREADS) {
+				const int32_t l = l0 + t;
+				SeedJobDev s = s0;
+				int32_t c = c_reg;
+				if (l0 > 0) {
+					s.kb_off = 0, s.cnt = 0, c = 0;
+					if (l < nl) s = jobs[j0 + l], c = cur[c0s + l];
 				}
-				cur2[c0s + l] = c;
+				const uint32_t *list = kb + s.kb_off;
+				// (the first step of a register-resident list was fetched while the range before was sorted; the steps after it are 16
+				// entries wide: a few frequent k-mers hold hundreds of a range's anchors and the slowest thread sets the pace)
+				if (c < s.cnt) {
+					uint32_t v[8];
+					if (l0 == 0) {
+#pragma unroll
+						for (int k = 0; k < 8; ++k) v[k] = pre[k];
+					} else sift_fetch<8>(v, list, c, s.cnt);
+					int32_t b = sift_place<8>(v, c, s.cnt, lo, hi, LB, (uint32_t)l, keys, &fill, SIFT_CAP);
+					c += b;
+					if (b == 8)
+						while (c < s.cnt) {
+							b = sift_take<16>(list, c, s.cnt, lo, hi, LB, (uint32_t)l, keys, &fill, SIFT_CAP);
+							c += b;
+							if (b < 16) break;
+						}
+				}
+				if (l < nl) cur2[c0s + l] = c;
+				if (l0 == 0) c_new0 = c;
 			}
 			__syncthreads();
 			n = fill;
@@ -660,6 +709,8 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 			__syncthreads();                                       // (fill has been read)
 		}
 		for (int32_t l = t; l < nl; l += SIFT_THREADS) cur[c0s + l] = cur2[c0s + l];
+		c_reg = c_new0;
+		if (c_reg < s0.cnt && hi < hi0) sift_fetch<8>(pre, kb + s0.kb_off, c_reg, s0.cnt);       // the next range's first step
 		const uint32_t total = n - n_carry;
 		// ---- sort keys[0, n): into buckets by the leading bits (in arrival order), then every key counts the smaller keys of its
 		// bucket -- a dozen instructions per key where a bitonic network spends a few hundred (keys are unique: no ties)
@@ -735,36 +786,53 @@ __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 		}
 		const int64_t left0 = prev_blk == 0xffffffffu ? -(int64_t)(1 << 30) : (int64_t)prev_blk - (int64_t)lo + 1;   // local block of the anchor below the buffer
 		const int64_t right_end = last && right_nb ? (int64_t)(hi0 - lo) + 1 : ((int64_t)1 << 40);                      // ... of the one above it
-		for (uint32_t base = 0; base < n_emit; base += SIFT_THREADS) {
-			const uint32_t i = base + t;
+		// keep flags of the thread's keys (one per chunk of 256), the chunks' per-wave counts, one scan of those (each wave does
+		// it for itself), then the writes: two barriers per range
+		constexpr int ECH = SIFT_CAP / SIFT_THREADS;
+		static_assert(ECH * 4 <= 64, "the scan of the chunk counts is one wave wide");
+		const uint32_t lane = t & 63, wv = t >> 6;
+		uint32_t keepbits = 0;
+#pragma unroll
+		for (int k = 0; k < ECH; ++k) {
+			const uint32_t i = (uint32_t)k * SIFT_THREADS + t;
 			bool keep = false;
-			uint32_t key = 0;
 			if (i < n_emit) {
-				key = keys[i];
-				const int64_t b = (int64_t)(key >> LB);
+				const int64_t b = (int64_t)(keys[i] >> LB);
 				const int64_t lf = i > 0 ? (int64_t)(keys[i - 1] >> LB) : left0;
 				const int64_t rt = i + 1 < n ? (int64_t)(keys[i + 1] >> LB) : right_end;
 				keep = b - lf <= 1 || rt - b <= 1;
 			}
+			keepbits |= (keep ? 1u : 0u) << k;
 			const unsigned long long bal = __ballot(keep);
-			const uint32_t lane = t & 63, wv = t >> 6;
-			const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-			__syncthreads();                                       // (wtot of the previous chunk has been read)
-			if (lane == 0) wtot[wv] = (uint32_t)__popcll(bal);
-			__syncthreads();
-			uint32_t off = kept_total + before;
-			for (uint32_t w = 0; w < wv; ++w) off += wtot[w];
-			if (kept_total + wtot[0] + wtot[1] + wtot[2] + wtot[3] > stage_cap) {   // (uniform) more than half of the segment's anchors kept: the host seeds this query
-				if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
-				return;
-			}
+			if (lane == 0) wtot[k * 4 + wv] = (uint32_t)__popcll(bal);
+		}
+		__syncthreads();
+		uint32_t inc = lane < (uint32_t)ECH * 4u ? wtot[lane] : 0u;
+		const uint32_t own = inc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t v = __shfl_up(inc, o);
+			if (lane >= (uint32_t)o) inc += v;
+		}
+		const uint32_t ex = inc - own, n_keep = __shfl(inc, 63);
+		if (kept_total + n_keep > stage_cap) {                     // (uniform) more than half of the segment's anchors kept: the host seeds this query
+			if (t == 0) { atomicExch(&qflag[q], 1); seg_kept[blockIdx.x] = 0; seg_base[blockIdx.x] = out0; }
+			return;
+		}
+#pragma unroll
+		for (int k = 0; k < ECH; ++k) {
+			if ((uint32_t)k * SIFT_THREADS >= n_emit) break;
+			const bool keep = (keepbits >> k) & 1u;
+			const unsigned long long bal = __ballot(keep);
+			const uint32_t first = __shfl(ex, k * 4 + (int)wv);
 			if (keep) {
-				const uint32_t l = key & lmask;
+				const uint32_t i = (uint32_t)k * SIFT_THREADS + t, key = keys[i], l = key & lmask;
+				const uint32_t off = kept_total + first + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
 				skey[out0 + off] = ((uint64_t)(uint32_t)q << nb) | (uint64_t)(lo + (key >> LB) - 1u);
 				sval[out0 + off] = ((uint64_t)(emitted + i) << 32) | (uint32_t)jobs[j0 + l].qpos;
 			}
-			kept_total += wtot[0] + wtot[1] + wtot[2] + wtot[3];
 		}
+		kept_total += n_keep;
 		// ---- the carry moves to the front (local block 0 of the next range); the range is done
 		if (n_emit > 0) prev_blk = lo + (keys[n_emit - 1] >> LB) - 1u;
 		uint32_t cv[SIFT_CARRY_MAX / SIFT_THREADS];
