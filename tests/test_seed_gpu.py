@@ -157,8 +157,8 @@ def test_device_chains_equal_host_chains(seed, monkeypatch):
 
 
 def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypatch):
-    """k_seed_sift holds the anchors of one range in a 2 048-entry LDS buffer; a query whose seeds put more than that into ONE
-    block (here: 3 000 identical k-mers of a poly-L protein over CTG repeats in the genome) is flagged by the kernel and
+    """k_seed_sift holds the anchors of one range in a 4 096-entry LDS buffer; a query whose seeds put more than that into ONE
+    block (here: 5 000 identical k-mers of a poly-L protein over CTG repeats in the genome) is flagged by the kernel and
     seeded on the host, the other queries of the batch stay on the device -- same survivors as the host stage for all of them"""
     contigs, prots, names, planted = gen_synth.generate(2000000, 1, 20, 31, return_planted=True)
     g = contigs[0]
@@ -170,7 +170,7 @@ def test_sift_declines_a_block_that_cannot_fit_and_the_host_takes_over(monkeypat
     idx.to_device(ctx)
     # (the third odd query: 300 seeds in the same few blocks of an otherwise wide range -- one bucket of the in-LDS sort holds
     # hundreds of keys, which sends that range to the bitonic network)
-    seqs = [bytes(p) for p in planted[:8]] + [b"M" + b"L" * 3000, b"L" * 1500 + bytes(planted[0]), bytes(planted[1]) + b"L" * 300] + [bytes(p) for p in planted[8:12]]
+    seqs = [bytes(p) for p in planted[:8]] + [b"M" + b"L" * 5000, b"L" * 1500 + bytes(planted[0]), bytes(planted[1]) + b"L" * 300] + [bytes(p) for p in planted[8:12]]
     q = mpa.Queries(seqs)
     mo = mpa.default_mapopt()
     mo.max_occ = 100000
