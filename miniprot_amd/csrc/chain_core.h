@@ -74,6 +74,7 @@ struct CoopSerial {          // a team of one: the host
 	static MPA_HD int64_t scan_excl(int64_t v, int64_t *total) { *total = v; return 0; }   // sum of v over the lanes below this one; the team's total
 	static MPA_HD int64_t scan_max_excl(int64_t v, int64_t *total) { *total = v; return INT64_MIN; }   // maximum over the lanes below (INT64_MIN: none); the team's
 	static MPA_HD void mark_time(int) {}                               // phase stamps of the device profile (MPA_TIMING=2)
+	static MPA_HD void note(int, int64_t) {}                           // ... and problem sizes
 	// among the lanes with `have`, those whose digit d equals this lane's: how many sit below this lane, and how many there are
 	static MPA_HD void digit_rank(int, bool, int *rank, int *cnt) { *rank = 0, *cnt = 1; }
 	static MPA_HD int first_unset(uint64_t m) { return m & 1u ? 1 : 0; }
@@ -371,6 +372,7 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 		[&](int64_t i) { const bool c = v.pred[i] >= 0; if (c) { if (v.f[i] <= p.kmer) odd = true; if (v.f[i] > max_f) max_f = v.f[i]; } return c; },
 		[&](int64_t i, int64_t k) { items[k] = SparseItem{ view_pos(v, i), Pair64{ (uint64_t)(int64_t)v.f[i], (uint64_t)i } }; });
 	max_f = C::reduce_max(max_f);
+	C::note(0, v.m), C::note(1, n_items);
 	if (C::any(odd)) return -1;
 	if (max_f < 256) { replay_low_digit<C>(n, p.kmer, items, n_items, out, S.hist); return n_items; }
 	if (max_f >= 65536) return -1;
@@ -385,6 +387,7 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 	C::sync();
 	for (int d = 1; d < 256; ++d) m_hi += cnt8[d];         // (scores below 256 are not counted: bucket 0 stays 0)
 	const int64_t c0 = n - m_hi;
+	C::note(2, m_hi);
 	Pair64 *tail8 = S.tail8;
 	MPA_COOP_FOR(C, i, m_hi) tail8[i] = Pair64{ (uint64_t)p.kmer, MPA_ABSENT };
 	C::sync();
@@ -461,6 +464,7 @@ template<class C> MPA_HD inline int64_t sorted_chain_ends_sparse(const ChainPara
 	C::mark_time(7);
 	for (int d = 0; d < 256; ++d) cnt_hi[d] = d ? cnt8[d] : 0u;   // (the level-2 passes below reuse the first 768 words of S.hist)
 	C::sync();
+	{ uint32_t big = 0; for (int d = 1; d < 256; ++d) big = cnt_hi[d] > big ? cnt_hi[d] : big; C::note(3, big), C::note(4, n_merged); }
 	int64_t n_out = 0;
 	if (c0 > 64) { replay_low_digit<C>(c0, p.kmer, merged, n_merged, out, S.hist); n_out = n_merged; }
 	else {                                                  // a short bucket is insertion-sorted: stable

@@ -610,8 +610,8 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	long long *d_prof = nullptr;
 	auto prof_begin = [&]() -> int {
 		if (!prof) return MPA_OK;
-		HIP_TRY(hipMalloc((void**)&d_prof, NQ * 64 + 64));
-		HIP_TRY(hipMemsetAsync(d_prof, 0, NQ * 64, s));
+		HIP_TRY(hipMalloc((void**)&d_prof, NQ * 128 + 64));
+		HIP_TRY(hipMemsetAsync(d_prof, 0, NQ * 128, s));
 		const int n_prof = (int)NQ;
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof_n), &n_prof, sizeof(n_prof), 0, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &d_prof, sizeof(d_prof), 0, hipMemcpyHostToDevice, s));
@@ -619,24 +619,42 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	};
 	auto prof_end = [&](const char *what) -> int {
 		if (!prof) return MPA_OK;
-		std::vector<long long> h(NQ * 8);
-		HIP_TRY(hipMemcpyAsync(h.data(), d_prof, NQ * 64, hipMemcpyDeviceToHost, s));
+		std::vector<long long> h(NQ * 16);
+		HIP_TRY(hipMemcpyAsync(h.data(), d_prof, NQ * 128, hipMemcpyDeviceToHost, s));
 		HIP_TRY(wait_stream(ctx, s));
 		double sum[4] = { 0, 0, 0, 0 }, sub[4] = { 0, 0, 0, 0 }, mx = 0;
 		int64_t cnt = 0, cnt2 = 0;
+		std::vector<std::pair<double, size_t>> by_time;
 		for (size_t q = 0; q < NQ; ++q) {
-			if (!h[q * 8 + 4] || !h[q * 8]) continue;
-			for (int k = 0; k < 4; ++k) sum[k] += (double)(h[q * 8 + k + 1] - h[q * 8 + k]) * 1e-5;   // 100 MHz ticks -> ms
-			mx = std::max(mx, (double)(h[q * 8 + 4] - h[q * 8]) * 1e-5), ++cnt;
-			if (h[q * 8 + 5] && h[q * 8 + 6] && h[q * 8 + 7]) {       // the two-level sort replay: its parts (stamps 5-7 lie between 0 and 1)
-				sub[0] += (double)(h[q * 8 + 5] - h[q * 8]) * 1e-5, sub[1] += (double)(h[q * 8 + 6] - h[q * 8 + 5]) * 1e-5;
-				sub[2] += (double)(h[q * 8 + 7] - h[q * 8 + 6]) * 1e-5, sub[3] += (double)(h[q * 8 + 1] - h[q * 8 + 7]) * 1e-5, ++cnt2;
+			const long long *t = &h[q * 16];
+			if (!t[4] || !t[0]) continue;
+			for (int k = 0; k < 4; ++k) sum[k] += (double)(t[k + 1] - t[k]) * 1e-5;   // 100 MHz ticks -> ms
+			mx = std::max(mx, (double)(t[4] - t[0]) * 1e-5), ++cnt;
+			by_time.emplace_back((double)(t[4] - t[0]) * 1e-5, q);
+			if (t[5] && t[6] && t[7]) {                            // the two-level sort replay: its parts (stamps 5-7 lie between 0 and 1)
+				sub[0] += (double)(t[5] - t[0]) * 1e-5, sub[1] += (double)(t[6] - t[5]) * 1e-5;
+				sub[2] += (double)(t[7] - t[6]) * 1e-5, sub[3] += (double)(t[1] - t[7]) * 1e-5, ++cnt2;
 			}
 		}
 		fprintf(stderr, "[mpa-extract-prof] %s: %lld problems; mean ms: sort replay %.2f, trees %.2f, extraction %.2f, output %.2f; slowest problem %.2f ms\n", what, (long long)cnt,
 		        sum[0] / std::max<int64_t>(cnt, 1), sum[1] / std::max<int64_t>(cnt, 1), sum[2] / std::max<int64_t>(cnt, 1), sum[3] / std::max<int64_t>(cnt, 1), mx);
 		if (cnt2) fprintf(stderr, "[mpa-extract-prof]   two-level replay (%lld problems): level-1 placement %.2f, level-1 walk %.2f, merge %.2f, level 2 %.2f ms\n", (long long)cnt2,
 		                  sub[0] / cnt2, sub[1] / cnt2, sub[2] / cnt2, sub[3] / cnt2);
+		if (!by_time.empty()) {                                   // the distribution, and what the slowest problems look like
+			std::sort(by_time.begin(), by_time.end());
+			const size_t n = by_time.size();
+			fprintf(stderr, "[mpa-extract-prof]   problem ms: p50 %.2f p90 %.2f p99 %.2f max %.2f\n", by_time[n / 2].first, by_time[n * 9 / 10].first, by_time[n * 99 / 100].first, by_time[n - 1].first);
+			for (size_t k = 0; k < std::min<size_t>(n, 6); ++k) {
+				const size_t q = by_time[n - 1 - k].second;
+				const long long *t = &h[q * 16];
+				fprintf(stderr, "[mpa-extract-prof]   slow #%zu: %.2f ms (replay %.2f [lvl2 %.2f] trees %.2f extraction %.2f output %.2f); view %lld, non-roots %lld, high scores %lld, largest level-2 bucket %lld, merged %lld\n", k,
+				        by_time[n - 1 - k].first, (double)(t[1] - t[0]) * 1e-5, t[7] ? (double)(t[1] - t[7]) * 1e-5 : 0.0, (double)(t[2] - t[1]) * 1e-5, (double)(t[3] - t[2]) * 1e-5, (double)(t[4] - t[3]) * 1e-5,
+				        t[8], t[9], t[10], t[11], t[12]);
+			}
+			const size_t q = by_time[n / 2].second;
+			const long long *t = &h[q * 16];
+			fprintf(stderr, "[mpa-extract-prof]   median problem: view %lld, non-roots %lld, high scores %lld, largest level-2 bucket %lld, merged %lld\n", t[8], t[9], t[10], t[11], t[12]);
+		}
 		long long *none = nullptr;
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_extract_prof), &none, sizeof(none), 0, hipMemcpyHostToDevice, s));
 		HIP_TRY(wait_stream(ctx, s));

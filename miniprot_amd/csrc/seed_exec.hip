@@ -311,7 +311,8 @@ struct CoopWave {
 	static __device__ __forceinline__ int first_unset(uint64_t m) { return m == ~0ull ? 64 : __ffsll((long long)~m) - 1; }
 	static __device__ __forceinline__ int lowest(uint64_t m) { return __ffsll((long long)m) - 1; }
 	static __device__ __forceinline__ uint64_t *scratch(int64_t *cap) { *cap = EXTRACT_STAGE_WORDS; return g_extract_stage(); }
-	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 8 + k] = (long long)wall_clock64(); }
+	static __device__ __forceinline__ void mark_time(int k) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 16 + k] = (long long)wall_clock64(); }
+	static __device__ __forceinline__ void note(int k, int64_t v) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 16 + 8 + k] = (long long)v; }
 };
 
 __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)
