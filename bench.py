@@ -223,8 +223,24 @@ def roofline_record(st, elapsed, world):
     extension call and the traceback calls of the round's first chunk; its duration is measured with HIP events on the stream
     it is launched on.  (With MPA_ONE_LAUNCH=0 the figures are those of the per-class extension kernels, whose durations
     overlap.)"""
-    if st["launches_round"] > 0 and st["ms_round"] > 0:
-        kernel = "k_dp_round (one launch per DP round: all extension classes + first traceback chunk)"
+    pool = None
+    if st["launches_round"] > 0 and st["ms_round"] > 0 and st.get("ms_round_union", 0) > 0:
+        # DP worker pool (default): the units of all rounds in flight are served by ONE population of k_dp_worker workgroups; a worker
+        # launch (one per round, from the lane's worker stream) runs units of any lane, so "ops of a launch" exist only in sum.
+        # The kernel's duration = the time during which the pool has a launch running (union of the launches' HIP-event intervals):
+        # what ONE persistent kernel's duration would be.  Sum and mean of the launches themselves are kept next to it (`per_launch`:
+        # the figures rocprofv3's kernel trace shows for k_dp_worker; they overlap up to MPA_DP_LANES deep).
+        kernel = "k_dp_worker (DP worker pool: every extension class + first traceback chunk of all rounds in flight; one launch of workers per round)"
+        n, ms = st["launches_round"], st["ms_round_union"]
+        ops = OPS_PER_CELL_EXT * st["cells_ext_round"] + OPS_PER_CELL_GLOB * st["cells_glob_round"]
+        cells = st["cells_ext_round"] + st["cells_glob_round"]
+        pool = {"launches": n, "sum_launch_ms": st["ms_round"], "avg_launch_ms": st["ms_round"] / n, "union_ms": ms,
+                "frac_by_sum_of_launches": ops / (st["ms_round"] * 1e-3) / VALU_I16_PEAK,
+                "note": "achieved/frac above use union_ms (time with >= 1 worker launch running on the device); frac_by_sum_of_launches divides by the "
+                        "SUM of the overlapping launches' durations instead"}
+        note = "HIP events on the lanes' worker streams against one base event; ops = all units of the timed rounds"
+    elif st["launches_round"] > 0 and st["ms_round"] > 0:
+        kernel = "k_dp_round (MPA_DP_POOL=0: one launch per DP round: all extension classes + first traceback chunk)"
         n, ms = st["launches_round"], st["ms_round"]
         ops = OPS_PER_CELL_EXT * st["cells_ext_round"] + OPS_PER_CELL_GLOB * st["cells_glob_round"]
         cells = st["cells_ext_round"] + st["cells_glob_round"]
@@ -260,13 +276,13 @@ def roofline_record(st, elapsed, world):
                 pass
     return {"kernel": kernel, "bound": "valu-int16", "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
             "traffic": traffic, "traffic_source": src,
-            "launches": n, "avg_launch_ms": ms / n, "cells_per_launch": cells / n, "ops_per_cell": {"score_only": OPS_PER_CELL_EXT, "traceback": OPS_PER_CELL_GLOB},
-            "gcups_per_launch": cells / (ms * 1e-3) / 1e9,
+            "launches": n, "avg_launch_ms": (st["ms_round"] if pool else ms) / n, "kernel_active_ms": ms, "cells_per_launch": cells / n, "ops_per_cell": {"score_only": OPS_PER_CELL_EXT, "traceback": OPS_PER_CELL_GLOB},
+            "gcups_per_launch": cells / (ms * 1e-3) / 1e9,          # (worker pool: GCUPS while the pool is running)
             "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes / n,
                     "note": "algorithmic bytes of the launch's calls (SURVEY.md 8(d): extension = packed window + protein + result; traceback adds 2 B per cell, the path's words and the CIGAR) / launch time: not the binding roof"},
             "wall": {"achieved": wall_ops / 1e12, "frac": wall_ops / VALU_I16_PEAK / max(world, 1), "unit": "Tops/s",
                      "note": "all DP ops of the timed steps (32/cell score-only + 65/cell traceback) / elapsed wall time / GPUs: includes every host stage and idle gap"},
-            "note": note}
+            "per_launch": pool, "note": note}
 
 
 def cli_end_to_end(wl, n_threads, cpu):
@@ -376,7 +392,7 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-            keys = ("cells_ext", "cells_glob", "alg_bytes_ext", "alg_bytes_glob", "launches_ext", "ms_ext", "cells_ext_round", "cells_glob_round", "launches_round", "ms_round", "host_cpu_s", "hbm_bytes")
+            keys = ("cells_ext", "cells_glob", "alg_bytes_ext", "alg_bytes_glob", "launches_ext", "ms_ext", "cells_ext_round", "cells_glob_round", "launches_round", "ms_round", "ms_round_union", "host_cpu_s", "hbm_bytes")
             tot = torch.tensor([float(st[k]) for k in keys], dtype=torch.float64, device=device)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             for k, v in zip(keys, tot.tolist()):

@@ -172,10 +172,15 @@ typedef struct {
 	int64_t alg_bytes_ext, alg_bytes_glob; /* algorithmic HBM bytes, SURVEY.md 8(d) */
 	double ms_prep, ms_ext, ms_glob, ms_backtrack, ms_total; /* HIP-event timings on the context's stream */
 	int32_t launches_ext, launches_glob;
-	/* k_dp_round (one launch per DP round: every extension call + the traceback calls of the first traceback chunk) */
+	/* the DP round kernel: k_dp_worker launches of the device's worker pool (default; one launch of workers per DP round, the
+	 * workers of all lanes serve the units of all rounds in flight), or k_dp_round (MPA_DP_POOL=0: one launch per round).  A round
+	 * = every extension call + the traceback calls of the first traceback chunk. */
 	int64_t cells_ext_round, cells_glob_round;   /* padded DP cells those launches swept */
 	double ms_round;                             /* sum of their HIP-event durations */
 	int32_t launches_round, pad_;
+	double ms_round_union;                       /* worker pool: time during which at least one worker launch of the DEVICE was running
+	                                              * (the union of the launches' intervals; the stream's rounds overlap) -- what one
+	                                              * persistent kernel's duration would be.  0 with MPA_DP_POOL=0. */
 } mpa_dp_stats_t;
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
 /* sums over every mpa_dp_run() of this context since the last reset */
@@ -285,6 +290,15 @@ typedef int32_t (*mpa_claim_fn)(void *user);
 int mpa_map_batches_claim(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
                           const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len,
                           mpa_claim_fn claim, void *user, int32_t *n_mapped, int32_t *order);
+
+/* The same job over SEVERAL GPUs of one process -- what mp_map_file()'s kt_for (map.c:264-271, 291) is across the threads of the
+ * reference: one pipeline per device context (ctxs[0 .. n_ctx), each created on a different device with mpa_ctx_create), every
+ * pipeline claiming the job's next mini-batch from a shared counter whenever it has room; the index is uploaded to each device
+ * (mpa_idx_to_device is called for you).  results / text / text_len come back in INPUT order with the hit ids of a single
+ * pipeline's run (GFF3 / GTF text is formatted after the mapping, from the prefix sum of mpa_result_n_output()).  n_threads is
+ * shared out over the pipelines.  This is what the mp_map_file() of this library runs on every visible device (MPA_DEVICES). */
+int mpa_map_batches_multi(int n_ctx, mpa_ctx_t *const *ctxs, mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                          const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len);
 
 const char *mpa_version(void);
 

@@ -60,7 +60,7 @@ class DpStats(C.Structure):
                 ("ms_prep", C.c_double), ("ms_ext", C.c_double), ("ms_glob", C.c_double),
                 ("ms_backtrack", C.c_double), ("ms_total", C.c_double), ("launches_ext", C.c_int32),
                 ("launches_glob", C.c_int32), ("cells_ext_round", C.c_int64), ("cells_glob_round", C.c_int64),
-                ("ms_round", C.c_double), ("launches_round", C.c_int32), ("pad_", C.c_int32)]
+                ("ms_round", C.c_double), ("launches_round", C.c_int32), ("pad_", C.c_int32), ("ms_round_union", C.c_double)]
 
 
 def build(verbose=False):
@@ -452,6 +452,32 @@ def map_batches(ctx, idx, mo, batches, n_threads=1, keep_results=False, want_tex
     if order is not None:
         return (order, out, results) if keep_results else (order, out)
     return (out, results) if keep_results else out
+
+
+def map_batches_multi(ctxs, idx, mo, batches, n_threads=1):
+    """mpa_map_batches_multi(): one job over several device contexts of THIS process (one pipeline per context, batches claimed
+    from a shared counter).  Returns the output texts in input order -- the bytes a single pipeline produces."""
+    n = len(batches)
+    if n == 0:
+        return []
+    qb = (QBatch * n)(*[b.c for b in batches])
+    res = (C.c_void_p * n)()
+    idc = C.c_int64(0)
+    name_arrays = [(C.c_char_p * len(b.names))(*[x.encode() for x in b.names]) for b in batches]
+    names = (C.POINTER(C.c_char_p) * n)(*[C.cast(a, C.POINTER(C.c_char_p)) for a in name_arrays])
+    text = (C.c_void_p * n)()
+    tlen = (C.c_int64 * n)()
+    hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    f = lib().mpa_map_batches_multi
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(len(ctxs), hs, idx.h, C.byref(mo), n, qb, names, n_threads, res, C.byref(idc), text, tlen))
+    out = []
+    for k in range(n):
+        out.append(C.string_at(text[k], tlen[k]))
+        lib().mpa_free(C.c_void_p(text[k]))
+        lib().mpa_result_destroy(C.c_void_p(res[k]))
+    return out
 
 
 def dp_run(ctx, idx, dpopt, queries, tasks, wide32=False):

@@ -103,6 +103,40 @@ mpa_ctx_t *shared_ctx()
 	return g_ctx;
 }
 
+// mp_map_file() maps on every visible GPU (the reference's kt_for over threads, map.c:291, becomes one pipeline per device):
+// MPA_DEVICES = "all" (default), a count ("4": devices 0..3) or a list ("0,2,5"; a device may be named twice: two pipelines on
+// it -- how the single-GPU tests exercise this path).  MPA_DEVICE alone (the device of mp_map / ns_global_gs16b) keeps the file
+// mapper on that one device.
+std::vector<mpa_ctx_t*> g_file_ctx;
+const std::vector<mpa_ctx_t*> &file_ctxs()             // caller holds g_mu
+{
+	if (!g_file_ctx.empty()) return g_file_ctx;
+	std::vector<int> devs;
+	const int n_dev = mpa_device_count();
+	const char *e = getenv("MPA_DEVICES");
+	if (!e || !*e) {
+		if (getenv("MPA_DEVICE")) devs.push_back(default_device());
+		else for (int d = 0; d < n_dev; ++d) devs.push_back(d);
+	} else if (strcmp(e, "all") == 0) {
+		for (int d = 0; d < n_dev; ++d) devs.push_back(d);
+	} else if (strchr(e, ',')) {
+		for (const char *p = e; *p; ) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+	} else {
+		for (int d = 0; d < atoi(e) && d < n_dev; ++d) devs.push_back(d);
+	}
+	if (devs.size() > 8) devs.resize(8);
+	bool shared_used = false;
+	for (int d : devs) {
+		mpa_ctx_t *c = nullptr;
+		if (d == default_device() && !shared_used) c = shared_ctx(), shared_used = true;
+		else c = mpa_ctx_create(d);
+		if (!c) die("mp_map_file: no usable HIP device (there is no CPU fallback)");
+		g_file_ctx.push_back(c);
+	}
+	if (g_file_ctx.empty()) g_file_ctx.push_back(shared_ctx());
+	return g_file_ctx;
+}
+
 double g_t0 = 0;
 double wall_now()
 {
@@ -349,8 +383,9 @@ int32_t mp_map_file(const mp_idx_t *idx, const char *fn, const mp_mapopt_t *opt,
 	CompatIndex *c = owner(idx);
 	const mpa_mapopt_t *mo = reinterpret_cast<const mpa_mapopt_t*>(opt);
 	std::unique_lock<std::mutex> g(g_mu);
-	mpa_ctx_t *ctx = shared_ctx();
-	if (mpa_idx_to_device(ctx, c->impl) != MPA_OK) die("mp_map_file: index upload");
+	const std::vector<mpa_ctx_t*> &ctxs = file_ctxs();
+	for (mpa_ctx_t *ctx : ctxs) if (mpa_idx_to_device(ctx, c->impl) != MPA_OK) die("mp_map_file: index upload");
+	if (mp_verbose >= 3 && ctxs.size() > 1) fprintf(stderr, "[M::%s] mapping on %d device pipelines\n", __func__, (int)ctxs.size());
 	if (opt->flag & MP_F_GFF) puts("##gff-version 3");
 	struct Batch { std::string seqs; std::vector<int64_t> off; std::vector<std::string> names; std::vector<const char*> name_ptr; };
 	int64_t id = 0;
@@ -358,7 +393,7 @@ int32_t mp_map_file(const mp_idx_t *idx, const char *fn, const mp_mapopt_t *opt,
 	std::string name, comment, seq;
 	while (more) {
 		// a group of mini-batches at a time: enough for the pipeline to overlap its stages, bounded memory for any file size
-		const int kGroup = 16;
+		const int kGroup = 16 * (int)ctxs.size();
 		std::vector<Batch> grp;
 		while (more && (int)grp.size() < kGroup) {
 			Batch bt;
@@ -386,7 +421,7 @@ int32_t mp_map_file(const mp_idx_t *idx, const char *fn, const mp_mapopt_t *opt,
 		std::vector<mpa_result_t*> res((size_t)nb, nullptr);
 		std::vector<char*> text((size_t)nb, nullptr);
 		std::vector<int64_t> tlen((size_t)nb, 0);
-		if (mpa_map_batches(ctx, c->impl, mo, nb, qb.data(), names.data(), n_threads > 1 ? n_threads : 1, res.data(), &id, text.data(), tlen.data()) != MPA_OK)
+		if (mpa_map_batches_multi((int)ctxs.size(), ctxs.data(), c->impl, mo, nb, qb.data(), names.data(), n_threads > 1 ? n_threads : 1, res.data(), &id, text.data(), tlen.data()) != MPA_OK)
 			die("mp_map_file");
 		for (int32_t k = 0; k < nb; ++k) {
 			fwrite(text[k], 1, (size_t)tlen[k], stdout);

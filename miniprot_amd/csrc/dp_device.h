@@ -79,6 +79,31 @@ enum DpUnitKind : int32_t {
 };
 struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; };
 
+// The device-resident unit queues of the DP worker pool (k_dp_worker, dp_kernels.hip): one slot per DP lane of the stream
+// pipeline (a batch in its DP round), all slots of a device in ONE block of device memory that every lane's workers see.
+// A round is armed by writing its arguments and unit list, then `lim` = {generation, number of units}, then `head` =
+// {generation, 0}; a workgroup takes unit i of a slot with one fetch-add on head -- its unit if i < n and the generations of
+// head and lim agree (an index past the end is nobody's; the head is set afresh at the next arming).  The last unit to finish (remaining reaches 0) stores the generation into the lane's word
+// of pinned host memory.  Workers are ordinary workgroups that run units until no slot has any left and then exit: nothing on
+// the device ever waits for the host.
+#define MPA_DP_SLOTS 16
+struct DpSlotCtl {
+	unsigned long long head;     // {generation << 32 | next unit}
+	unsigned long long lim;      // {generation << 32 | number of units}
+	int32_t remaining;           // units of this round not yet finished
+	int32_t stamp;               // the pool's arm sequence number when this round was armed
+	int32_t *done;               // pinned host word of the lane: receives the generation when the round is complete
+	long long *trace;            // (MPA_DP_TRACE) per unit {start, end} in 100-MHz ticks, or nullptr
+	char pad2_[24];              // 64 bytes: slots do not share a cache line
+};
+struct DpPoolCtl {
+	int32_t alive;               // admitted workers that have not exited
+	int32_t budget;              // admission limit (the first few workgroups of every launch are admitted regardless)
+	int32_t arm_seq;             // rounds armed so far on this device
+	int32_t acquire_mode;        // what a worker does before it reads a round's inputs (MPA_DP_ACQUIRE, see k_dp_worker)
+	int32_t pad_[12];
+};
+
 struct DpConst {         // scalar scoring parameters, passed by value
 	int32_t go, ge, fs, xdrop, end_bonus;
 	int32_t sp[6];

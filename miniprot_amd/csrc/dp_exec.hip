@@ -92,6 +92,7 @@ struct DeviceIndex {
 	uint32_t *kb = nullptr;                   // k-mer occurrence lists (block ids), uploaded on first GPU seeding call
 	size_t kb_bytes = 0;
 	uint8_t *spsc = nullptr;                  // splice-score track (--spsc), uploaded with the genome when the index has one
+	size_t seq_bytes = 0, spsc_bytes = 0;     // bytes counted into g_dev_bytes for the genome and the track
 };
 
 struct HostPinned {
@@ -160,6 +161,22 @@ struct mpa_ctx_s {
 	struct PoolHints { std::atomic<size_t> dev[3][96]; };
 	PoolHints *hints = nullptr;               // (root context only, owned) high-water marks per pipeline role and pool
 	bool antidiag = false;                    // (measurement) the 32-column extension class runs on the anti-diagonal prototype, k_ext_antidiag (mpa_dbg_antidiag)
+	// ---- DP worker pool (dp_kernels.hip, k_dp_worker).  The pool itself belongs to the ROOT context of a device ...
+	mpa_ctx_s *root = nullptr;                // the context this one is a sibling of (nullptr: a root)
+	DpPool *dp_pool = nullptr;                // (root) slots + arguments of every lane, one block of device memory
+	std::mutex pool_mu;                       // (root) guards pool creation, slot numbers and the interval list
+	int pool_slots = 0;                       // (root) slots handed out
+	hipEvent_t pool_base = nullptr;           // (root) time zero of the worker launches' intervals
+	std::vector<std::pair<float, float>> pool_iv;   // (root) [start, end) of every finished worker launch of the device, ms since pool_base
+	// ... a slot, a generation counter, a word of pinned host memory and a worker stream belong to every context that runs DP rounds
+	int dp_slot = -1;
+	unsigned int dp_gen = 0;
+	int32_t *dp_done = nullptr;               // pinned: receives the generation of a round when its last unit has finished
+	hipStream_t worker_stream = nullptr;      // the lane's worker launches (never waited for by a round: its workers may be busy with other lanes' units)
+	hipEvent_t arm_ev = nullptr;
+	struct WorkerLaunch { hipEvent_t e0, e1; };
+	std::vector<WorkerLaunch> wl_busy, wl_free;   // event pairs of worker launches not yet harvested / free for reuse
+	DevBuf dp_trace;                          // (MPA_DP_TRACE) per-unit start/end ticks of the current round
 };
 
 namespace mpa {
@@ -199,8 +216,10 @@ static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 {
-	if (mi->dev && mi->dev->device == ctx->device) return MPA_OK;
-	if (mi->dev) dev_free_index(mi);
+	if (ctx->device < 0 || ctx->device >= mpa_idx_s::kMaxDevices) { set_error("device number beyond what an index keeps copies for"); return MPA_ERR_UNSUPPORTED; }
+	static std::mutex mu;                                     // (the pipelines of several devices may get here together)
+	std::lock_guard<std::mutex> g(mu);
+	if (mi->dev[ctx->device]) return MPA_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
 	DeviceIndex *d = new DeviceIndex();
 	d->device = ctx->device;
@@ -219,22 +238,25 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 		HIP_TRY(hipMalloc((void**)&d->spsc, mi->spsc.size() + 16));
 		HIP_TRY(hipMemcpy(d->spsc, mi->spsc.data(), mi->spsc.size(), hipMemcpyHostToDevice));
 	}
-	mi->dev = d;
+	d->seq_bytes = mi->seq.size() + 16, d->spsc_bytes = mi->spsc.empty() ? 0 : mi->spsc.size() + 16;   // (what was added is what dev_free_index takes off again)
+	mi->dev[ctx->device] = d;
 	undo.d = nullptr;
-	g_dev_bytes += (long long)(mi->seq.size() + mi->spsc.size());
+	g_dev_bytes += (long long)(d->seq_bytes + d->spsc_bytes);
 	return MPA_OK;
 }
 
 void dev_free_index(mpa_idx_s *mi)
 {
-	if (!mi->dev) return;
-	(void)hipSetDevice(mi->dev->device);
-	(void)hipFree(mi->dev->seq); (void)hipFree(mi->dev->ctg_off); (void)hipFree(mi->dev->ctg_len);
-	g_dev_bytes -= (long long)(mi->seq.size() + mi->spsc.size());
-	if (mi->dev->kb) { (void)hipFree(mi->dev->kb); g_dev_bytes -= (long long)mi->dev->kb_bytes; }
-	if (mi->dev->spsc) (void)hipFree(mi->dev->spsc);
-	delete mi->dev;
-	mi->dev = nullptr;
+	for (DeviceIndex *&d : mi->dev) {
+		if (!d) continue;
+		(void)hipSetDevice(d->device);
+		(void)hipFree(d->seq); (void)hipFree(d->ctg_off); (void)hipFree(d->ctg_len);
+		g_dev_bytes -= (long long)(d->seq_bytes + d->spsc_bytes);
+		if (d->kb) { (void)hipFree(d->kb); g_dev_bytes -= (long long)d->kb_bytes; }
+		if (d->spsc) (void)hipFree(d->spsc);
+		delete d;
+		d = nullptr;
+	}
 }
 
 // ns_log2 (nasw-sse.c:330-338) and the extension-length penalty of nasw-sse.c:426 tabulated as a step
@@ -358,6 +380,13 @@ void mpa_ctx_destroy(mpa_ctx_t *ctx)
 	ctx->siblings.clear();
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->worker_stream) { (void)hipStreamSynchronize(ctx->worker_stream); (void)hipStreamDestroy(ctx->worker_stream); }   // (workers exit by themselves once no slot has a unit left)
+	for (auto *v : { &ctx->wl_busy, &ctx->wl_free }) { for (auto &w : *v) { (void)hipEventDestroy(w.e0); (void)hipEventDestroy(w.e1); } v->clear(); }
+	if (ctx->arm_ev) (void)hipEventDestroy(ctx->arm_ev);
+	if (ctx->dp_done) (void)hipHostFree(ctx->dp_done);
+	if (ctx->pool_base) (void)hipEventDestroy(ctx->pool_base);
+	if (ctx->dp_pool) (void)hipFree(ctx->dp_pool);
+	ctx->dp_trace.release();
 	SeedBufs &B = ctx->seed;
 	ctx_each_devbuf(ctx, [](DevBuf &b, int) { b.release(); });
 	for (HostPinned *h : { &B.h_jobs, &B.h_rhits, &B.hc_a, &B.hc_f, &B.hc_pred, &B.h_meta, &B.h_back, &B.h_xoff, &ctx->h_up, &ctx->h_down, &ctx->h_pool }) h->release();
@@ -395,6 +424,7 @@ mpa_ctx_t *ctx_sibling(mpa_ctx_t *ctx, int k)
 		mpa_ctx_t *sb = mpa_ctx_create(ctx->device);
 		if (!sb) return nullptr;
 		sb->tb_budget = ctx->tb_budget;
+		sb->root = ctx;
 		ctx->siblings.push_back(sb);
 	}
 	return ctx->siblings[k - 1];
@@ -416,9 +446,12 @@ SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k)
 	return ctx->holds[(size_t)k];
 }
 
+void pool_harvest(mpa_ctx_t *ctx, bool wait);
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
+	pool_harvest(ctx, true);
 	for (mpa_ctx_s *sb : ctx->siblings) {
+		pool_harvest(sb, true);
 		mpa_dp_stats_t &t = ctx->total, &u = sb->total;
 		t.n_ext += u.n_ext, t.n_glob += u.n_glob, t.cells_ext += u.cells_ext, t.cells_glob += u.cells_glob, t.rows_prep += u.rows_prep;
 		t.alg_bytes_ext += u.alg_bytes_ext, t.alg_bytes_glob += u.alg_bytes_glob;
@@ -734,7 +767,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	if (pre.bbit <= 0) { set_error("GPU pre-chain needs block anchors (bbit > 0)"); return MPA_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(ctx->device));
 	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
-	DeviceIndex *d = mi->dev;
+	DeviceIndex *d = mi->dev[ctx->device];
 	if (!d->kb) {
 		static std::mutex mu;
 		std::lock_guard<std::mutex> g(mu);
@@ -802,7 +835,7 @@ int dev_index_build(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	    io.min_aa_len > 1000) { set_error("index build: parameters outside the device kernel's range"); return MPA_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(ctx->device));
 	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
-	DeviceIndex *d = mi->dev;
+	DeviceIndex *d = mi->dev[ctx->device];
 	hipStream_t s = ctx->stream;
 	std::vector<int64_t> chunk_first((size_t)n_strand + 1, 0);
 	for (int32_t j = 0; j < n_strand; ++j) chunk_first[j + 1] = chunk_first[j] + (mi->ctg[j >> 1].len + REFINE_CHUNK - 1) / REFINE_CHUNK;
@@ -1018,7 +1051,7 @@ int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_
 	HIP_TRY(hipMemsetAsync(B.r_count.p, 0, 16, s));
 	RefineTab rt;
 	for (int c = 0; c < 64; ++c) rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
-	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, nullptr, mi->l_seq };
+	DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, nullptr, mi->l_seq };
 	const size_t lds = ((size_t)4 << hs_log2) + REFINE_CHUNK + 2 * REFINE_HALO;
 	const char *dm = B.r_win.as<char>();
 	hipLaunchKernelGGL(k_refine_scan, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk),
@@ -1116,7 +1149,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	HIP_TRY(hipMemsetAsync(B.rx_all.p, 0, zero_bytes, s));
 	RefineTab rt;
 	for (int c = 0; c < 64; ++c) rt.t[c] = tab_codon()[c] >= 20 ? 0xff : tab_codon13()[c];
-	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, nullptr, mi->l_seq };
+	DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, nullptr, mi->l_seq };
 	const char *dm = B.r_win.as<char>();
 	RefineGroups gr{ (const int64_t*)(dm + o_qg), (const uint32_t*)(dm + o_gw), (const uint32_t*)(dm + o_gf), (const uint32_t*)(dm + o_gc), (const uint32_t*)(dm + o_qp) };
 	const int64_t *d_wg = (const int64_t*)(dm + o_wg);
@@ -1235,10 +1268,105 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 
 extern "C" {
 
+} // extern "C" (reopened below)
+
+namespace mpa {
+// ---- DP worker pool: host side (the kernels and the protocol are in dp_kernels.hip, "The DP worker pool")
+static bool dp_pool_enabled()
+{
+	static const bool on = [] { const char *e = getenv("MPA_DP_POOL"); return !e || atoi(e) != 0; }();
+	return on;
+}
+// resident worker workgroups the pool admits (MPA_DP_WORKERS).  The workers ask for a fifth of a CU's LDS plus a little, so four
+// fit per CU (1 024 on the chip); the default keeps three per CU busy and leaves the fourth slot to the workgroups that arrive,
+// find the pool full and leave -- and registers and LDS to the seeding kernels of the batches behind.
+static int dp_pool_budget()
+{
+	static const int b = [] { const char *e = getenv("MPA_DP_WORKERS"); const int v = e ? atoi(e) : 768; return v < 1 ? 1 : v; }();
+	return b;
+}
+// MPA_DP_TRACE=<file>: every unit of every round appends "slot generation unit kind priority start end" (100-MHz device ticks);
+// tools/dp_trace.py turns that into resident units over time
+static const char *dp_trace_path()
+{
+	static const char *p = [] { const char *e = getenv("MPA_DP_TRACE"); return e && *e ? e : (const char*)nullptr; }();
+	return p;
+}
+// the calling context's slot, done word and worker stream (created on its first round); the device's pool on the first of all
+static int pool_attach(mpa_ctx_t *ctx)
+{
+	mpa_ctx_s *root = ctx->root ? ctx->root : ctx;
+	std::lock_guard<std::mutex> g(root->pool_mu);
+	if (!root->dp_pool) {
+		DpPool *p = nullptr;
+		HIP_TRY(hipMalloc((void**)&p, sizeof(DpPool)));
+		HIP_TRY(hipMemset(p, 0, sizeof(DpPool)));
+		const int32_t budget = dp_pool_budget();
+		HIP_TRY(hipMemcpy(&p->ctl.budget, &budget, 4, hipMemcpyHostToDevice));
+		const int32_t acq = [] { const char *e = getenv("MPA_DP_ACQUIRE"); return e ? atoi(e) : 2; }();
+		HIP_TRY(hipMemcpy(&p->ctl.acquire_mode, &acq, 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipEventCreate(&root->pool_base));
+		HIP_TRY(hipEventRecord(root->pool_base, root->stream));
+		root->dp_pool = p;
+	}
+	if (ctx->dp_slot < 0) {
+		if (root->pool_slots >= MPA_DP_SLOTS) { set_error("more than " + std::to_string(MPA_DP_SLOTS) + " contexts of one device run DP rounds"); return MPA_ERR_UNSUPPORTED; }
+		HIP_TRY(hipHostMalloc((void**)&ctx->dp_done, 64, hipHostMallocDefault));
+		*(volatile int32_t*)ctx->dp_done = 0;
+		HIP_TRY(hipStreamCreateWithFlags(&ctx->worker_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&ctx->arm_ev, hipEventDisableTiming));
+		ctx->dp_slot = root->pool_slots++;
+	}
+	return MPA_OK;
+}
+// durations of the context's worker launches that have ended (wait: of all of them -- only when no round is pending anywhere, the
+// workers then leave within microseconds) into the context's totals and the device's interval list
+void pool_harvest(mpa_ctx_t *ctx, bool wait)
+{
+	if (ctx->wl_busy.empty()) return;
+	mpa_ctx_s *root = ctx->root ? ctx->root : ctx;
+	(void)hipSetDevice(ctx->device);
+	if (wait) (void)wait_stream(ctx, ctx->worker_stream);
+	size_t keep = 0;
+	for (size_t k = 0; k < ctx->wl_busy.size(); ++k) {
+		mpa_ctx_s::WorkerLaunch w = ctx->wl_busy[k];
+		float a = 0, b = 0;
+		if (hipEventQuery(w.e1) == hipSuccess && hipEventElapsedTime(&a, root->pool_base, w.e0) == hipSuccess && hipEventElapsedTime(&b, root->pool_base, w.e1) == hipSuccess) {
+			ctx->total.ms_round += (double)(b - a), ctx->total.launches_round++;
+			{ std::lock_guard<std::mutex> g(root->pool_mu); root->pool_iv.emplace_back(a, b); }
+			ctx->wl_free.push_back(w);
+		} else ctx->wl_busy[keep++] = w;
+	}
+	(void)hipGetLastError();
+	ctx->wl_busy.resize(keep);
+}
+// time during which at least one worker launch of the device was running
+static double pool_union_ms(mpa_ctx_s *root, bool reset)
+{
+	std::lock_guard<std::mutex> g(root->pool_mu);
+	std::vector<std::pair<float, float>> iv = root->pool_iv;
+	if (reset) root->pool_iv.clear();
+	std::sort(iv.begin(), iv.end());
+	double sum = 0, lo = 0, hi = -1;
+	for (auto &x : iv) {
+		if (hi < 0) { lo = x.first, hi = x.second; continue; }
+		if (x.first <= hi) { hi = std::max<double>(hi, x.second); continue; }
+		sum += hi - lo, lo = x.first, hi = x.second;
+	}
+	if (hi >= 0) sum += hi - lo;
+	return sum;
+}
+} // namespace mpa
+
+extern "C" {
+
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st) { *st = ctx->stats; }
 void mpa_dp_total_stats(mpa_ctx_t *ctx, mpa_dp_stats_t *st, int reset)
 {
-	if (st) *st = ctx->total;
+	pool_harvest(ctx, true);
+	mpa_ctx_s *root = ctx->root ? ctx->root : ctx;
+	const double u = pool_union_ms(root, reset != 0);
+	if (st) *st = ctx->total, st->ms_round_union = u;
 	if (reset) ctx->total = mpa_dp_stats_t();
 }
 
@@ -1249,7 +1377,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	if (cigar_pool) *cigar_pool = nullptr;
 	if (n_pool) *n_pool = 0;
 	if (!ctx) { set_error("no device context"); return MPA_ERR_NO_DEVICE; }
-	if (!mi->dev || mi->dev->device != ctx->device) { set_error("index is not resident on this context's device (call mpa_idx_to_device)"); return MPA_ERR_ARG; }
+	if (ctx->device >= mpa_idx_s::kMaxDevices || !mi->dev[ctx->device]) { set_error("index is not resident on this context's device (call mpa_idx_to_device)"); return MPA_ERR_ARG; }
 	ctx->stats = mpa_dp_stats_t();
 	if (n <= 0) return MPA_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1405,7 +1533,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	             up_waves = up_q + al256((size_t)q_bytes), up_list = up_waves + al256(sizeof(ExtWave) * ewaves.size()),
 	             up_gw = up_list + al256(4 * glob_ids.size()), up_units = up_gw + al256(sizeof(GlobWave) * (glob_ids.size() + 8)),
 	             up_off = up_units + al256(sizeof(DpUnit) * (4 * ewaves.size() + glob_ids.size() + 64)),
-	             up_ids = up_off + al256(8 * glob_ids.size()), up_end = up_ids + al256(4 * glob_ids.size());
+	             up_ids = up_off + al256(8 * glob_ids.size()), up_args = up_ids + al256(4 * glob_ids.size()), up_end = up_args + al256(sizeof(DpRoundArgs));
 	if ((rc = ctx->h_up.ensure(up_end + 256))) return rc;
 	char *hup = ctx->h_up.as<char>();
 	memcpy(hup + up_tasks, T.data(), sizeof(DTask) * n);
@@ -1453,7 +1581,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
 	for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
 	dc.sp_null_bonus = opt->sp_null_bonus;
-	DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, mi->dev->spsc, mi->l_seq };
+	DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, mi->dev[ctx->device]->spsc, mi->l_seq };
 
 	// ---- K3: per-row records and profiles
 	// (measured, round 4: putting these two on a high-priority stream of their own gives every DP lane a second active hardware
@@ -1502,6 +1630,11 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	ga.tb = ctx->tb.as<uint16_t>(), ga.bnd = ctx->bnd.as<int4>(), ga.score = ctx->score.as<int32_t>(), ga.c = dc, ga.rowkey64 = nullptr, ga.waves = nullptr;
 	hipEvent_t ev_round0 = ctx->lev[2 * (mpa_ctx_s::kSide - 1)], ev_round1 = ctx->lev[2 * (mpa_ctx_s::kSide - 1) + 1];
 	bool round_launched = false;
+	const bool use_pool = dp_pool_enabled();
+	bool round_pending = false;                              // (worker pool) a round is armed and not yet known to be complete
+	unsigned int round_gen = 0;
+	size_t round_units = 0;
+	const DpUnit *round_unit_list = nullptr;
 	// units of the round: the extension waves/groups of every class, plus (gw_first/gw_cnt != nullptr) the traceback waves of
 	// the first traceback chunk; longest first
 	auto launch_round = [&](const int *gw_first, const int *gw_cnt, const std::vector<GlobWave> *gwv, GlobWave *d_gw) -> int {
@@ -1513,7 +1646,10 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		for (int cls = 0; cls < 3; ++cls)
 			for (int k = 0; k < ewave_cnt[cls] && !(cls == 1 && ctx->antidiag); k += 4)
 				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(4, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
-		for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
+		// (worker pool: a workgroup goes on to its next unit, so all four waves must leave a unit through the same barriers -- a
+		// 65..128-column group then takes a whole workgroup on the four-wave body, its waves 2 and 3 on dead columns)
+		if (use_pool) for (int k = 0; k < ewave_cnt[3]; ++k) add(U_EXT_W4, ewave_first[3] + k, 1, (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
+		else for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
 		for (int k = 0; k < ewave_cnt[4]; ++k) add(U_EXT_W4, ewave_first[4] + k, 1, (int64_t)ewaves[ewave_first[4] + k].max_nl * 370);
 		for (int k = 0; k < ewave_cnt[6]; ++k)
 			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
@@ -1523,12 +1659,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			static const int kind_of[8] = { U_GLOB16, U_GLOB32, U_GLOB64, U_GLOB_W2, U_GLOB_W4, -1, -1, U_GLOB_MB };
 			for (int cls = 0; cls < 8; ++cls) {
 				if (kind_of[cls] < 0) continue;
-				const int per = cls == 3 ? 2 : cls == 4 ? 1 : 4;
+				const int per = cls == 3 ? (use_pool ? 1 : 2) : cls == 4 ? 1 : 4;
 				for (int k = 0; k < gw_cnt[cls]; k += per) {
 					const GlobWave &g = (*gwv)[gw_first[cls] + k];
 					int64_t cost = (int64_t)g.max_nl * (cls >= 3 && cls <= 4 ? 510 : 430);
 					if (cls == 7) cost *= (T[g.task[0]].ncol + 63) / 64;
-					add(kind_of[cls], gw_first[cls] + k, std::min(per, gw_cnt[cls] - k), cost);
+					add(cls == 3 && use_pool ? (int)U_GLOB_W4 : kind_of[cls], gw_first[cls] + k, std::min(per, gw_cnt[cls] - k), cost);
 				}
 			}
 		}
@@ -1558,13 +1694,85 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			const size_t pad = (((size_t)160 * 1024 / 5) + 256) & ~(size_t)255;
 			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
 		}();
-		if (round_lds > 48 * 1024) HIP_TRY(ensure_dynamic_lds((const void*)k_dp_round, ctx->device, round_lds));
-		HIP_TRY(hipEventRecord(ev_round0, s));
-		hipLaunchKernelGGL(k_dp_round, dim3((unsigned)n_units), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipEventRecord(ev_round1, s));
+		if (use_pool) {
+			// the round's arguments and units into the lane's slot of the device's pool, the slot armed in stream order behind
+			// everything the round reads, the lane's workers on the worker stream (a worker takes any lane's units: this stream is
+			// never waited for by a round -- a round is complete when its last unit says so in pinned memory)
+			if ((rc2 = pool_attach(ctx))) return rc2;
+			mpa_ctx_s *root = ctx->root ? ctx->root : ctx;
+			DpPool *pool = root->dp_pool;
+			int n_slots;
+			{ std::lock_guard<std::mutex> g(root->pool_mu); n_slots = root->pool_slots; }
+			DpRoundArgs *ha = (DpRoundArgs*)(hup + up_args);
+			ha->ea = ea, ha->wa = wa, ha->ga = ga, ha->units = ctx->units.as<DpUnit>();
+			HIP_TRY(hipMemcpyAsync(&pool->args[ctx->dp_slot], ha, sizeof(DpRoundArgs), hipMemcpyHostToDevice, s));
+			long long *d_trace = nullptr;
+			if (dp_trace_path()) {
+				if ((rc2 = ctx->dp_trace.ensure(n_units * 16))) return rc2;
+				HIP_TRY(hipMemsetAsync(ctx->dp_trace.p, 0, n_units * 16, s));
+				d_trace = ctx->dp_trace.as<long long>();
+			}
+			round_gen = ++ctx->dp_gen;
+			hipLaunchKernelGGL(k_dp_arm, dim3(1), dim3(1), 0, s, pool, ctx->dp_slot, (int)n_units, round_gen, ctx->dp_done, d_trace);
+			HIP_TRY(hipGetLastError());
+			// MPA_DP_WORKER_STREAM=0: the workers on the lane's own stream (what follows the round on that stream then also waits for
+			// this launch's workers to run out of units of ANY lane)
+			static const bool own_stream = [] { const char *e = getenv("MPA_DP_WORKER_STREAM"); return !e || atoi(e) != 0; }();
+			hipStream_t ws = own_stream ? ctx->worker_stream : s;
+			if (own_stream) {
+				HIP_TRY(hipEventRecord(ctx->arm_ev, s));
+				HIP_TRY(hipStreamWaitEvent(ws, ctx->arm_ev, 0));
+			}
+			mpa_ctx_s::WorkerLaunch wl;
+			if (!ctx->wl_free.empty()) wl = ctx->wl_free.back(), ctx->wl_free.pop_back();
+			else { HIP_TRY(hipEventCreate(&wl.e0)); HIP_TRY(hipEventCreate(&wl.e1)); }
+			HIP_TRY(ensure_dynamic_lds((const void*)k_dp_worker, ctx->device, round_lds));
+			static const int launch_cap = [] { const char *e = getenv("MPA_DP_LAUNCH_WORKERS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : dp_pool_budget(); }();
+			const unsigned grid = (unsigned)std::min<size_t>(n_units, (size_t)launch_cap);
+			HIP_TRY(hipEventRecord(wl.e0, ws));
+			hipLaunchKernelGGL(k_dp_worker, dim3(grid), dim3(256), round_lds, ws, pool, ctx->dp_slot, n_slots);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipEventRecord(wl.e1, ws));
+			ctx->wl_busy.push_back(wl);
+			round_pending = true, round_units = n_units, round_unit_list = units;
+		} else {
+			if (round_lds > 48 * 1024) HIP_TRY(ensure_dynamic_lds((const void*)k_dp_round, ctx->device, round_lds));
+			HIP_TRY(hipEventRecord(ev_round0, s));
+			hipLaunchKernelGGL(k_dp_round, dim3((unsigned)n_units), dim3(256), round_lds, s, ea, wa, ga, ctx->units.as<DpUnit>());
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipEventRecord(ev_round1, s));
+		}
 		round_launched = true;
 		ctx->stats.launches_ext++;
+		return MPA_OK;
+	};
+	// worker pool: the round is complete when the last of its units has stored the round's generation into the lane's pinned word
+	auto wait_round = [&]() -> int {
+		if (!round_pending) return MPA_OK;
+		volatile int32_t *d = ctx->dp_done;
+		const double t0 = now_ms();
+		for (int polls = 0; (unsigned int)*d != round_gen; ++polls) {
+			if (polls >= 8) { struct timespec ts = { 0, 100000L }; nanosleep(&ts, nullptr); }
+			if ((polls & 1023) == 1023) {
+				if (now_ms() - t0 > 120000.0) { set_error("DP worker pool: a round did not complete within two minutes"); return MPA_ERR_HIP; }
+				const hipError_t e = hipStreamQuery(ctx->worker_stream);           // (a fault in a worker kernel shows up here, not in the word)
+				if (e != hipSuccess && e != hipErrorNotReady) { set_error(std::string("DP worker launch: ") + hipGetErrorString(e)); return MPA_ERR_HIP; }
+			}
+		}
+		round_pending = false;
+		hipLaunchKernelGGL(k_l2_writeback, dim3(128), dim3(64), 0, s);       // the units' results out of the L2s, before anything enqueued behind reads them
+		HIP_TRY(hipGetLastError());
+		if (const char *path = dp_trace_path()) {                             // (debug) one line per unit: who ran when
+			std::vector<long long> tr(2 * round_units);
+			HIP_TRY(hipMemcpy(tr.data(), ctx->dp_trace.p, round_units * 16, hipMemcpyDeviceToHost));
+			static std::mutex tmu;
+			std::lock_guard<std::mutex> g(tmu);
+			if (FILE *f = fopen(path, "a")) {
+				for (size_t k = 0; k < round_units; ++k)
+					fprintf(f, "%d\t%u\t%zu\t%d\t%d\t%lld\t%lld\n", ctx->dp_slot, round_gen, k, round_unit_list[k].kind, round_unit_list[k].pad_, tr[2 * k], tr[2 * k + 1]);
+				fclose(f);
+			}
+		}
 		return MPA_OK;
 	};
 	if (ctx->antidiag && ewave_cnt[1] > 0) {                           // (measurement) the 32-column class on the anti-diagonal prototype, one wave per block
@@ -1650,11 +1858,6 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
 		const size_t first_glob_launch = launches.size();
 		const bool in_round = ri == 0;                       // the first chunk's calls ride in the round's one launch
-		if (in_round) {
-			if ((rc = launch_round(first, cnt, &gwaves, d_gw)) != MPA_OK) return rc;
-			ctx->stats.launches_glob++;
-			mark("    dp: units up, round launched");
-		}
 		const int order[5] = { 6, 5, 4, 3, -1 };
 		for (int oi = 0; oi < 5; ++oi) {
 			const int cls = order[oi];
@@ -1669,6 +1872,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			}
 			ctx->stats.launches_glob++;
 		}
+		if (in_round) {                                        // (behind the 512/1024-thread classes' own launches: with the worker pool the host waits here)
+			if ((rc = launch_round(first, cnt, &gwaves, d_gw)) != MPA_OK) return rc;
+			ctx->stats.launches_glob++;
+			mark("    dp: units up, round launched");
+			if ((rc = wait_round()) != MPA_OK) return rc;
+			if (use_pool) mark("    dp: round (units done)");
+		}
 		for (size_t k = first_glob_launch; k < launches.size(); ++k) (void)hipStreamWaitEvent(s, ctx->lev[2 * launches[k].side + 1], 0);
 		HIP_TRY(hipEventRecord(ctx->ev[4], s));
 		hipLaunchKernelGGL(k_backtrack, dim3((unsigned)glist.size()), dim3(64), 0, s, ctx->tasks.as<DTask>(), d_list, (int32_t)glist.size(),
@@ -1677,8 +1887,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		HIP_TRY(hipEventRecord(ctx->ev[5], s));
 		glob_timed = true;                                                // (ev[3..5] are read after the next wait)
 	}
-	if (!round_launched) { if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc; }
-	mark("    dp: (round without traceback launched)");
+	if (!round_launched) {
+		if ((rc = launch_round(nullptr, nullptr, nullptr, nullptr)) != MPA_OK) return rc;
+		mark("    dp: (round without traceback launched)");
+		if ((rc = wait_round()) != MPA_OK) return rc;
+		if (use_pool) mark("    dp: round (units done)");
+	}
 	// ---- join
 	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
 	HIP_TRY(hipEventRecord(ctx->ev[2], s));
@@ -1703,10 +1917,11 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		ms_glob += a, ms_bt += b;
 	}
 	float ms_ext_sum = 0;                                                 // sum of the per-launch durations of the extension kernels
-	if (round_launched) {
+	if (round_launched && !use_pool) {
 		(void)hipEventElapsedTime(&ms_ext_sum, ev_round0, ev_round1);
 		ctx->stats.ms_round = ms_ext_sum, ctx->stats.launches_round = 1;
 	}
+	if (use_pool) pool_harvest(ctx, false);                             // (worker launches that have ended: into the context's totals)
 	for (auto &l : launches) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ctx->lev[2 * l.side], ctx->lev[2 * l.side + 1]);

@@ -1412,18 +1412,15 @@ __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 constexpr size_t dp_round_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t DP_ROUND_LDS = dp_round_max(dp_round_max(dp_round_max(4 * EXT_NARROW_LDS, 2 * EXT_WIDE_LDS(2)), dp_round_max(EXT_WIDE_LDS(4), 4 * GLOB_NARROW_LDS)),
                                              dp_round_max(2 * GLOB_WIDE_LDS(2), GLOB_WIDE_LDS(4)));   // 30 400 bytes: five workgroups per CU
-__global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
+// one DpUnit on the four waves of a 256-thread workgroup (lds: the workgroup's DP_ROUND_LDS bytes)
+__device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, const ExtWideArgs &wa, const GlobArgs &ga, char *lds, const int tid)
 {
-	extern __shared__ uint32_t lds_raw[];
-	char *lds = (char*)lds_raw;
-	const DpUnit u = units[blockIdx.x];
-	const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const WavePos one{ lds, lane, 0, lane };                      // a one-wave unit: its LDS region is set per case
+	const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	switch (u.pad_) {                                             // issue priority by expected duration (dp_exec.hip, launch_round)
 	case 3: __builtin_amdgcn_s_setprio(3); break;
 	case 2: __builtin_amdgcn_s_setprio(2); break;
 	case 1: __builtin_amdgcn_s_setprio(1); break;
-	default: break;
+	default: __builtin_amdgcn_s_setprio(0); break;
 	}
 	switch (u.kind) {
 	case U_EXT16: if (wv < u.count) ext_narrow<16>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
@@ -1433,8 +1430,8 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 		const int g = wv >> 1, w = wv & 1;
 		if (g < u.count) ext_wide_body<2, false>(wa, u.first + g, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds + g * EXT_WIDE_LDS(2), lane, w, w * 64 + lane });
 	} break;
-	case U_EXT_W4: ext_wide_body<4, false>(wa, u.first, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
-	case U_EXT_SPLIT: ext_wide_body<4, true>(wa, u.first, SplitPos{ u.sgroup, u.blk, u.n_blk, u.xg_first }, WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
+	case U_EXT_W4: ext_wide_body<4, false>(wa, u.first, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds, lane, wv, tid }); break;
+	case U_EXT_SPLIT: ext_wide_body<4, true>(wa, u.first, SplitPos{ u.sgroup, u.blk, u.n_blk, u.xg_first }, WavePos{ lds, lane, wv, tid }); break;
 	case U_GLOB16: if (wv < u.count) glob_narrow<16, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
 	case U_GLOB32: if (wv < u.count) glob_narrow<32, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
 	case U_GLOB64: if (wv < u.count) glob_narrow<64, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
@@ -1443,10 +1440,164 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 		const int g = wv >> 1, w = wv & 1;
 		if (g < u.count) glob_wide_body<2>(ga, ga.waves[u.first + g], WavePos{ lds + g * GLOB_WIDE_LDS(2), lane, w, w * 64 + lane });
 	} break;
-	case U_GLOB_W4: glob_wide_body<4>(ga, ga.waves[u.first], WavePos{ lds, lane, wv, (int)threadIdx.x }); break;
+	case U_GLOB_W4: glob_wide_body<4>(ga, ga.waves[u.first], WavePos{ lds, lane, wv, tid }); break;
 	default: break;
 	}
-	(void)one;
+}
+
+// (MPA_DP_POOL=0: one launch per round, one workgroup per unit, the hardware's in-order dispatcher as the task queue)
+__global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
+{
+	extern __shared__ uint32_t lds_raw[];
+	const DpUnit u = units[blockIdx.x];
+	dp_run_unit(u, ea, wa, ga, (char*)lds_raw, (int)threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The DP worker pool (the default): the units of ALL batches in their DP rounds on a device are served by one bounded
+// population of worker workgroups instead of one launch per round.
+//
+// Why.  A round's units are a few thousand short ones and a handful that sweep 100 000 - 190 000 rows (25 - 50 ms at one row per
+// ~255 ns).  As one launch per round, a round occupies every workgroup slot the LDS allows for its first milliseconds and then
+// idles the chip behind its stragglers; several batches in flight take turns at flooding the CUs (round 4: 20 000 waves per
+// launch, 114 GCUPS per launch against 924 GCUPS for the same kernel on a full machine; every kernel next to a starting round
+// stretched 2-6 x).  With the pool the number of resident DP workgroups is bounded and steady, a straggler of batch k runs
+// under the bulk of batches k+1.., and a lane's workers that run out of their own round's units take another lane's.
+//
+// How.  Every DP lane owns a slot of the device's DpPool: its round's arguments and unit list (longest unit first).  The
+// lane arms the slot (k_dp_arm, in stream order behind the round's uploads and prep kernels) and launches workers on a stream
+// of its own; a worker takes units from its home slot first, then from the other slots, and EXITS when no slot has a unit
+// left -- no workgroup ever waits for the host, so nothing can hang on a host that is slow, blocked in hipFree, or gone.
+// Admission: a worker beyond the pool's budget of resident workers leaves at once (the first 64 workgroups of a launch are
+// always admitted: every round brings workers of its own, whatever the others do).  A round is complete when its `remaining`
+// counter reaches zero -- the lane polls a word of pinned host memory -- not when any particular launch ends.
+// Visibility: a worker that switches to another (slot, generation) does an agent-scope acquire before it reads the round's
+// inputs (written by kernels and copies that finished before the slot was armed, possibly while this worker was already
+// running: its CU's L1 and its XCD's L2 may hold lines of the round before); a unit's results are written back from the L2s by
+// k_l2_writeback, which the lane launches behind the completed round, before anything reads them.
+// ------------------------------------------------------------------------------------------------
+struct DpRoundArgs { ExtArgs ea; ExtWideArgs wa; GlobArgs ga; const DpUnit *units; };
+struct DpPool { DpPoolCtl ctl; DpSlotCtl slot[MPA_DP_SLOTS]; DpRoundArgs args[MPA_DP_SLOTS]; };
+#define MPA_DP_ALWAYS_ADMITTED 64
+
+__device__ __forceinline__ unsigned long long ld_u64_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// arms slot `s` for a round of n units (generation gen); single thread, stream-ordered behind everything the round reads
+__global__ void k_dp_arm(DpPool *pool, int s, int n, unsigned int gen, int32_t *done, long long *trace)
+{
+	DpSlotCtl &c = pool->slot[s];
+	__hip_atomic_store(&c.remaining, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.stamp, atomicAdd(&pool->ctl.arm_seq, 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	c.done = done, c.trace = trace;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	__hip_atomic_store(&c.lim, (unsigned long long)gen << 32 | (unsigned int)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	__hip_atomic_store(&c.head, (unsigned long long)gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Writes the dirty lines of every XCD's L2 back to memory: the results of a round's units, wherever their workers ran.  Launched by
+// the lane behind a completed round, 16 workgroups per XCD (workgroup b runs on XCD b % 8; any one per XCD would do).
+__global__ __launch_bounds__(64) void k_l2_writeback()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dp_worker(DpPool *pool, const int home, const int n_slots)
+{
+	extern __shared__ uint32_t lds_raw[];
+	__shared__ int32_t pick[4];                                   // slot, unit, generation (thread 0 -> the workgroup)
+	char *lds = (char*)lds_raw;
+	int tid = (int)threadIdx.x;                                   // (made opaque once per unit, see below)
+	if (tid == 0) {
+		int ok = 1;
+		if (blockIdx.x >= MPA_DP_ALWAYS_ADMITTED) {
+			const int a = atomicAdd(&pool->ctl.alive, 1);
+			if (a >= __hip_atomic_load(&pool->ctl.budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicSub(&pool->ctl.alive, 1), ok = 0;
+		} else atomicAdd(&pool->ctl.alive, 1);
+		pick[3] = ok;
+	}
+	__syncthreads();
+	if (!pick[3]) return;
+	int seen_slot = -1;                                           // the (slot, generation) whose inputs this workgroup has acquired
+	unsigned int seen_gen = 0;
+	int seen_seq = 0;                                             // every round armed up to this sequence number was armed before this workgroup's last acquire
+	const int acquire_mode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->ctl.acquire_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	for (;;) {
+		// (the thread index is made opaque per unit: otherwise every lane-dependent constant of every body -- column masks, group
+		// indices, profile addresses of twelve instantiations -- is hoisted out of this loop and stays live across it: 204 VGPRs)
+		asm volatile("" : "+v"(tid));
+		if (tid == 0) {
+			int got = -1, unit = 0;
+			unsigned int gen = 0;
+			for (int k = 0; k < n_slots && got < 0; ++k) {
+				const int s = home + k < n_slots ? home + k : home + k - n_slots;
+				DpSlotCtl &c = pool->slot[s];
+				for (;;) {
+					// look first (plain atomic loads: an empty slot costs its scanners no read-modify-write), then take with ONE fetch-add --
+					// never a compare-and-swap loop: with several hundred workgroups at one head word every failed attempt is another
+					// round trip to the L2 (measured: a launch of 1 024 workers on 1 024 units took 8.4 ms against 2.3 ms)
+					const unsigned long long h = ld_u64_agent(&c.head), l = ld_u64_agent(&c.lim);
+					if ((h >> 32) != (l >> 32) || (unsigned int)h >= (unsigned int)l) break;          // being armed, or no unit left
+					const unsigned long long h2 = __hip_atomic_fetch_add(&c.head, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long l2 = ld_u64_agent(&c.lim);
+					// (an index past the end is nobody's unit: the head is set afresh when the slot is armed again, and a head of a
+					// generation can only be seen once that generation's lim has been written)
+					if ((h2 >> 32) == (l2 >> 32) && (unsigned int)h2 < (unsigned int)l2) { got = s, unit = (int)(unsigned int)h2, gen = (unsigned int)(h2 >> 32); break; }
+				}
+			}
+			pick[0] = got, pick[1] = unit, pick[2] = (int32_t)gen;
+		}
+		__syncthreads();
+		const int s = pick[0], ui = pick[1];
+		const unsigned int gen = (unsigned int)pick[2];
+		if (s < 0) break;
+		// MPA_DP_ACQUIRE: 1 = acquire whenever the workgroup moves to another (slot, generation); 2 (default) = only when the round
+		// was armed after the workgroup's last acquire -- an acquire is not about a slot, it drops every stale line the CU's L1 and
+		// the XCD's L2 hold at that moment, and it is expensive for everybody: each one invalidates the XCD's L2 under the seeding
+		// kernels' feet (mode 1: up to one per unit while a lane's queue runs dry and its workers steal -- 14 M residues/s against
+		// 22 M); 0 = none (measurement only: relies on the kernel boundaries between a round's producers and its arming).
+		bool fresh = false;
+		if (acquire_mode == 1) fresh = s != seen_slot || gen != seen_gen;
+		else if (acquire_mode == 2) {
+			const int stamp = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->slot[s].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			fresh = stamp - seen_seq > 0;
+		}
+		if (fresh) {
+			const int now_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->ctl.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			seen_slot = s, seen_gen = gen, seen_seq = now_seq;
+		}
+		// The round's arguments are read through the CONSTANT address space: they do not change while the round is live, and scalar
+		// loads keep them out of the vector registers (as plain global loads behind the atomics above they cost 110 VGPRs: two
+		// workgroups per CU instead of four).  The scalar cache is not covered by the acquire: it is invalidated by hand.
+		if (fresh) __builtin_amdgcn_s_dcache_inv();
+		typedef const __attribute__((address_space(4))) DpRoundArgs *ConstArgs;
+		const DpRoundArgs &ra = *(const DpRoundArgs*)(ConstArgs)(uintptr_t)&pool->args[s];
+		DpUnit u;
+		{
+			const DpUnit *up = ra.units + ui;
+			u.kind = __builtin_amdgcn_readfirstlane(up->kind), u.first = __builtin_amdgcn_readfirstlane(up->first), u.count = __builtin_amdgcn_readfirstlane(up->count);
+			u.blk = __builtin_amdgcn_readfirstlane(up->blk), u.n_blk = __builtin_amdgcn_readfirstlane(up->n_blk), u.sgroup = __builtin_amdgcn_readfirstlane(up->sgroup);
+			u.xg_first = __builtin_amdgcn_readfirstlane(up->xg_first), u.pad_ = __builtin_amdgcn_readfirstlane(up->pad_);
+		}
+		long long *trace = pool->slot[s].trace;
+		const long long t0 = trace ? wall_clock64() : 0;               // (uniform: scalar registers)
+		dp_run_unit(u, ra.ea, ra.wa, ra.ga, lds, tid);
+		__builtin_amdgcn_s_setprio(0);
+		// The unit's results stay where the stores left them -- dirty lines of this XCD's L2: the round's consumers are kernels and
+		// copies the lane enqueues AFTER it has seen the round complete, behind k_l2_writeback (one L2 write-back per XCD and round).
+		// A release fence here, per wave and unit, is 40 000 whole-L2 write-backs per round: measured, it stretched every kernel on
+		// the chip (13 M residues/s against 22 M).  All that is needed is that the stores have left the CU before the unit counts.
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tid == 0) {
+			if (trace) trace[2 * ui] = t0, trace[2 * ui + 1] = wall_clock64();
+			DpSlotCtl &c = pool->slot[s];
+			if (__hip_atomic_fetch_add(&c.remaining, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+				__hip_atomic_store(c.done, (int32_t)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+	if (tid == 0) atomicSub(&pool->ctl.alive, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

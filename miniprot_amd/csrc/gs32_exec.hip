@@ -29,7 +29,7 @@ extern "C" int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt
 		if (cigar_pool) *cigar_pool = nullptr;
 		if (n_pool) *n_pool = 0;
 		if (!ctx) { set_error("no device context"); return MPA_ERR_NO_DEVICE; }
-		if (!mi->dev || mi->dev->device != ctx->device) { set_error("index is not resident on this context's device (call mpa_idx_to_device)"); return MPA_ERR_ARG; }
+		if (ctx->device >= mpa_idx_s::kMaxDevices || !mi->dev[ctx->device]) { set_error("index is not resident on this context's device (call mpa_idx_to_device)"); return MPA_ERR_ARG; }
 		if (n <= 0) return MPA_OK;
 		if (n > (1 << 20)) { set_error("mpa_dp_run32: at most 2^20 calls per batch"); return MPA_ERR_ARG; }
 		// the sweep's arithmetic wraps like the reference's _mm_add/_sub_epi32; these bounds keep everything far from wrapping
@@ -90,7 +90,7 @@ extern "C" int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt
 		dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
 		for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
 		dc.sp_null_bonus = opt->sp_null_bonus;
-		DevGenome dg{ mi->dev->seq, mi->dev->ctg_off, mi->dev->ctg_len, mi->dev->spsc, mi->l_seq };
+		DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, mi->dev[ctx->device]->spsc, mi->l_seq };
 		if (!chunks.empty())
 			hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, s, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
 		hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);

@@ -101,7 +101,7 @@ public:
 	// never destroyed: workers outlive main().  One pool per lane, so that the pipeline stages of mpa_map_batches()
 	// (seeding of the next batch / DP-round bookkeeping / flattening + formatting of the previous one) can each run
 	// their own parallel region at the same time.
-	static const int kPools = 24;
+	static const int kPools = 24 * 8;                   // 24 lanes per pipeline (mpa_map_batches), up to eight pipelines per process (mpa_map_batches_multi)
 	static WorkerPool &get(int lane) { static WorkerPool *p = new WorkerPool[kPools]; return p[lane % kPools]; }
 	void run(int n_threads, int64_t n, const std::function<void(int64_t)> &fn) {
 		if (n_threads <= 1 || n <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
@@ -1378,8 +1378,9 @@ static int run_batch_on(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t 
 // results / text / text_len are then in CLAIM order, order[j] says which batch slot j holds, *n_mapped how many there are.
 static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
                     const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len,
-                    mpa_claim_fn claim = nullptr, void *claim_user = nullptr, int32_t *n_mapped = nullptr, int32_t *order = nullptr)
+                    mpa_claim_fn claim = nullptr, void *claim_user = nullptr, int32_t *n_mapped = nullptr, int32_t *order = nullptr, int pipe = 0)
 {
+	const int lane0 = 24 * (pipe & 7);                    // worker-pool lanes of this pipeline (several pipelines of one process: one per device)
 	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
 	if (!ctx) { set_error("mpa_map_batches needs a device context: the DP has no CPU fallback"); return MPA_ERR_NO_DEVICE; }
 	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
@@ -1450,7 +1451,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// as a stage of its own, one or two batches ahead of the seeders, whose stage is then device work only -- it was the stage that
 	// bounded the stream (141 ms of wall per batch on two seeders, round 4).  It also claims the job's batches.
 	auto sketcher_body = [&]() { try {
-		tl_pool_lane = 20, tl_thread_div = 4;
+		tl_pool_lane = lane0 + 20, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "sketch: worker pool";
 		CpuSpan cs("sketch: stage thread");
 		for (;;) {
@@ -1487,7 +1488,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 		}
 	} catch (const std::exception &e) { fail(MPA_ERR_HIP, std::string("sketch stage: ") + e.what()); } };
 	auto seeder_body = [&](int sd) { try {
-		tl_pool_lane = 10 + sd, tl_thread_div = 4;
+		tl_pool_lane = lane0 + 10 + sd, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "seeding: worker pool";
 		CpuSpan cs("seeding: stage thread (waits for the device)");
 		for (;;) {
@@ -1516,7 +1517,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<std::thread> seeders;
 	for (int sd = 0; sd < n_seed; ++sd) seeders.emplace_back(seeder_body, sd);
 	auto planner_body = [&](int pl) { try {
-		tl_pool_lane = 14 + pl, tl_thread_div = n_plan;
+		tl_pool_lane = lane0 + 14 + pl, tl_thread_div = n_plan;
 		WorkerPool::get(tl_pool_lane).label_ = "planning: worker pool";
 		CpuSpan cs("planning: stage thread (serial parts + waits)");
 		for (;;) {
@@ -1539,7 +1540,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	std::vector<std::thread> planners;
 	for (int pl = 0; pl < n_plan; ++pl) planners.emplace_back(planner_body, pl);
 	std::thread finisher([&] { try {
-		tl_pool_lane = 1, tl_thread_div = 4;
+		tl_pool_lane = lane0 + 1, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "output: worker pool";
 		CpuSpan cs("output: stage thread (flatten + format)");
 		for (int32_t k = 0; k < (int32_t)slot.size(); ++k) {
@@ -1567,7 +1568,7 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// a lane that is free takes the next batch in input order (a static deal would leave lanes idle behind a slow batch)
 	int32_t next_dp = 0;
 	auto dp_lane = [&](int d, mpa_ctx_t *cd) { try {
-		tl_pool_lane = 2 + d, tl_thread_div = 4;
+		tl_pool_lane = lane0 + 2 + d, tl_thread_div = 4;
 		WorkerPool::get(tl_pool_lane).label_ = "DP lanes: worker pool";
 		CpuSpan cs("DP lanes: lane thread (round bookkeeping + waits)");
 		for (;;) {
@@ -1637,6 +1638,90 @@ int mpa_map_batches_claim(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_
 {
 	if (!claim || !n_mapped || !order) { set_error("mpa_map_batches_claim: claim, n_mapped and order are required"); return MPA_ERR_ARG; }
 	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batches_impl(ctx, mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len, claim, user, n_mapped, order); });
+}
+
+// One job over the GPUs of ONE process: the kt_for of mp_map_file (map.c:264-271, 291) across devices.  A pipeline per device
+// context, each claiming the job's next mini-batch from one atomic counter whenever it has room (a faster or less loaded GPU
+// maps more of the job); no data-path exchange between them -- the index is resident on every device, the results come back
+// to the host anyway.  PAF text is formatted inside the pipelines; GFF3 / GTF text needs the running hit id of the whole file
+// (map.c:306), so those jobs are formatted afterwards, in input order, from the exclusive prefix sum of mpa_result_n_output().
+static int mpa_map_batches_multi_impl(int n_ctx, mpa_ctx_t *const *ctxs, mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                                      const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
+{
+	if (n_ctx <= 0 || !ctxs) { set_error("mpa_map_batches_multi: no device context"); return MPA_ERR_NO_DEVICE; }
+	if (n_ctx > 8) { set_error("mpa_map_batches_multi: at most eight device contexts"); return MPA_ERR_ARG; }
+	if (names && (!text || !text_len || !id_io)) { set_error("mpa_map_batches_multi: names given without text/text_len/id_io"); return MPA_ERR_ARG; }
+	for (int p = 0; p < n_ctx; ++p) {
+		if (!ctxs[p]) { set_error("mpa_map_batches_multi: null context"); return MPA_ERR_NO_DEVICE; }
+		const int rc = dev_upload_index(ctxs[p], mi);
+		if (rc != MPA_OK) return rc;
+	}
+	if (n_ctx == 1) return mpa_map_batches_impl(ctxs[0], mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len);
+	for (int32_t k = 0; k < n_batches; ++k) { results[k] = nullptr; if (text) text[k] = nullptr; if (text_len) text_len[k] = 0; }
+	const bool needs_ids = names && (opt->flag & (MPA_MF_GFF | MPA_MF_GTF));
+	struct Pipe {
+		std::vector<mpa_result_t*> res;
+		std::vector<char*> text;
+		std::vector<int64_t> tlen;
+		std::vector<int32_t> order;
+		int32_t n_mapped = 0;
+		int64_t id = 0;
+		int rc = MPA_OK;
+		std::string err;
+	};
+	std::vector<Pipe> pipes((size_t)n_ctx);
+	std::atomic<int32_t> next{0};
+	struct Claim { std::atomic<int32_t> *next; int32_t n; };
+	Claim cl{ &next, n_batches };
+	auto claim = [](void *u) -> int32_t { Claim *c = (Claim*)u; const int32_t k = c->next->fetch_add(1); return k < c->n ? k : -1; };
+	const int threads_each = std::max(1, n_threads / n_ctx);
+	std::vector<std::thread> th;
+	for (int p = 0; p < n_ctx; ++p) {
+		Pipe &P = pipes[(size_t)p];
+		P.res.assign((size_t)n_batches, nullptr), P.text.assign((size_t)n_batches, nullptr), P.tlen.assign((size_t)n_batches, 0), P.order.assign((size_t)n_batches, -1);
+		th.emplace_back([&, p] {
+			Pipe &Q = pipes[(size_t)p];
+			Q.rc = mpa::guarded<int>(MPA_ERR_HIP, [&] {
+				return mpa_map_batches_impl(ctxs[p], mi, opt, n_batches, batches, needs_ids ? nullptr : names, threads_each, Q.res.data(), &Q.id, needs_ids ? nullptr : Q.text.data(),
+				                            needs_ids ? nullptr : Q.tlen.data(), claim, &cl, &Q.n_mapped, Q.order.data(), p);
+			});
+			if (Q.rc != MPA_OK) { Q.err = mpa_last_error(); next.store(n_batches); }   // (a failed pipeline ends the job for the others too)
+		});
+	}
+	for (auto &t : th) t.join();
+	int rc = MPA_OK;
+	for (Pipe &P : pipes) if (P.rc != MPA_OK && rc == MPA_OK) rc = P.rc, set_error(P.err);
+	for (Pipe &P : pipes)
+		for (int32_t j = 0; j < P.n_mapped; ++j) {
+			const int32_t k = P.order[(size_t)j];
+			if (rc == MPA_OK && k >= 0 && k < n_batches) {
+				results[k] = P.res[(size_t)j];
+				if (names && !needs_ids) text[k] = P.text[(size_t)j], text_len[k] = P.tlen[(size_t)j];
+			} else { delete P.res[(size_t)j]; if (P.text[(size_t)j]) free(P.text[(size_t)j]); }
+		}
+	if (rc != MPA_OK) {
+		for (int32_t k = 0; k < n_batches; ++k) { delete results[k], results[k] = nullptr; if (text && text[k]) free(text[k]), text[k] = nullptr; }
+		return rc;
+	}
+	for (int32_t k = 0; k < n_batches; ++k) if (!results[k]) { set_error("mpa_map_batches_multi: a batch was not mapped"); return MPA_ERR_HIP; }
+	if (needs_ids) {
+		std::vector<int64_t> id0((size_t)n_batches + 1, *id_io);
+		for (int32_t k = 0; k < n_batches; ++k) id0[(size_t)k + 1] = id0[(size_t)k] + mpa_result_n_output(opt, &batches[k], results[k]);
+		for (int32_t k = 0; k < n_batches; ++k) {               // (mpa_format_output threads its own parallel region over the queries)
+			int64_t id = id0[(size_t)k];
+			text_len[k] = mpa_format_output(mi, opt, &batches[k], names[k], results[k], &id, &text[k]);
+		}
+		*id_io = id0[(size_t)n_batches];
+	} else if (names) {
+		for (int32_t k = 0; k < n_batches; ++k) *id_io += mpa_result_n_output(opt, &batches[k], results[k]);
+	}
+	return MPA_OK;
+}
+
+int mpa_map_batches_multi(int n_ctx, mpa_ctx_t *const *ctxs, mpa_idx_t *mi, const mpa_mapopt_t *opt, int32_t n_batches, const mpa_qbatch_t *batches,
+                          const char *const *const *names, int n_threads, mpa_result_t **results, int64_t *id_io, char **text, int64_t *text_len)
+{
+	return mpa::guarded<int>(MPA_ERR_HIP, [&] { return mpa_map_batches_multi_impl(n_ctx, ctxs, mi, opt, n_batches, batches, names, n_threads, results, id_io, text, text_len); });
 }
 
 static int mpa_map_batch_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, mpa_result_t **out)

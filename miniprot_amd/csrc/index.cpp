@@ -317,7 +317,7 @@ int64_t mpa::idx_read_spsc(mpa_idx_s *mi, const char *fn, int32_t max_sc)
 	std::unordered_map<std::string, int32_t> cid_of;
 	for (size_t i = 0; i < mi->ctg.size(); ++i) cid_of.emplace(mi->ctg[i].name, (int32_t)i);
 	mi->spsc.assign((size_t)mi->l_seq * 2, 0xff);
-	if (mi->dev) dev_free_index(mi);                         // a resident copy without the track is stale
+	dev_free_index(mi);                                      // a resident copy without the track is stale
 	int64_t n_kept = 0;
 	std::string line;
 	char buf[65536];

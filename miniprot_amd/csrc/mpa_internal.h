@@ -94,7 +94,10 @@ struct mpa_idx_s {
 	std::vector<uint32_t> bo;        // per (contig,strand) block offset, 2*n_ctg+1 entries (index.c:11-26)
 	uint32_t n_block = 0;
 	std::vector<uint8_t> spsc;       // splice-score track (--spsc), empty if none: [strand][l_seq], indexed by contig offset + strand-local position
-	mpa::DeviceIndex *dev = nullptr; // genome resident in HBM (set by mpa_idx_to_device)
+	// genome (and, once seeding has run there, the occurrence lists) resident in the HBM of device d (set by mpa_idx_to_device): one copy
+	// per device, so that the pipelines of several GPUs of one process map against the same index (mpa_map_batches_multi)
+	static const int kMaxDevices = 16;
+	mpa::DeviceIndex *dev[kMaxDevices] = {};
 	void *map_base = nullptr;        // the .mpi file mapped by mpa_idx_restore (seq / kb are views into it), or null
 	size_t map_len = 0;
 };

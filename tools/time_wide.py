@@ -28,4 +28,7 @@ for it in range(3):
     mpa.dp_run(ctx, idx, dp, q, tasks)
     st = ctx.dp_stats()
     ms = st["ms_ext"] if flag != 1 else st["ms_glob"]
+    tot = ctx.dp_stats(total=True, reset=True)
+    if tot["ms_round"] > 0:                        # worker pool (default): the round is a k_dp_worker launch on the worker stream
+        ms = tot["ms_round"]
     print("al %d nl %d x %d flag %d%s: %.2f ms -> %.1f ns/row (backtrack %.2f ms)" % (al, nl, n, flag, " ANTIDIAG" if antidiag else "", ms, ms * 1e6 / nl, st["ms_backtrack"]))
