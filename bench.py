@@ -225,7 +225,7 @@ def roofline_record(st, elapsed, world):
     overlap.)"""
     pool = None
     if st["launches_round"] > 0 and st["ms_round"] > 0 and st.get("ms_round_union", 0) > 0:
-        # DP worker pool (default): the units of all rounds in flight are served by ONE population of k_dp_worker workgroups; a worker
+        # DP worker pool (MPA_DP_POOL=1): the units of all rounds in flight are served by ONE population of k_dp_worker workgroups; a worker
         # launch (one per round, from the lane's worker stream) runs units of any lane, so "ops of a launch" exist only in sum.
         # The kernel's duration = the time during which the pool has a launch running (union of the launches' HIP-event intervals):
         # what ONE persistent kernel's duration would be.  Sum and mean of the launches themselves are kept next to it (`per_launch`:
@@ -240,7 +240,7 @@ def roofline_record(st, elapsed, world):
                         "SUM of the overlapping launches' durations instead"}
         note = "HIP events on the lanes' worker streams against one base event; ops = all units of the timed rounds"
     elif st["launches_round"] > 0 and st["ms_round"] > 0:
-        kernel = "k_dp_round (MPA_DP_POOL=0: one launch per DP round: all extension classes + first traceback chunk)"
+        kernel = "k_dp_round (one launch per DP round: all extension classes + first traceback chunk)"
         n, ms = st["launches_round"], st["ms_round"]
         ops = OPS_PER_CELL_EXT * st["cells_ext_round"] + OPS_PER_CELL_GLOB * st["cells_glob_round"]
         cells = st["cells_ext_round"] + st["cells_glob_round"]

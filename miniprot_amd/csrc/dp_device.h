@@ -45,6 +45,9 @@ __host__ __device__ static inline uint32_t make_rec(uint32_t nas, int32_t donor_
 	return (nas & 0xff) | ((uint32_t)(donor_next & 0xff) << 8) | ((gei & 0xff) << 16) | ((uint32_t)(acceptor & 0xff) << 24);
 }
 
+// rows of one call that one workgroup of k_prep_rows turns into records (256 threads, four rows each)
+#define MPA_PREP_CHUNK_ROWS 1024
+
 // A wave of the extension kernel works on up to 8 calls at once: lanes are split in 64/G groups of G
 // columns, and each 32-bit lane register carries two independent calls in its int16 halves.
 struct ExtWave {
@@ -87,14 +90,14 @@ struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; 
 // of pinned host memory.  Workers are ordinary workgroups that run units until no slot has any left and then exit: nothing on
 // the device ever waits for the host.
 #define MPA_DP_SLOTS 16
-struct DpSlotCtl {
-	unsigned long long head;     // {generation << 32 | next unit}
-	unsigned long long lim;      // {generation << 32 | number of units}
-	int32_t remaining;           // units of this round not yet finished
+struct DpSlotCtl {               // two queues: [0] units that take a whole workgroup, [1] one-wave units (taken by single waves)
+	unsigned long long head[2];  // {generation << 32 | next unit}
+	unsigned long long lim[2];   // {generation << 32 | number of units}
+	int32_t remaining;           // units of this round (both queues) not yet finished
 	int32_t stamp;               // the pool's arm sequence number when this round was armed
 	int32_t *done;               // pinned host word of the lane: receives the generation when the round is complete
 	long long *trace;            // (MPA_DP_TRACE) per unit {start, end} in 100-MHz ticks, or nullptr
-	char pad2_[24];              // 64 bytes: slots do not share a cache line
+	char pad2_[8];               // 64 bytes: slots do not share a cache line
 };
 struct DpPoolCtl {
 	int32_t alive;               // admitted workers that have not exited
@@ -103,6 +106,8 @@ struct DpPoolCtl {
 	int32_t acquire_mode;        // what a worker does before it reads a round's inputs (MPA_DP_ACQUIRE, see k_dp_worker)
 	int32_t pad_[12];
 };
+
+static_assert(sizeof(DpSlotCtl) == 64 && sizeof(DpPoolCtl) == 64, "pool control records are one cache line each");
 
 struct DpConst {         // scalar scoring parameters, passed by value
 	int32_t go, ge, fs, xdrop, end_bonus;

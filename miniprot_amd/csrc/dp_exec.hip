@@ -214,6 +214,18 @@ static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 	}
 }
 
+// The seeding / refinement kernels of a context run on a stream of their own, created with the device's highest priority: they are
+// short and a pipeline stage waits for each of them (MPA_PRIO_SEED=0: normal priority; MPA_PRIO_MAIN=1: the contexts' main streams
+// -- the DP lanes' prep kernels, walks and copies -- get the high priority too).
+static void ensure_seed_stream(mpa_ctx_t *ctx)
+{
+	if (ctx->seed_stream) return;
+	static const bool high = [] { const char *e = getenv("MPA_PRIO_SEED"); return !e || atoi(e) != 0; }();
+	int least = 0, greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+	if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, high ? greatest : least) != hipSuccess) ctx->seed_stream = ctx->stream;
+}
+
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 {
 	if (ctx->device < 0 || ctx->device >= mpa_idx_s::kMaxDevices) { set_error("device number beyond what an index keeps copies for"); return MPA_ERR_UNSUPPORTED; }
@@ -358,7 +370,10 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
 	mpa_ctx_s *ctx = new mpa_ctx_s();
 	ctx->device = device;
-	bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+	static const bool main_high = [] { const char *e = getenv("MPA_PRIO_MAIN"); return e && atoi(e) != 0; }();
+	int least = 0, greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+	bool ok = (main_high ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) == hipSuccess;
 	for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -799,11 +814,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 		}
 	}
 	SeedBufs &B = ctx->seed;
-	if (!ctx->seed_stream) {
-		int least = 0, greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
-	}
+	ensure_seed_stream(ctx);
 	hipStream_t s = ctx->seed_stream;
 	const double t_begin = now_ms();
 	// ---- upload the seed jobs
@@ -960,11 +971,7 @@ int dev_chain_forward(mpa_ctx_t *ctx, const ChainParams &cp, int32_t n_prob, con
 		if (first[q + 1] - first[q] > INT32_MAX - 2) { set_error("chain forward pass: a problem has too many anchors"); return MPA_ERR_UNSUPPORTED; }
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeedBufs &B = ctx->seed;
-	if (!ctx->seed_stream) {
-		int least = 0, greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
-	}
+	ensure_seed_stream(ctx);
 	hipStream_t s = ctx->seed_stream;
 	PreParams pp;
 	pp.max_dist_x = std::max(cp.max_dist_x, cp.bw), pp.max_dist_y = cp.max_dist_y;
@@ -1016,11 +1023,7 @@ int dev_refine_scan(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_aa_
 	HIP_TRY(hipSetDevice(ctx->device));
 	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
 	SeedBufs &B = ctx->seed;
-	if (!ctx->seed_stream) {
-		int least = 0, greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
-	}
+	ensure_seed_stream(ctx);
 	hipStream_t s = ctx->seed_stream;
 	// windows, chunks, the queries' k-mer words: laid out in ONE pinned block and uploaded with one copy (pageable copies are
 	// staged by the runtime, synchronously and spinning)
@@ -1098,11 +1101,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	HIP_TRY(hipSetDevice(ctx->device));
 	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
 	SeedBufs &B = ctx->seed;
-	if (!ctx->seed_stream) {
-		int least = 0, greatest = 0;
-		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (hipStreamCreateWithPriority(&ctx->seed_stream, hipStreamNonBlocking, greatest) != hipSuccess) ctx->seed_stream = ctx->stream;
-	}
+	ensure_seed_stream(ctx);
 	hipStream_t s = ctx->seed_stream;
 	const double t0 = now_ms();
 	// ---- one pinned block up: windows | chunks | wg_first | qg_first | gword | gfirst | gcount | qpos
@@ -1272,9 +1271,16 @@ extern "C" {
 
 namespace mpa {
 // ---- DP worker pool: host side (the kernels and the protocol are in dp_kernels.hip, "The DP worker pool")
+// MPA_DP_POOL=1 selects the pool; the default is one k_dp_round launch per round.  Measured (profiles/r05_experiments.txt): with
+// identical sweep code the pool is level with the launches on the DP-bound config 5 (1.05-1.14 M against 1.09 M residues/s), 5-10 %
+// behind on config 3 (19.4-19.8 M against 20.0-21.9 M) and a third behind on config 2 (17-ms batches: arming, the second host
+// round trip and the L2 write-back weigh).  The hardware's workgroup dispatcher already IS a work-conserving queue across the
+// launches in flight -- a slot that a finished unit frees goes to the oldest pending workgroup of ANY launch -- so what the pool
+// adds (units taken wave by wave, a bounded DP population) buys no throughput here, and its round latency is longer because the
+// rounds in flight share the workers instead of being served in order of arrival.
 static bool dp_pool_enabled()
 {
-	static const bool on = [] { const char *e = getenv("MPA_DP_POOL"); return !e || atoi(e) != 0; }();
+	static const bool on = [] { const char *e = getenv("MPA_DP_POOL"); return e && atoi(e) != 0; }();
 	return on;
 }
 // resident worker workgroups the pool admits (MPA_DP_WORKERS).  The workers ask for a fifth of a CU's LDS plus a little, so four
@@ -1446,7 +1452,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.rec_off = rec_total, rec_total += t.nl;
 		t.prof_off = prof_total, prof_total += (int64_t)22 * t.pw;
 		max_nl = std::max(max_nl, t.nl);
-		for (int32_t r = 0; r < t.nl; r += 256) chunks.push_back(PrepChunk{ id, r });
+		for (int32_t r = 0; r < t.nl; r += MPA_PREP_CHUNK_ROWS) chunks.push_back(PrepChunk{ id, r });
 	};
 	int64_t hkey_total = 0;                                 // per-row keys (8 B) of the extension calls wider than 1024 columns
 	std::vector<int32_t> huge_ids;
@@ -1643,9 +1649,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		auto add = [&](int kind, int first, int count, int64_t cost, int blk = 0, int n_blk = 1, int sgroup = 0, int xg_first = 0) {
 			cu.push_back(Cost{ cost, DpUnit{ kind, first, count, blk, n_blk, sgroup, xg_first, 0 } });
 		};
+		// (worker pool: the one-wave kinds are units of ONE wave descriptor each, taken by single waves; without the pool a
+		// workgroup's four waves take four neighbours of the sorted list)
+		const int per_narrow = use_pool ? 1 : 4;
 		for (int cls = 0; cls < 3; ++cls)
-			for (int k = 0; k < ewave_cnt[cls] && !(cls == 1 && ctx->antidiag); k += 4)
-				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(4, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
+			for (int k = 0; k < ewave_cnt[cls] && !(cls == 1 && ctx->antidiag); k += per_narrow)
+				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(per_narrow, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
 		// (worker pool: a workgroup goes on to its next unit, so all four waves must leave a unit through the same barriers -- a
 		// 65..128-column group then takes a whole workgroup on the four-wave body, its waves 2 and 3 on dead columns)
 		if (use_pool) for (int k = 0; k < ewave_cnt[3]; ++k) add(U_EXT_W4, ewave_first[3] + k, 1, (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
@@ -1659,7 +1668,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			static const int kind_of[8] = { U_GLOB16, U_GLOB32, U_GLOB64, U_GLOB_W2, U_GLOB_W4, -1, -1, U_GLOB_MB };
 			for (int cls = 0; cls < 8; ++cls) {
 				if (kind_of[cls] < 0) continue;
-				const int per = cls == 3 ? (use_pool ? 1 : 2) : cls == 4 ? 1 : 4;
+				const int per = cls == 3 ? (use_pool ? 1 : 2) : cls == 4 ? 1 : per_narrow;
 				for (int k = 0; k < gw_cnt[cls]; k += per) {
 					const GlobWave &g = (*gwv)[gw_first[cls] + k];
 					int64_t cost = (int64_t)g.max_nl * (cls >= 3 && cls <= 4 ? 510 : 430);
@@ -1670,13 +1679,24 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		}
 		if (cu.empty()) return MPA_OK;
 		std::stable_sort(cu.begin(), cu.end(), [](const Cost &x, const Cost &y) { return x.cost > y.cost; });   // (stable: the workgroups of a split group stay adjacent, in column order)
+		// worker pool: the units that take a whole workgroup first (queue 0), then the one-wave units (queue 1), each longest first;
+		// priorities stay relative to the round's longest unit of either kind
+		const int64_t cost_max = cu[0].cost;
+		size_t n_group_units = 0;
+		if (use_pool) {
+			auto is_group = [](const Cost &c) { return c.u.kind == U_EXT_W4 || c.u.kind == U_EXT_SPLIT || c.u.kind == U_GLOB_W4; };
+			std::stable_partition(cu.begin(), cu.end(), is_group);
+			for (const Cost &c : cu) n_group_units += is_group(c);
+		}
 		DpUnit *units = (DpUnit*)(hup + up_units);          // (pinned: the copy below needs no wait)
 		const size_t n_units = cu.size();
 		if (sizeof(DpUnit) * n_units > up_off - up_units) { set_error("internal: more DP units than the staging buffer holds"); return MPA_ERR_HIP; }
 		// the units that bound the round's duration issue ahead of the short ones they share a SIMD with (s_setprio in k_dp_round)
 		for (size_t k = 0; k < cu.size(); ++k) {
 			units[k] = cu[k].u;
-			units[k].pad_ = cu[k].cost * 2 >= cu[0].cost ? 3 : cu[k].cost * 4 >= cu[0].cost ? 2 : cu[k].cost * 10 >= cu[0].cost ? 1 : 0;
+			units[k].pad_ = cu[k].cost * 2 >= cost_max ? 3 : cu[k].cost * 4 >= cost_max ? 2 : cu[k].cost * 10 >= cost_max ? 1 : 0;
+			static const bool unit_prio = [] { const char *e = getenv("MPA_DP_PRIO"); return !e || atoi(e) != 0; }();   // (MPA_DP_PRIO=0: measurement)
+			if (!unit_prio) units[k].pad_ = 0;
 		}
 		int rc2;
 		if ((rc2 = ctx->units.ensure(n_units * sizeof(DpUnit)))) return rc2;
@@ -1704,7 +1724,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			int n_slots;
 			{ std::lock_guard<std::mutex> g(root->pool_mu); n_slots = root->pool_slots; }
 			DpRoundArgs *ha = (DpRoundArgs*)(hup + up_args);
-			ha->ea = ea, ha->wa = wa, ha->ga = ga, ha->units = ctx->units.as<DpUnit>();
+			ha->ea = ea, ha->wa = wa, ha->ga = ga, ha->units = ctx->units.as<DpUnit>(), ha->n_group = (int32_t)n_group_units, ha->pad_ = 0;
 			HIP_TRY(hipMemcpyAsync(&pool->args[ctx->dp_slot], ha, sizeof(DpRoundArgs), hipMemcpyHostToDevice, s));
 			long long *d_trace = nullptr;
 			if (dp_trace_path()) {
@@ -1713,7 +1733,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 				d_trace = ctx->dp_trace.as<long long>();
 			}
 			round_gen = ++ctx->dp_gen;
-			hipLaunchKernelGGL(k_dp_arm, dim3(1), dim3(1), 0, s, pool, ctx->dp_slot, (int)n_units, round_gen, ctx->dp_done, d_trace);
+			hipLaunchKernelGGL(k_dp_arm, dim3(1), dim3(1), 0, s, pool, ctx->dp_slot, (int)n_group_units, (int)(n_units - n_group_units), round_gen, ctx->dp_done, d_trace);
 			HIP_TRY(hipGetLastError());
 			// MPA_DP_WORKER_STREAM=0: the workers on the lane's own stream (what follows the round on that stream then also waits for
 			// this launch's workers to run out of units of ANY lane)
@@ -1728,7 +1748,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			else { HIP_TRY(hipEventCreate(&wl.e0)); HIP_TRY(hipEventCreate(&wl.e1)); }
 			HIP_TRY(ensure_dynamic_lds((const void*)k_dp_worker, ctx->device, round_lds));
 			static const int launch_cap = [] { const char *e = getenv("MPA_DP_LAUNCH_WORKERS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : dp_pool_budget(); }();
-			const unsigned grid = (unsigned)std::min<size_t>(n_units, (size_t)launch_cap);
+			// a workgroup serves one workgroup unit at a time, or four one-wave units side by side
+			const unsigned grid = (unsigned)std::min<size_t>(n_group_units + (n_units - n_group_units + 3) / 4, (size_t)launch_cap);
 			HIP_TRY(hipEventRecord(wl.e0, ws));
 			hipLaunchKernelGGL(k_dp_worker, dim3(grid), dim3(256), round_lds, ws, pool, ctx->dp_slot, n_slots);
 			HIP_TRY(hipGetLastError());

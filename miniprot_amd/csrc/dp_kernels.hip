@@ -245,27 +245,39 @@ __device__ __forceinline__ uint64_t packed_window16(const uint8_t *seq, int64_t 
 // donor/acceptor/nas of window row i (the window fetch, ntseq.c:89-114 -- 4-bit unpack, reverse complement -- is folded into the
 // addressing).  Forward: ns_prep_seq (nasw-sse.c:106-155); left extension:
 // ns_prep_seq_left (nasw-sse.c:157-210).  int8 wrap-around of the reference's arrays is preserved.
+// Four rows per thread (rows i, i + 256, i + 512, i + 768 of a 1 024-row chunk): the kernel is bound by the chain of dependent loads
+// chunk -> task -> contig -> genome words and by how many waves the chip holds at once, not by bandwidth or arithmetic (round 4:
+// 1.8 ms alone for 200 M rows = 0.5 TB/s, and 2-6 x that next to the other kernels of the stream, on every round's critical
+// path) -- a thread that fetches the words of four rows together pays the chain once for four records.
+#define MPA_PREP_ROWS (MPA_PREP_CHUNK_ROWS / 256)
 __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tasks, const PrepChunk *chunks, uint32_t *rec, DpConst c, DevTables tb)
 {
 	MPA_SHORT_KERNEL();
 	const PrepChunk ch = chunks[blockIdx.x];
 	const DTask t = tasks[ch.task];
-	const int32_t i = ch.row0 + (int32_t)threadIdx.x, nl = t.nl;
-	if (i >= nl) return;
+	const int32_t nl = t.nl;
 	const int cid = t.vid >> 1, rev = t.vid & 1, left = (t.flag & 2) != 0;
 	const int64_t off = g.ctg_off[cid], len = g.ctg_len[cid];
 	// w[j] = b[i-6+j], j=0..15, where b[] is the (possibly reversed) window; 15 = outside the window.
 	// The sixteen bases are consecutive in the packed genome (ascending, or descending for a reversed window / the minus strand):
 	// three aligned words cover them, and the sixteen nibbles are shifted out of those -- instead of sixteen dependent byte loads
-	// with 64-bit address arithmetic each (round 4: this kernel sits on the critical path of every DP round and ran 10 x longer
-	// next to the round kernels of the other lanes than alone).  The genome buffer is padded by 16 bytes; what lies outside the
+	// with 64-bit address arithmetic each.  The genome buffer is padded by 16 bytes; what lies outside the
 	// window is masked to 15 whatever was read for it.
-	uint64_t nib;
+	uint64_t nibs[MPA_PREP_ROWS];
+	const int64_t x0 = t.nt_off + (left ? nl - 1 : 0);             // strand position of window position 0
+	const int64_t p0 = rev ? off + len - 1 - x0 : off + x0;        // ... its position in the packed genome
+	const int dir = (left != (rev != 0)) ? -1 : 1;
+#pragma unroll
+	for (int r = 0; r < MPA_PREP_ROWS; ++r) {
+		const int32_t i = ch.row0 + (int32_t)threadIdx.x + 256 * r;
+		nibs[r] = i < nl ? packed_window16(g.seq, g.l_seq, p0 + (int64_t)dir * (i - 6), dir, rev) : 0;
+	}
+#pragma unroll
+	for (int r = 0; r < MPA_PREP_ROWS; ++r) {
+	const int32_t i = ch.row0 + (int32_t)threadIdx.x + 256 * r;
+	if (i >= nl) continue;
+	uint64_t nib = nibs[r];
 	{
-		const int64_t x0 = t.nt_off + (left ? nl - 1 : 0);             // strand position of window position 0
-		const int64_t p0 = rev ? off + len - 1 - x0 : off + x0;        // ... its position in the packed genome
-		const int dir = (left != (rev != 0)) ? -1 : 1;
-		nib = packed_window16(g.seq, g.l_seq, p0 + (int64_t)dir * (i - 6), dir, rev);
 		const int32_t jlo = 6 - i > 0 ? (6 - i > 16 ? 16 : 6 - i) : 0;                        // w[j], j < jlo: before the window
 		const int32_t jhi = nl - i + 6 < 16 ? (nl - i + 6 < 0 ? 0 : nl - i + 6) : 16;       // w[j], j >= jhi: behind it
 		uint64_t valid = jhi >= 16 ? ~0ULL : ((1ULL << (4 * jhi)) - 1);
@@ -364,6 +376,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 		}
 	}
 	rec[t.rec_off + i] = make_rec(nas * PROF_AA_STRIDE_REC, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
+	}
 }
 
 // query profile prof[a][col] = mat[a][aa(col)] (ns_gen_prof nasw-sse.c:212-224); columns >= al score -32768
@@ -1413,6 +1426,8 @@ constexpr size_t dp_round_max(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t DP_ROUND_LDS = dp_round_max(dp_round_max(dp_round_max(4 * EXT_NARROW_LDS, 2 * EXT_WIDE_LDS(2)), dp_round_max(EXT_WIDE_LDS(4), 4 * GLOB_NARROW_LDS)),
                                              dp_round_max(2 * GLOB_WIDE_LDS(2), GLOB_WIDE_LDS(4)));   // 30 400 bytes: five workgroups per CU
 // one DpUnit on the four waves of a 256-thread workgroup (lds: the workgroup's DP_ROUND_LDS bytes)
+// WG_ONLY: only the kinds that take a whole workgroup (the worker pool runs the one-wave kinds wave by wave)
+template<bool WG_ONLY>
 __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, const ExtWideArgs &wa, const GlobArgs &ga, char *lds, const int tid)
 {
 	const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1423,22 +1438,22 @@ __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, 
 	default: __builtin_amdgcn_s_setprio(0); break;
 	}
 	switch (u.kind) {
-	case U_EXT16: if (wv < u.count) ext_narrow<16>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
-	case U_EXT32: if (wv < u.count) ext_narrow<32>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
-	case U_EXT64: if (wv < u.count) ext_narrow<64>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT16: if (!WG_ONLY && wv < u.count) ext_narrow<16>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT32: if (!WG_ONLY && wv < u.count) ext_narrow<32>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT64: if (!WG_ONLY && wv < u.count) ext_narrow<64>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_EXT_W2: {
 		const int g = wv >> 1, w = wv & 1;
-		if (g < u.count) ext_wide_body<2, false>(wa, u.first + g, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds + g * EXT_WIDE_LDS(2), lane, w, w * 64 + lane });
+		if (!WG_ONLY && g < u.count) ext_wide_body<2, false>(wa, u.first + g, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds + g * EXT_WIDE_LDS(2), lane, w, w * 64 + lane });
 	} break;
 	case U_EXT_W4: ext_wide_body<4, false>(wa, u.first, SplitPos{ 0, 0, 1, 0 }, WavePos{ lds, lane, wv, tid }); break;
 	case U_EXT_SPLIT: ext_wide_body<4, true>(wa, u.first, SplitPos{ u.sgroup, u.blk, u.n_blk, u.xg_first }, WavePos{ lds, lane, wv, tid }); break;
-	case U_GLOB16: if (wv < u.count) glob_narrow<16, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
-	case U_GLOB32: if (wv < u.count) glob_narrow<32, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
-	case U_GLOB64: if (wv < u.count) glob_narrow<64, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
-	case U_GLOB_MB: if (wv < u.count) glob_narrow<64, true>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB16: if (!WG_ONLY && wv < u.count) glob_narrow<16, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB32: if (!WG_ONLY && wv < u.count) glob_narrow<32, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB64: if (!WG_ONLY && wv < u.count) glob_narrow<64, false>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
+	case U_GLOB_MB: if (!WG_ONLY && wv < u.count) glob_narrow<64, true>(ga, ga.waves[u.first + wv], WavePos{ lds + wv * GLOB_NARROW_LDS, lane, 0, lane }); break;
 	case U_GLOB_W2: {
 		const int g = wv >> 1, w = wv & 1;
-		if (g < u.count) glob_wide_body<2>(ga, ga.waves[u.first + g], WavePos{ lds + g * GLOB_WIDE_LDS(2), lane, w, w * 64 + lane });
+		if (!WG_ONLY && g < u.count) glob_wide_body<2>(ga, ga.waves[u.first + g], WavePos{ lds + g * GLOB_WIDE_LDS(2), lane, w, w * 64 + lane });
 	} break;
 	case U_GLOB_W4: glob_wide_body<4>(ga, ga.waves[u.first], WavePos{ lds, lane, wv, tid }); break;
 	default: break;
@@ -1450,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 {
 	extern __shared__ uint32_t lds_raw[];
 	const DpUnit u = units[blockIdx.x];
-	dp_run_unit(u, ea, wa, ga, (char*)lds_raw, (int)threadIdx.x);
+	dp_run_unit<false>(u, ea, wa, ga, (char*)lds_raw, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1476,23 +1491,26 @@ __global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, Gl
 // running: its CU's L1 and its XCD's L2 may hold lines of the round before); a unit's results are written back from the L2s by
 // k_l2_writeback, which the lane launches behind the completed round, before anything reads them.
 // ------------------------------------------------------------------------------------------------
-struct DpRoundArgs { ExtArgs ea; ExtWideArgs wa; GlobArgs ga; const DpUnit *units; };
+struct DpRoundArgs { ExtArgs ea; ExtWideArgs wa; GlobArgs ga; const DpUnit *units; int32_t n_group, pad_; };
 struct DpPool { DpPoolCtl ctl; DpSlotCtl slot[MPA_DP_SLOTS]; DpRoundArgs args[MPA_DP_SLOTS]; };
 #define MPA_DP_ALWAYS_ADMITTED 64
 
 __device__ __forceinline__ unsigned long long ld_u64_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// arms slot `s` for a round of n units (generation gen); single thread, stream-ordered behind everything the round reads
-__global__ void k_dp_arm(DpPool *pool, int s, int n, unsigned int gen, int32_t *done, long long *trace)
+// arms slot `s` for a round of n_group workgroup units and n_wave one-wave units (generation gen); single thread, stream-ordered
+// behind everything the round reads
+__global__ void k_dp_arm(DpPool *pool, int s, int n_group, int n_wave, unsigned int gen, int32_t *done, long long *trace)
 {
 	DpSlotCtl &c = pool->slot[s];
-	__hip_atomic_store(&c.remaining, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.remaining, n_group + n_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__hip_atomic_store(&c.stamp, atomicAdd(&pool->ctl.arm_seq, 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	c.done = done, c.trace = trace;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-	__hip_atomic_store(&c.lim, (unsigned long long)gen << 32 | (unsigned int)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.lim[0], (unsigned long long)gen << 32 | (unsigned int)n_group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.lim[1], (unsigned long long)gen << 32 | (unsigned int)n_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-	__hip_atomic_store(&c.head, (unsigned long long)gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.head[0], (unsigned long long)gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&c.head[1], (unsigned long long)gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Writes the dirty lines of every XCD's L2 back to memory: the results of a round's units, wherever their workers ran.  Launched by
@@ -1502,10 +1520,76 @@ __global__ __launch_bounds__(64) void k_l2_writeback()
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
+// One lane takes the next unit of queue q (0: workgroup units, 1: one-wave units) of the first slot that has one, the home slot
+// first.  Returns the slot or -1.
+__device__ __forceinline__ int dp_pull(DpPool *pool, const int q, const int home, const int n_slots, int &unit, unsigned int &gen)
+{
+	for (int k = 0; k < n_slots; ++k) {
+		const int s = home + k < n_slots ? home + k : home + k - n_slots;
+		DpSlotCtl &c = pool->slot[s];
+		for (;;) {
+			// look first (plain atomic loads: an empty slot costs its scanners no read-modify-write), then take with ONE fetch-add --
+			// never a compare-and-swap loop: with several hundred workgroups at one head word every failed attempt is another
+			// round trip to the L2 (measured: a launch of 1 024 workers on 1 024 units took 8.4 ms against 2.3 ms)
+			const unsigned long long h = ld_u64_agent(&c.head[q]), l = ld_u64_agent(&c.lim[q]);
+			if ((h >> 32) != (l >> 32) || (unsigned int)h >= (unsigned int)l) break;          // being armed, or no unit left
+			const unsigned long long h2 = __hip_atomic_fetch_add(&c.head[q], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long l2 = ld_u64_agent(&c.lim[q]);
+			// (an index past the end is nobody's unit: the head is set afresh when the slot is armed again, and a head of a
+			// generation can only be seen once that generation's lim has been written)
+			if ((h2 >> 32) == (l2 >> 32) && (unsigned int)h2 < (unsigned int)l2) { unit = (int)(unsigned int)h2, gen = (unsigned int)(h2 >> 32); return s; }
+		}
+	}
+	return -1;
+}
+
+// What a worker does before it reads the inputs of a round it has not read before (MPA_DP_ACQUIRE).  2 (default): an agent-scope
+// acquire if the round was armed after the last acquire on this CU that this workgroup knows of -- an acquire is not about a slot,
+// it drops every stale line the CU's L1 and the XCD's L2 hold at that moment (the arguments, unit lists and task tables of a round
+// arrive by host-to-device copies, which no kernel boundary makes visible to a workgroup that is already running:
+// profiles/r05_stale_reads_across_kernel_boundaries.txt), and it is not free for the kernels next door; 1: whenever the workgroup
+// moves to another (slot, generation); 0: never (measurement only).  The round's arguments are read through the scalar cache
+// (constant address space), which the fence does not cover: invalidated by hand.  `seen` = {sequence number, slot, generation} in LDS,
+// shared by the waves of the workgroup.
+__device__ __forceinline__ void dp_acquire(DpPool *pool, const int mode, const int s, const unsigned int gen, volatile int32_t *seen)
+{
+	bool fresh = false;
+	if (mode == 1) fresh = s != seen[1] || (int32_t)gen != seen[2];
+	else if (mode == 2) fresh = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->slot[s].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - seen[0] > 0;
+	if (fresh) {
+		const int now_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->ctl.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		__builtin_amdgcn_s_dcache_inv();
+		seen[0] = now_seq, seen[1] = s, seen[2] = (int32_t)gen;
+	}
+}
+
+// a unit's results are in the L2 (see the comment in the loop below): count it, and tell the lane if it was the round's last
+__device__ __forceinline__ void dp_unit_done(DpPool *pool, const int s, const unsigned int gen)
+{
+	DpSlotCtl &c = pool->slot[s];
+	if (__hip_atomic_fetch_add(&c.remaining, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+		__hip_atomic_store(c.done, (int32_t)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ DpUnit dp_load_unit(const DpUnit *up)
+{
+	DpUnit u;
+	u.kind = __builtin_amdgcn_readfirstlane(up->kind), u.first = __builtin_amdgcn_readfirstlane(up->first), u.count = __builtin_amdgcn_readfirstlane(up->count);
+	u.blk = __builtin_amdgcn_readfirstlane(up->blk), u.n_blk = __builtin_amdgcn_readfirstlane(up->n_blk), u.sgroup = __builtin_amdgcn_readfirstlane(up->sgroup);
+	u.xg_first = __builtin_amdgcn_readfirstlane(up->xg_first), u.pad_ = __builtin_amdgcn_readfirstlane(up->pad_);
+	return u;
+}
+
+// A worker workgroup.  First its four waves work TOGETHER on workgroup units (wide and split extension groups, wide traceback
+// groups: bodies that use the workgroup barrier) until no slot has one left; then every wave goes its own way and takes one-wave
+// units (up to eight narrow extension calls or four traceback calls each) until no slot has one of those left -- a wave whose
+// calls are x-dropped after a few hundred rows is on its next unit while its neighbour sweeps 100 000 rows.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dp_worker(DpPool *pool, const int home, const int n_slots)
 {
 	extern __shared__ uint32_t lds_raw[];
-	__shared__ int32_t pick[4];                                   // slot, unit, generation (thread 0 -> the workgroup)
+	__shared__ int32_t pick[4];                                   // slot, unit, generation (thread 0 -> the workgroup), admission
+	__shared__ int32_t seen[4];                                   // dp_acquire; [3]: waves that have left
 	char *lds = (char*)lds_raw;
 	int tid = (int)threadIdx.x;                                   // (made opaque once per unit, see below)
 	if (tid == 0) {
@@ -1515,89 +1599,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 			if (a >= __hip_atomic_load(&pool->ctl.budget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicSub(&pool->ctl.alive, 1), ok = 0;
 		} else atomicAdd(&pool->ctl.alive, 1);
 		pick[3] = ok;
+		seen[0] = 0, seen[1] = -1, seen[2] = 0, seen[3] = 0;
 	}
 	__syncthreads();
 	if (!pick[3]) return;
-	int seen_slot = -1;                                           // the (slot, generation) whose inputs this workgroup has acquired
-	unsigned int seen_gen = 0;
-	int seen_seq = 0;                                             // every round armed up to this sequence number was armed before this workgroup's last acquire
 	const int acquire_mode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->ctl.acquire_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	typedef const __attribute__((address_space(4))) DpRoundArgs *ConstArgs;
+	// ---- workgroup units
 	for (;;) {
 		// (the thread index is made opaque per unit: otherwise every lane-dependent constant of every body -- column masks, group
-		// indices, profile addresses of twelve instantiations -- is hoisted out of this loop and stays live across it: 204 VGPRs)
+		// indices, profile addresses of twelve instantiations -- is hoisted out of the loop and stays live across it: 204 VGPRs)
 		asm volatile("" : "+v"(tid));
 		if (tid == 0) {
-			int got = -1, unit = 0;
+			int unit = 0;
 			unsigned int gen = 0;
-			for (int k = 0; k < n_slots && got < 0; ++k) {
-				const int s = home + k < n_slots ? home + k : home + k - n_slots;
-				DpSlotCtl &c = pool->slot[s];
-				for (;;) {
-					// look first (plain atomic loads: an empty slot costs its scanners no read-modify-write), then take with ONE fetch-add --
-					// never a compare-and-swap loop: with several hundred workgroups at one head word every failed attempt is another
-					// round trip to the L2 (measured: a launch of 1 024 workers on 1 024 units took 8.4 ms against 2.3 ms)
-					const unsigned long long h = ld_u64_agent(&c.head), l = ld_u64_agent(&c.lim);
-					if ((h >> 32) != (l >> 32) || (unsigned int)h >= (unsigned int)l) break;          // being armed, or no unit left
-					const unsigned long long h2 = __hip_atomic_fetch_add(&c.head, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					const unsigned long long l2 = ld_u64_agent(&c.lim);
-					// (an index past the end is nobody's unit: the head is set afresh when the slot is armed again, and a head of a
-					// generation can only be seen once that generation's lim has been written)
-					if ((h2 >> 32) == (l2 >> 32) && (unsigned int)h2 < (unsigned int)l2) { got = s, unit = (int)(unsigned int)h2, gen = (unsigned int)(h2 >> 32); break; }
-				}
-			}
-			pick[0] = got, pick[1] = unit, pick[2] = (int32_t)gen;
+			pick[0] = dp_pull(pool, 0, home, n_slots, unit, gen), pick[1] = unit, pick[2] = (int32_t)gen;
 		}
 		__syncthreads();
 		const int s = pick[0], ui = pick[1];
 		const unsigned int gen = (unsigned int)pick[2];
 		if (s < 0) break;
-		// MPA_DP_ACQUIRE: 1 = acquire whenever the workgroup moves to another (slot, generation); 2 (default) = only when the round
-		// was armed after the workgroup's last acquire -- an acquire is not about a slot, it drops every stale line the CU's L1 and
-		// the XCD's L2 hold at that moment, and it is expensive for everybody: each one invalidates the XCD's L2 under the seeding
-		// kernels' feet (mode 1: up to one per unit while a lane's queue runs dry and its workers steal -- 14 M residues/s against
-		// 22 M); 0 = none (measurement only: relies on the kernel boundaries between a round's producers and its arming).
-		bool fresh = false;
-		if (acquire_mode == 1) fresh = s != seen_slot || gen != seen_gen;
-		else if (acquire_mode == 2) {
-			const int stamp = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->slot[s].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			fresh = stamp - seen_seq > 0;
-		}
-		if (fresh) {
-			const int now_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool->ctl.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			seen_slot = s, seen_gen = gen, seen_seq = now_seq;
-		}
+		if ((tid >> 6) == 0) dp_acquire(pool, acquire_mode, s, gen, seen);
+		__syncthreads();
 		// The round's arguments are read through the CONSTANT address space: they do not change while the round is live, and scalar
-		// loads keep them out of the vector registers (as plain global loads behind the atomics above they cost 110 VGPRs: two
-		// workgroups per CU instead of four).  The scalar cache is not covered by the acquire: it is invalidated by hand.
-		if (fresh) __builtin_amdgcn_s_dcache_inv();
-		typedef const __attribute__((address_space(4))) DpRoundArgs *ConstArgs;
+		// loads keep them out of the vector registers (as plain global loads behind the atomics above they cost 110 VGPRs).
 		const DpRoundArgs &ra = *(const DpRoundArgs*)(ConstArgs)(uintptr_t)&pool->args[s];
-		DpUnit u;
-		{
-			const DpUnit *up = ra.units + ui;
-			u.kind = __builtin_amdgcn_readfirstlane(up->kind), u.first = __builtin_amdgcn_readfirstlane(up->first), u.count = __builtin_amdgcn_readfirstlane(up->count);
-			u.blk = __builtin_amdgcn_readfirstlane(up->blk), u.n_blk = __builtin_amdgcn_readfirstlane(up->n_blk), u.sgroup = __builtin_amdgcn_readfirstlane(up->sgroup);
-			u.xg_first = __builtin_amdgcn_readfirstlane(up->xg_first), u.pad_ = __builtin_amdgcn_readfirstlane(up->pad_);
-		}
+		const DpUnit u = dp_load_unit(ra.units + ui);
 		long long *trace = pool->slot[s].trace;
 		const long long t0 = trace ? wall_clock64() : 0;               // (uniform: scalar registers)
-		dp_run_unit(u, ra.ea, ra.wa, ra.ga, lds, tid);
+		dp_run_unit<true>(u, ra.ea, ra.wa, ra.ga, lds, tid);
 		__builtin_amdgcn_s_setprio(0);
 		// The unit's results stay where the stores left them -- dirty lines of this XCD's L2: the round's consumers are kernels and
 		// copies the lane enqueues AFTER it has seen the round complete, behind k_l2_writeback (one L2 write-back per XCD and round).
 		// A release fence here, per wave and unit, is 40 000 whole-L2 write-backs per round: measured, it stretched every kernel on
-		// the chip (13 M residues/s against 22 M).  All that is needed is that the stores have left the CU before the unit counts.
+		// the chip.  All that is needed is that the stores have left the CU before the unit counts.
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (tid == 0) {
 			if (trace) trace[2 * ui] = t0, trace[2 * ui + 1] = wall_clock64();
-			DpSlotCtl &c = pool->slot[s];
-			if (__hip_atomic_fetch_add(&c.remaining, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
-				__hip_atomic_store(c.done, (int32_t)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			dp_unit_done(pool, s, gen);
 		}
 	}
-	if (tid == 0) atomicSub(&pool->ctl.alive, 1);
+	// ---- one-wave units: no workgroup barrier from here on
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	char *lds_wave = lds + wv * EXT_NARROW_LDS;
+	for (;;) {
+		asm volatile("" : "+v"(tid));
+		const int lane = tid & 63;
+		int s = -1, ui = 0;
+		unsigned int gen = 0;
+		if (lane == 0) s = dp_pull(pool, 1, home, n_slots, ui, gen);
+		s = __builtin_amdgcn_readfirstlane(s), ui = __builtin_amdgcn_readfirstlane(ui), gen = (unsigned int)__builtin_amdgcn_readfirstlane((int)gen);
+		if (s < 0) break;
+		dp_acquire(pool, acquire_mode, s, gen, seen);
+		const DpRoundArgs &ra = *(const DpRoundArgs*)(ConstArgs)(uintptr_t)&pool->args[s];
+		const int uidx = ra.n_group + ui;                            // (the one-wave units follow the workgroup units in the round's list)
+		const DpUnit u = dp_load_unit(ra.units + uidx);
+		long long *trace = pool->slot[s].trace;
+		const long long t0 = trace ? wall_clock64() : 0;
+		switch (u.pad_) {                                             // issue priority by expected duration (dp_exec.hip, launch_round)
+		case 3: __builtin_amdgcn_s_setprio(3); break;
+		case 2: __builtin_amdgcn_s_setprio(2); break;
+		case 1: __builtin_amdgcn_s_setprio(1); break;
+		default: break;
+		}
+		const WavePos wp{ lds_wave, lane, 0, lane };
+		switch (u.kind) {
+		case U_EXT16: ext_narrow<16>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_EXT32: ext_narrow<32>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_EXT64: ext_narrow<64>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_GLOB16: glob_narrow<16, false>(ra.ga, ra.ga.waves[u.first], wp); break;
+		case U_GLOB32: glob_narrow<32, false>(ra.ga, ra.ga.waves[u.first], wp); break;
+		case U_GLOB64: glob_narrow<64, false>(ra.ga, ra.ga.waves[u.first], wp); break;
+		case U_GLOB_MB: glob_narrow<64, true>(ra.ga, ra.ga.waves[u.first], wp); break;
+		default: break;
+		}
+		__builtin_amdgcn_s_setprio(0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (lane == 0) {
+			if (trace) trace[2 * uidx] = t0, trace[2 * uidx + 1] = wall_clock64();
+			dp_unit_done(pool, s, gen);
+		}
+	}
+	if ((tid & 63) == 0 && atomicAdd(&seen[3], 1) == 3) atomicSub(&pool->ctl.alive, 1);   // the last wave to leave takes the workgroup off the count
 }
 
 // ------------------------------------------------------------------------------------------------

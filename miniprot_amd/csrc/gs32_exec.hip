@@ -60,7 +60,7 @@ extern "C" int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt
 			t.prof_off = prof_total, prof_total += (int64_t)22 * t.pw;
 			t.bnd_off = scr_total, scr_total += gs32_scratch_words(t.al);     // (int32 words of the sweep's scratch)
 			max_nl = std::max(max_nl, t.nl);
-			for (int32_t r = 0; r < t.nl; r += 256) chunks.push_back(PrepChunk{ (int32_t)k, r });
+			for (int32_t r = 0; r < t.nl; r += MPA_PREP_CHUNK_ROWS) chunks.push_back(PrepChunk{ (int32_t)k, r });
 			if ((x.flag & MPA_F_CIGAR) && !(x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT))) {
 				t.tb_off = tb_total, tb_total += (int64_t)t.nl * t.ncol;
 				t.cig_cap = t.nl + t.al + 4, t.cig_off = cig_total, cig_total += t.cig_cap;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 5 A/B runs on the GPU box (through gpurun): bench.py on a cached config-3 workload under the environment variants given
 # as arguments ("NAME:VAR=VAL,VAR=VAL" ...), one summary block per variant.
-#   bash tools/r05_ab.sh OUTDIR STEPS WARMUP "base:MPA_DP_POOL=0" "pool768:" "pool512:MPA_DP_WORKERS=512"
+#   bash tools/r05_ab.sh OUTDIR STEPS WARMUP "base:" "pool768:MPA_DP_POOL=1" "pool512:MPA_DP_POOL=1,MPA_DP_WORKERS=512"
+# (the runs recorded in profiles/r05_experiments.txt were made while the pool was the default: there "MPA_DP_POOL=0" marks the launches)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$1; STEPS=$2; WARM=$3; shift 3
