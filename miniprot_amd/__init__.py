@@ -116,9 +116,13 @@ def lib():
         if hasattr(L, "mpa_dp_handoff_retries"):                      # (absent from older builds loaded through MPA_LIB_PATH)
             L.mpa_dp_handoff_retries.argtypes = [C.c_void_p]
             L.mpa_dp_handoff_retries.restype = C.c_int64
-        L.mpa_device_bytes.restype = C.c_int64
-        L.mpa_pool_growths.restype = C.c_int64
-        L.mpa_stage_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        # (an older build loaded through MPA_LIB_PATH may lack the diagnostics below: the accessors then return 0 / empty)
+        if hasattr(L, "mpa_device_bytes"):
+            L.mpa_device_bytes.restype = C.c_int64
+        if hasattr(L, "mpa_pool_growths"):
+            L.mpa_pool_growths.restype = C.c_int64
+        if hasattr(L, "mpa_stage_clocks"):
+            L.mpa_stage_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mpa_free.argtypes = [C.c_void_p]
         for name, res, args in [
             ("mpa_batch_begin", C.c_void_p, [C.c_void_p, C.POINTER(MapOpt), C.POINTER(QBatch), C.c_int]),
@@ -186,24 +190,25 @@ class Context:
 
     def handoff_retries(self):
         """DP rounds repeated because a workgroup hand-off of a split extension call timed out (mpa_dp_handoff_retries)."""
-        return int(lib().mpa_dp_handoff_retries(self.h))
+        return int(lib().mpa_dp_handoff_retries(self.h)) if hasattr(lib(), "mpa_dp_handoff_retries") else 0
 
     @staticmethod
     def device_bytes():
         """bytes of HBM held through the library: resident index + every pool of every context (mpa_device_bytes)"""
-        return int(lib().mpa_device_bytes())
+        return int(lib().mpa_device_bytes()) if hasattr(lib(), "mpa_device_bytes") else 0
 
     @staticmethod
     def stage_clocks(reset=False):
         """{stage: (wall ms, calls)} of mpa_map_batches' stages since the last reset (mpa_stage_clocks)"""
         ms, n = (C.c_double * 5)(), (C.c_int64 * 5)()
-        lib().mpa_stage_clocks(ms, n, 1 if reset else 0)
+        if hasattr(lib(), "mpa_stage_clocks"):
+            lib().mpa_stage_clocks(ms, n, 1 if reset else 0)
         return {k: (ms[i], int(n[i])) for i, k in enumerate(("seeding", "planning", "dp", "output", "sketch"))}
 
     @staticmethod
     def pool_growths():
         """how often a device pool had to be re-allocated so far (mpa_pool_growths)"""
-        return int(lib().mpa_pool_growths())
+        return int(lib().mpa_pool_growths()) if hasattr(lib(), "mpa_pool_growths") else 0
 
     def __del__(self):
         try:

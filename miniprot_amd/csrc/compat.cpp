@@ -81,6 +81,8 @@ CompatIndex *wrap_index(mpa_idx_t *impl)
 	memset(&c->pub, 0, sizeof(c->pub));
 	memcpy(&c->pub.opt, &impl->opt, sizeof(mp_idxopt_t));
 	c->pub.n_block = impl->n_block, c->pub.nt = &c->nt;
+	// (kb of a RESTORED index is a view into the mapped .mpi and may be misaligned for uint32_t -- the section follows the contig
+	// names; a caller that reads mp_idx_t::kb itself should memcpy the entries out.  ki, bo and every built index are aligned.)
 	c->pub.n_kb = impl->n_kb, c->pub.ki = impl->ki.data(), c->pub.bo = impl->bo.data(), c->pub.kb = impl->kb.data();
 	return c;
 }

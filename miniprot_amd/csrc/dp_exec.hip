@@ -47,11 +47,14 @@ struct DevBuf {
 	// once for everybody instead of once per context (a growth is a hipFree: it waits for the whole device)
 	std::atomic<size_t> *hint = nullptr;
 	int ensure(size_t bytes) {
+		const size_t asked = bytes;
 		if (hint) {
 			size_t h = hint->load(std::memory_order_relaxed);
 			while (bytes > h && !hint->compare_exchange_weak(h, bytes, std::memory_order_relaxed)) {}
 			if (bytes <= cap) return MPA_OK;
-			if (h > bytes) bytes = h;
+			// (the siblings' high-water mark is a guess about batches to come, not a need: it is taken only while it stays within
+			// twice the request -- one outlier batch on one lane must not make every lane's pool that large for the rest of the job)
+			if (h > bytes && h <= 2 * bytes) bytes = h;
 		}
 		if (bytes <= cap) return MPA_OK;
 		const double t0 = now_ms();
@@ -61,10 +64,14 @@ struct DevBuf {
 		if (p) { (void)hipFree(p); g_dev_bytes -= (long long)cap; ++g_pool_growths; }
 		p = nullptr, cap = 0;
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
-		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases)
+		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases -- but slack and hint
+		// are wishes: when the device cannot give that much, the bare request is tried before the call fails)
 		size_t want = bytes;
 		want += want / 3 + 4096;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b - (free_b >> 4)) want = asked + 4096;
 		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess && want > asked + 4096) { (void)hipGetLastError(); want = asked + 4096; e = hipMalloc(&p, want); }
 		if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr, tl_alloc_failed = true; set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); return MPA_ERR_HIP; }
 		cap = want;
 		g_dev_bytes += (long long)cap;

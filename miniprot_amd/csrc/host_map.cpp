@@ -851,11 +851,14 @@ static void take_round3(mpa_batch_s *b, const mpa_dp_rst_t *rst, const uint32_t 
 extern "C" {
 
 // MPA_GPU_SEED: 0 = seeding always on the host, 1 = always on the device, unset = by the size of the batch
+static thread_local int tl_seed_mode = -2;          // (the mpa_dbg_* test hooks force a mode for their own call, on their own thread)
 static int gpu_seeding_mode()
 {
+	if (tl_seed_mode != -2) return tl_seed_mode;
 	const char *e = getenv("MPA_GPU_SEED");             // (read per call: the tests flip it)
 	return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
+struct SeedModeScope { int keep; explicit SeedModeScope(int m) : keep(tl_seed_mode) { tl_seed_mode = m; } ~SeedModeScope() { tl_seed_mode = keep; } };
 // Below this many anchors per mini-batch the host's own sort + forward pass is faster than a round trip to a GPU that is
 // busy with DP rounds (measured: 2.7 M anchors at config 2 -> host, 25 M at 600 Mbp and 240 M at config 3 -> device).
 static const int64_t kDeviceSeedingMinAnchors = 8000000;
@@ -1139,13 +1142,10 @@ int64_t mpa_dbg_refine_hits(mpa_ctx_t *ctx, const mpa_idx_t *mi, int32_t kmer, c
 int64_t mpa_dbg_anchors(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out)
 {
 	*out = nullptr;
-	const char *saved = getenv("MPA_GPU_SEED");
-	const std::string keep = saved ? saved : "";
-	setenv("MPA_GPU_SEED", "0", 1);
 	mpa_mapopt_t o2 = *opt;
 	o2.flag |= MPA_MF_NO_PRE_CHAIN;                       // (stage_anchors_host then stops after the sort)
-	mpa_batch_t *b = batch_seed_phase(nullptr, mi, &o2, q, n_threads, false);
-	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	mpa_batch_t *b;
+	{ SeedModeScope host_only(0); b = batch_seed_phase(nullptr, mi, &o2, q, n_threads, false); }
 	if (!b) return MPA_ERR_ARG;
 	std::vector<std::vector<uint64_t>> per((size_t)q->n_seq);
 	parallel_for(b->n_threads, q->n_seq, [&](int64_t i) { stage_anchors_host(b, b->qs[i], per[i]); });
@@ -1162,11 +1162,8 @@ int64_t mpa_dbg_anchors(const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_
 int64_t mpa_dbg_prechain_survivors(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapopt_t *opt, const mpa_qbatch_t *q, int n_threads, int64_t *off, uint64_t **out)
 {
 	*out = nullptr;
-	const char *saved = getenv("MPA_GPU_SEED");
-	const std::string keep = saved ? saved : "";
-	setenv("MPA_GPU_SEED", ctx ? "1" : "0", 1);
-	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads, false);
-	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	mpa_batch_t *b;
+	{ SeedModeScope forced(ctx ? 1 : 0); b = batch_seed_phase(ctx, mi, opt, q, n_threads, false); }
 	if (!b) return MPA_ERR_ARG;
 	if (ctx && !b->seeded_on_device && q->n_seq > 0 && prechain_enabled(*opt)) { delete b; set_error("device seeding was not used"); return MPA_ERR_UNSUPPORTED; }
 	std::vector<std::vector<uint64_t>> per((size_t)q->n_seq);
@@ -1192,11 +1189,8 @@ int64_t mpa_dbg_main_chains(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_mapop
                             int64_t *off_a, uint64_t **out_a)
 {
 	*out_u = *out_a = nullptr;
-	const char *saved = getenv("MPA_GPU_SEED");
-	const std::string keep = saved ? saved : "";
-	setenv("MPA_GPU_SEED", ctx ? "1" : "0", 1);
-	mpa_batch_t *b = batch_seed_phase(ctx, mi, opt, q, n_threads, true);
-	if (saved) setenv("MPA_GPU_SEED", keep.c_str(), 1); else unsetenv("MPA_GPU_SEED");
+	mpa_batch_t *b;
+	{ SeedModeScope forced(ctx ? 1 : 0); b = batch_seed_phase(ctx, mi, opt, q, n_threads, true); }
 	if (!b) return MPA_ERR_ARG;
 	if (ctx && q->n_seq > 0 && prechain_enabled(*opt) && !(b->seeded_on_device && b->sparse.has_chains)) { delete b; set_error("the device did not chain"); return MPA_ERR_UNSUPPORTED; }
 	std::vector<std::vector<uint64_t>> us((size_t)q->n_seq), as((size_t)q->n_seq);

@@ -109,10 +109,22 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 	struct stat st;
 	if (fstat(fd, &st) != 0 || st.st_size < 44) { close(fd); set_error(std::string(fn) + " is not a valid .mpi index"); return nullptr; }
 	const size_t flen = (size_t)st.st_size;
-	// (MAP_PRIVATE + PROT_WRITE: callers of the reference's mp_idx_t get non-const pointers; a write would copy the page, never reach the file)
-	void *base = mmap(nullptr, flen, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0);
+	// (MAP_PRIVATE + PROT_WRITE: callers of the reference's mp_idx_t get non-const pointers; a write would copy the page, never reach
+	// the file.  MAP_NORESERVE: nobody is expected to write, so the mapping must not be charged against the commit limit once per
+	// rank.  Should the mapping fail -- a file system without mmap, an address-space limit -- the file is read into memory instead.)
+	void *base = mmap(nullptr, flen, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
+	bool mapped = base != MAP_FAILED;
+	std::vector<char> *owned = nullptr;
+	if (!mapped) {
+		owned = new (std::nothrow) std::vector<char>();
+		bool got = owned != nullptr;
+		if (got) try { owned->resize(flen); } catch (const std::exception&) { got = false; }
+		size_t done = 0;
+		while (got && done < flen) { const ssize_t k = pread(fd, owned->data() + done, flen - done, (off_t)done); if (k <= 0) got = false; else done += (size_t)k; }
+		if (!got) { delete owned; close(fd); set_error(std::string("cannot map or read ") + fn); return nullptr; }
+		base = owned->data();
+	}
 	close(fd);
-	if (base == MAP_FAILED) { set_error(std::string("cannot map ") + fn); return nullptr; }
 	const char *f = (const char*)base;
 	size_t at = 0;
 	auto take = [&](void *dst, size_t bytes) -> bool { if (bytes > flen - at) return false; if (dst) memcpy(dst, f + at, bytes); at += bytes; return true; };
@@ -151,12 +163,17 @@ mpa_idx_t *mpa_idx_restore(const char *fn)
 		ok = ok && take(nullptr, (size_t)mi->n_kb * 4);
 		if (ok && off != mi->l_seq) ok = false;
 		if (ok) {
-			mi->seq.view((uint8_t*)base + seq_at, seq_bytes);
-			mi->kb.view((uint32_t*)((char*)base + kb_at), (size_t)mi->n_kb);
+			if (mapped) mi->seq.view((uint8_t*)base + seq_at, seq_bytes);
+			else { mi->seq.resize(seq_bytes); memcpy(mi->seq.data(), (const char*)base + seq_at, seq_bytes); }
+			// (the occurrence lists follow the names, whose length is arbitrary: the view may be misaligned for uint32_t -- 6 GB at
+			// 3 Gbp are not copied for that; the library reads them through IdxArray's memcpy accessors and uploads them as bytes)
+			if (mapped) mi->kb.view((uint32_t*)((char*)base + kb_at), (size_t)mi->n_kb);
+			else { mi->kb.resize((size_t)mi->n_kb); memcpy(mi->kb.data(), (const char*)base + kb_at, (size_t)mi->n_kb * 4); }
 		}
 	} catch (const std::exception&) { ok = false; }
-	if (!ok) { munmap(base, flen); set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
-	mi->map_base = base, mi->map_len = flen;
+	if (!ok) { if (mapped) munmap(base, flen); delete owned; set_error(std::string(fn) + " is not a valid .mpi index"); delete mi; return nullptr; }
+	delete owned;                                            // (read path: everything has been copied out)
+	if (mapped) mi->map_base = base, mi->map_len = flen;
 	compute_block_offsets(mi);
 	return mi;
 }

@@ -66,8 +66,8 @@ template<class T> struct IdxArray {
 	const T *data() const { return p; }
 	size_t size() const { return n; }
 	bool empty() const { return n == 0; }
-	T &operator[](size_t i) { return p[i]; }
-	const T &operator[](size_t i) const { return p[i]; }
+	T &operator[](size_t i) { return p[i]; }                 // (writes: owned storage only, which is aligned)
+	T operator[](size_t i) const { return at(i); }           // (reads go through memcpy: a view may be misaligned for T)
 	T at(size_t i) const { T v; memcpy(&v, (const char*)p + i * sizeof(T), sizeof(T)); return v; }
 	void resize(size_t k) { adopt(); own.resize(k); sync(); }
 	void resize(size_t k, T v) { adopt(); own.resize(k, v); sync(); }

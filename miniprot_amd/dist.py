@@ -162,7 +162,11 @@ def run_sharded(n_batches, rank, world, device, needs_ids, map_mine, count_fn, f
     # every rank learns whether ANY rank failed before the first collective of the gather: a rank that raised alone would leave
     # the others waiting in all_gather for ever
     if any_rank_failed(err is not None, world, device):
-        raise RuntimeError("run_sharded: mapping failed on %s" % ("this rank: %r" % (err,) if err is not None else "another rank"))
+        if err is not None and (world == 1 or rank is None):
+            raise err                                            # (a single process: the caller gets the error it caused, type and traceback)
+        if err is not None:
+            raise RuntimeError("run_sharded: mapping failed on this rank: %r" % (err,)) from err
+        raise RuntimeError("run_sharded: mapping failed on another rank")
     if not needs_ids:
         return gather_texts(mine, res, n_batches, rank, world, device), None
     counts = exchange_counts(mine, [count_fn(k, r) for k, r in zip(mine, res)], n_batches, world, device)
