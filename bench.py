@@ -155,11 +155,42 @@ class Workload:
                 per[self.batch_of[line.split(b"\t", 1)[0]]].append(line + b"\n")
         per = [b"".join(x) for x in per]
         res = aligned_residues(out)
-        rec = {"value": res / max(t_run - t_load, 1e-6), "unit": "aligned residues/s", "cores": ncpu, "kind": "reference",
+        # the same binary on ONE thread, on a bounded sample of the same protein set (the per-core rate next to the
+        # all-cores one): the first proteins of the set, about 10-20 s of CPU work
+        t1 = None
+        try:
+            n1 = max(1, min(len(self.prots), int(self.cfg.get("t1_sample", 800))))
+            sub = os.path.join(os.path.dirname(self.faa), "t1_sample.faa")
+            with open(self.faa) as f, open(sub, "w") as g:
+                k = 0
+                for line in f:
+                    if line.startswith(">"):
+                        k += 1
+                        if k > n1:
+                            break
+                    g.write(line)
+            t_load1 = timed(empty, 1)[0]
+            t_one, out1 = timed(sub, 1)
+            res1 = aligned_residues(out1)
+            t1 = {"value": res1 / max(t_one - t_load1, 1e-6), "unit": "aligned residues/s", "cores": 1,
+                  "sample": "the first %d proteins of the set, -t1, wall %.2f s minus index load %.2f s; %d residues aligned" % (n1, t_one, t_load1, res1)}
+        except Exception as e:                                       # (the one-thread figure is a courtesy: never fail the bench for it)
+            t1 = {"error": repr(e)[:200]}
+        rec = {"value": res / max(t_run - t_load, 1e-6), "unit": "aligned residues/s", "cores": ncpu, "kind": "reference", "cpu_model": cpu_model(), "one_thread": t1,
                "sample": "the whole workload: %d proteins, oracle/_ref/miniprot -t%d %s on the same .mpi; wall %.2f s minus index load %.2f s; %d residues aligned"
                          % (len(self.prots), ncpu, " ".join(self.cfg["flags"]), t_run, t_load, res),
                "wall_s": t_run, "index_load_s": t_load, "md5": hashlib.md5(out).hexdigest(), "wall_s_by_threads": {str(k): v for k, v in tried.items()}}
         return rec, per
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
 
 
 def host_cpu_seconds():
@@ -263,14 +294,26 @@ def roofline_record(st, elapsed, world):
     traffic, src = None, None
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_round.sh): a
     # profile constant measured on this workload at this mini-batch size, NOT collected in this run
-    for name, what in (("r04_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch"),
-                       ("r03_pmc_summary.json", "config 3 at full size, this mini-batch size (round 3: three DP rounds per batch)")):
+    # -- and only quoted when it was measured on THIS source of the DP kernels (the profile carries the md5 of dp_kernels.hip +
+    # dp_device.h it was collected with): counters of another kernel next to this run's timings would be a stale claim
+    cur = hashlib.md5()
+    for f in ("dp_kernels.hip", "dp_device.h"):
+        try:
+            cur.update(open(os.path.join(ROOT, "miniprot_amd", "csrc", f), "rb").read())
+        except OSError:
+            pass
+    cur = cur.hexdigest()
+    kname = "k_dp_worker" if pool else "k_dp_round"
+    for name, what in (("r05_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch"),):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
                 d = json.load(open(pmc))
-                traffic = d["kernels"]["k_dp_round"]["hbm_bytes_per_launch"]
-                src = "profiles/%s: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over %s" % (name, what)
+                if d.get("dp_kernel_source_md5") != cur:
+                    src = "profiles/%s was collected on another source of the DP kernels (md5 %s, running %s): not quoted" % (name, str(d.get("dp_kernel_source_md5"))[:8], cur[:8])
+                    continue
+                traffic = d["kernels"][kname]["hbm_bytes_per_launch"]
+                src = "profiles/%s: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over %s; kernel source md5 %s = the running library's" % (name, what, cur[:8])
                 break
             except Exception:
                 pass
@@ -448,6 +491,8 @@ def main():
                    # the host: what one GPU's pipeline costs the host it shares with the other ranks
                    "host_cpu_s_per_step": st["host_cpu_s"] / max(len(texts), 1) * nb, "host_cpu_s_per_mini_batch": st["host_cpu_s"] / max(len(texts), 1),
                    "host_cores_busy": st["host_cpu_s"] / max(elapsed, 1e-9),
+                   # what a rank's pipeline keeps busy on the host (user + system CPU seconds of its process / wall): N ranks need N x this
+                   "host_cores_busy_per_gpu": st["host_cpu_s"] / max(elapsed, 1e-9) / max(world, 1),
                    # (rank 0's cgroup: 100 ms scheduler periods in which the quota ran out, and thread-seconds spent frozen because of it)
                    "host_throttled": {"periods": st.get("throttled_periods"), "thread_seconds": st.get("throttled_s")}}
         ctx.close()
@@ -510,7 +555,7 @@ def main():
                "hbm_resident_gb": r["hbm_resident_gb"], "pool_growth_events_timed": r["pool_growth_events_timed"], "pool_growth_events_total": r["pool_growth_events_total"],
                "cli_end_to_end": r["cli_end_to_end"],
                "host_cpu_s_per_step": r["host_cpu_s_per_step"], "host_cpu_s_per_mini_batch": r["host_cpu_s_per_mini_batch"], "host_cores_busy": r["host_cores_busy"],
-               "host_throttled": r["host_throttled"],
+               "host_cores_busy_per_gpu": r["host_cores_busy_per_gpu"], "host_throttled": r["host_throttled"],
                "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "dp_cells": r["dp_cells"], "gcups_wall": r["gcups_wall"], "setup_s": r["setup_s"]}
         out.update(extra)
         print(json.dumps(out))

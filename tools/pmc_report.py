@@ -2,11 +2,19 @@
 """Derived per-kernel metrics from the merged PMC dump of tools/pmc_summary.py (gfx950 corrections of MI355X_MICROARCH.md applied
 where the guide gives one): HBM bytes per launch, LDS bank-conflict rate, VALU busy, wave residency.
     python tools/pmc_report.py pmc_all.json > pmc_summary.json"""
-import json, re, sys
+import hashlib, json, re, sys
 d = json.load(open(sys.argv[1]))
 import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def dp_kernel_source_md5():
+    """identity of the DP kernels' source (what bench.py compares before it quotes these counters next to a run)"""
+    h = hashlib.md5()
+    for f in ("dp_kernels.hip", "dp_device.h"):
+        h.update(open(os.path.join(ROOT, "miniprot_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 out = {"source": "rocprofv3 --pmc <block> --kernel-trace, one pass per counter block (tools/pmc_round.sh); workload: "
                  + os.environ.get("PMC_WORKLOAD_NOTE", "config 3 scaled x0.1 (300 Mbp x 2 000 proteins, -I -u), 3 blocking steps, MPA_DP_LANES=1"),
+       "dp_kernel_source_md5": dp_kernel_source_md5(),
        "corrections": "FETCH_SIZE x2 (gfx950 rocprofv3 tallies 128-B requests as 64 B, guide section HBM), KB units; WRITE_SIZE uncorrected; SQ_*_CYCLES in quad-cycles", "kernels": {}}
 def short(n):
     m = re.search(r"(k_[a-z0-9_]+)(ILi(\d+))?", n)
