@@ -113,6 +113,7 @@ struct DpConst {         // scalar scoring parameters, passed by value
 	int32_t go, ge, fs, xdrop, end_bonus;
 	int32_t sp[6];
 	int32_t sp_null_bonus;   // splice-score track only
+	int32_t wide_ge;         // ge or fs above 255: the records carry a stop flag instead of the row's gap extension (glob_cands<K, true>)
 };
 
 struct DevGenome {

@@ -332,10 +332,11 @@ static int ext_class_of(int32_t ncol)
 	return -1;
 }
 
-template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s)
+template<int NW> static hipError_t launch_glob_wide(const GlobArgs &a, int n_groups, hipStream_t s, bool wide_ge = false)
 {
 	const size_t lds = (size_t)NW * 22 * 64 * 2 + 2 * NW * 16 + 64 * 4;
-	hipLaunchKernelGGL((k_glob_wide<NW>), dim3(n_groups), dim3(NW * 64), lds, s, a);
+	if (wide_ge) hipLaunchKernelGGL((k_glob_wide<NW, true>), dim3(n_groups), dim3(NW * 64), lds, s, a);
+	else hipLaunchKernelGGL((k_glob_wide<NW, false>), dim3(n_groups), dim3(NW * 64), lds, s, a);
 	return hipGetLastError();
 }
 
@@ -345,14 +346,15 @@ extern "C" {
 
 // traceback classes 0,1,2 (16/32/64 lanes) and 7 (block-major, > 1024 columns) in one launch; a.waves = whole array
 // (the traceback chunks after the first, which do not ride in the round's launch)
-static hipError_t launch_glob_narrow(const GlobArgs &a, const int *first, const int *cnt, hipStream_t s)
+static hipError_t launch_glob_narrow(const GlobArgs &a, const int *first, const int *cnt, hipStream_t s, bool wide_ge = false)
 {
 	const size_t lds = (size_t)22 * 64 * 2 + (size_t)4 * 32 * 4;
 	NarrowMap m{};
 	const int cls[4] = { 0, 1, 2, 7 };
 	int total = 0;
 	for (int k = 0; k < 4; ++k) m.first[k] = first[cls[k]], m.cnt[k] = cnt[cls[k]], total += cnt[cls[k]];
-	hipLaunchKernelGGL(k_glob_narrow, dim3((unsigned)total), dim3(64), lds, s, a, m);
+	if (wide_ge) hipLaunchKernelGGL(k_glob_narrow<true>, dim3((unsigned)total), dim3(64), lds, s, a, m);
+	else hipLaunchKernelGGL(k_glob_narrow<false>, dim3((unsigned)total), dim3(64), lds, s, a, m);
 	return hipGetLastError();
 }
 
@@ -1400,10 +1402,15 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	// ---- parameter guards: outside these the packed-int16 kernels would not be bit-exact
 	int32_t max_mat = 0;
 	for (int k = 0; k < 484; ++k) max_mat = std::max<int32_t>(max_mat, opt->mat[k]);
-	if (opt->go < 0 || opt->go > 32000 || opt->ge < 0 || opt->ge > 255 || opt->fs < 0 || opt->fs > 255 || opt->xdrop < 0 || opt->xdrop > 32000 ||
-	    opt->end_bonus < 0 || opt->end_bonus > 1000) {
-		set_error("DP parameters outside the supported range (go<=32000, ge/fs<=255, 0<=xdrop<=32000)"); return MPA_ERR_UNSUPPORTED;
+	if (opt->go < 0 || opt->go > 32000 || opt->ge < 0 || opt->ge > 16000 || opt->fs < 0 || opt->fs > 16000 || opt->xdrop < 0 || opt->xdrop > 32000 ||
+	    opt->end_bonus < 0 || opt->end_bonus > 1000 || (opt->ge > 255 && opt->go + opt->ge > 32000)) {
+		set_error("DP parameters outside the supported range (go <= 32000, ge, fs <= 16000, 0 <= xdrop <= 32000, 0 <= end_bonus <= 1000)"); return MPA_ERR_UNSUPPORTED;
 	}
+	// Gap-extension / frameshift penalties above 255 (-E / -F of the reference's command line, main.c:133,136) do not fit the byte
+	// the row records give them.  Such a run keeps the records' layout -- the byte then flags a stop codon -- and sweeps every call
+	// with the kernels that read it that way (glob_cands<K, true>): the stand-alone traceback kernels and, for extension calls,
+	// the block-major one-wave sweep (k_ext_huge); the packed round kernel is not used.  Slow, exact, and nobody's default.
+	const bool wide_ge = opt->ge > 255 || opt->fs > 255;
 
 	// ---- classify, order and lay out the calls
 	std::vector<DTask> T(n);
@@ -1424,10 +1431,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.q_off = q->q_off[x.qid] + x.aa_off - q->q_off[0];     // relative to the slice uploaded below
 		t.ncol = (x.al + 7) / 8 * 8;
 		t.out_idx = (int32_t)k;
+		// (the int32 sweeps keep the striped reference's lane segments apart by offsets of 2^20 in their scans: column * ge must stay below)
+		if ((int64_t)t.ncol * opt->ge >= (1 << 19)) { set_error("DP call too wide for this gap-extension penalty (columns x ge must stay below 2^19)"); return MPA_ERR_UNSUPPORTED; }
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
 			int cls = ext_class_of(t.ncol);                        // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
 			if (ctx->no_split && cls >= 5) cls = -1;               // repeated round: no inter-workgroup hand-off (see mpa_dp_run)
+			if (wide_ge) cls = -1;
 			// The packed kernels run their gap scan on h + j*ge with saturating adds, which is only the reference's value while
 			// nothing can reach the int16 limits; calls that could (more than ~2900 columns with BLOSUM62, hence always of the
 			// "huge" class) are swept by k_ext_huge, whose int32 arithmetic clamps every operation like the reference does.
@@ -1594,6 +1604,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
 	for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
 	dc.sp_null_bonus = opt->sp_null_bonus;
+	dc.wide_ge = wide_ge ? 1 : 0;
 	DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, mi->dev[ctx->device]->spsc, mi->l_seq };
 
 	// ---- K3: per-row records and profiles
@@ -1816,7 +1827,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		ha.tasks = ctx->tasks.as<DTask>(), ha.waves = d_hw, ha.rec = ctx->rec.as<uint32_t>(), ha.prof = ctx->prof.as<int16_t>();
 		ha.tb = nullptr, ha.bnd = ctx->bnd.as<int4>(), ha.score = nullptr, ha.c = dc, ha.rowkey64 = ctx->hkey.as<unsigned long long>();
 		hipStream_t st = begin_side(true);
-		hipLaunchKernelGGL(k_ext_huge, dim3((unsigned)huge_ids.size()), dim3(64), (size_t)22 * 64 * 2 + 4 * 32 * 4, st, ha);
+		if (wide_ge) hipLaunchKernelGGL(k_ext_huge<true>, dim3((unsigned)huge_ids.size()), dim3(64), (size_t)22 * 64 * 2 + 4 * 32 * 4, st, ha);
+		else hipLaunchKernelGGL(k_ext_huge<false>, dim3((unsigned)huge_ids.size()), dim3(64), (size_t)22 * 64 * 2 + 4 * 32 * 4, st, ha);
 		HIP_TRY(hipGetLastError());
 		hipLaunchKernelGGL(k_ext_replay, dim3((unsigned)huge_ids.size()), dim3(64), 0, st, ctx->tasks.as<DTask>(), d_hlist, (int32_t)huge_ids.size(),
 		                   ctx->hkey.as<unsigned long long>(), ctx->extout.as<ExtOut>(), dc, pen);
@@ -1872,20 +1884,20 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		ga.tb = ctx->tb.as<uint16_t>();
 		// classes 0,1,2,7 share one launch ("narrow"); every wide class has its own
 		auto launch_glob_class = [&](int cls, hipStream_t st) -> hipError_t {
-			if (cls < 0) { ga.waves = d_gw; return launch_glob_narrow(ga, first, cnt, st); }
+			if (cls < 0) { ga.waves = d_gw; return launch_glob_narrow(ga, first, cnt, st, wide_ge); }
 			ga.waves = d_gw + first[cls];
 			switch (cls) {
-			case 3: return launch_glob_wide<2>(ga, cnt[cls], st);
-			case 4: return launch_glob_wide<4>(ga, cnt[cls], st);
-			case 5: return launch_glob_wide<8>(ga, cnt[cls], st);
-			default: return launch_glob_wide<16>(ga, cnt[cls], st);
+			case 3: return launch_glob_wide<2>(ga, cnt[cls], st, wide_ge);
+			case 4: return launch_glob_wide<4>(ga, cnt[cls], st, wide_ge);
+			case 5: return launch_glob_wide<8>(ga, cnt[cls], st, wide_ge);
+			default: return launch_glob_wide<16>(ga, cnt[cls], st, wide_ge);
 			}
 		};
 		HIP_TRY(hipEventRecord(ctx->ev[3], s));
 		// every launch on its own stream (next to the extension classes in the first round); the walk needs them all
 		HIP_TRY(hipEventRecord(ctx->fork_ev, s));
 		const size_t first_glob_launch = launches.size();
-		const bool in_round = ri == 0;                       // the first chunk's calls ride in the round's one launch
+		const bool in_round = ri == 0 && !wide_ge;           // the first chunk's calls ride in the round's one launch
 		const int order[5] = { 6, 5, 4, 3, -1 };
 		for (int oi = 0; oi < 5; ++oi) {
 			const int cls = order[oi];

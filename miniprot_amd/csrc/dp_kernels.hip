@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void k_prep_rows(DevGenome g, const DTask *tas
 			acc = adjust(acc, ss_at(nl - 1 - i), false);     // "acceptor"[i] <- donor entries at nl-1-i
 		}
 	}
-	rec[t.rec_off + i] = make_rec(nas * PROF_AA_STRIDE_REC, don, nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
+	// (byte 2: the row's gap extension -- fs on a stop codon, nasw-sse.c:263,370 -- or, when the penalties do not fit a byte, just the stop flag)
+	rec[t.rec_off + i] = make_rec(nas * PROF_AA_STRIDE_REC, don, c.wide_ge ? (uint32_t)(nas == 20) : nas == 20 ? (uint32_t)c.fs : (uint32_t)c.ge, acc);
 	}
 }
 
@@ -1058,14 +1059,19 @@ __device__ __forceinline__ void glob_state_init(GlobState &s, const uint32_t q0,
 // Row i (K = i mod 3) up to the choice among the states other than I: returns the key of the best of them, leaves the new D, A,
 // B, C in the state and the four "old value kept" differences (sign bit = direction bit) in dD..dC.  rcur = record of row i,
 // S = profile score of the row's amino acid in this lane's column (splat).
-template<int K>
+// WIDE: gap-extension / frameshift penalties above 255 (-E / -F of the reference's command line, main.c:133,136) do not fit the
+// record's byte: the byte then only says whether the row's codon is a stop, and the penalty (ge, or fs on a stop: nasw-sse.c:263,
+// 370) is chosen here.  Only the stand-alone traceback / block-major kernels are instantiated with it (dp_exec.hip routes every
+// call of such a run to them); the round kernel and its packed extension bodies never pay for it.
+template<int K, bool WIDE = false>
 __device__ __forceinline__ int32_t glob_cands(GlobState &s, const uint32_t rcur, const uint32_t S, const uint32_t go, const uint32_t io, const uint32_t fs,
-                                              uint32_t &dD, uint32_t &dA, uint32_t &dB, uint32_t &dC)
+                                              uint32_t &dD, uint32_t &dA, uint32_t &dB, uint32_t &dC, const uint32_t ge_wide = 0)
 {
 	constexpr int R1 = (K + 2) % 3, R2 = (K + 1) % 3, R3 = K;      // slots of rows i-1, i-2 and i-3 (the one row i overwrites)
 	s.dn[R3] = __builtin_amdgcn_perm(rcur, rcur, 0x08010801u);      // donor(i), acceptor(i): sign-extended bytes 1 and 3
 	s.ac[R3] = __builtin_amdgcn_perm(rcur, rcur, 0x09030903u);
-	const uint32_t gei = __builtin_amdgcn_perm(rcur, rcur, 0x0c020c02u);
+	uint32_t gei = __builtin_amdgcn_perm(rcur, rcur, 0x0c020c02u);
+	if (WIDE) gei = gei ? fs : ge_wide;
 	const uint32_t H1 = s.H[R1], H2 = s.H[R2], H3 = s.H[R3], H1s = s.Hs[R1], H2s = s.Hs[R2], H3s = s.Hs[R3];
 	const uint32_t M = p_adds(H3s, S);
 	uint32_t u = p_subs(H3, go), tt;
@@ -1088,7 +1094,7 @@ __device__ __forceinline__ int32_t glob_cands(GlobState &s, const uint32_t rcur,
 // kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
 // per-row key (best H + end bonus, first column) that k_ext_replay consumes.
 #define GLOB_NARROW_LDS ((size_t)22 * 64 * 2 + (size_t)4 * 32 * 4)   /* bytes per wave */
-template<int G, bool MB, bool EXT = false>
+template<int G, bool MB, bool EXT = false, bool WIDE = false>
 __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv, const WavePos wp)
 {
 	constexpr int NG = 64 / G;
@@ -1139,7 +1145,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 
 		GlobState gs;
 		glob_state_init(gs, ring[0], ring[1], first_blk && col == 0, fs);
-		const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs);
+		const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs), ge_s = splat16(ge);
 		const char *profb = (const char*)myprof;                // + byte0(record) * G = this lane's score for the row's amino acid
 		uint32_t r[3];                                          // records of rows i, i+1 (and, once fetched, i+2) at slot row mod 3
 		r[2] = ring[2], r[0] = ring[3], r[1] = 0;
@@ -1163,7 +1169,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 
 			// candidates other than I
 			uint32_t dD, dA, dB, dC;
-			const int32_t knon = glob_cands<K>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC);
+			const int32_t knon = glob_cands<K, WIDE>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC, ge_s);
 			const int32_t nonI = knon >> 16;
 			// first-pass I: the chain restarts at every lane start of the striped reference (segments of slen columns)
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
@@ -1220,26 +1226,28 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 }
 
 // one launch for the narrow traceback shapes (classes 16 / 32 / 64 lanes and the block-major one), see k_ext_narrow
+template<bool WIDE>
 __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 {
 	int b = blockIdx.x;
 	extern __shared__ uint32_t lds_raw[];
 	const WavePos wp = whole_block((char*)lds_raw);
-	if (b < m.cnt[0]) { glob_narrow<16, false>(a, a.waves[m.first[0] + b], wp); return; }
+	if (b < m.cnt[0]) { glob_narrow<16, false, false, WIDE>(a, a.waves[m.first[0] + b], wp); return; }
 	b -= m.cnt[0];
-	if (b < m.cnt[1]) { glob_narrow<32, false>(a, a.waves[m.first[1] + b], wp); return; }
+	if (b < m.cnt[1]) { glob_narrow<32, false, false, WIDE>(a, a.waves[m.first[1] + b], wp); return; }
 	b -= m.cnt[1];
-	if (b < m.cnt[2]) { glob_narrow<64, false>(a, a.waves[m.first[2] + b], wp); return; }
+	if (b < m.cnt[2]) { glob_narrow<64, false, false, WIDE>(a, a.waves[m.first[2] + b], wp); return; }
 	b -= m.cnt[2];
-	glob_narrow<64, true>(a, a.waves[m.first[3] + b], wp);
+	glob_narrow<64, true, false, WIDE>(a, a.waves[m.first[3] + b], wp);
 }
 
 // Extension calls wider than 1024 columns: one wave per call, 64-column blocks swept one after the other (each all rows),
 // boundary records through HBM, per-row keys combined across blocks with 64-bit atomic maxima.
+template<bool WIDE>
 __global__ __launch_bounds__(64) void k_ext_huge(GlobArgs a)
 {
 	extern __shared__ uint32_t lds_raw[];
-	glob_narrow<64, true, true>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
+	glob_narrow<64, true, true, WIDE>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
 }
 
 // nasw-sse.c:423-443 replayed over per-row keys ((row max + 32768) << 32 | ~column): best row under the length penalty,
@@ -1304,7 +1312,7 @@ __global__ __launch_bounds__(64) void k_ext_replay(const DTask *tasks, const int
 // the block-major passes of the narrow kernel collapse into one sweep of nl + NW steps.
 // ------------------------------------------------------------------------------------------------
 #define GLOB_WIDE_LDS(NW) ((size_t)(NW) * 22 * 64 * 2 + 2 * (NW) * 16 + 64 * 4)   /* bytes per group */
-template<int NW>
+template<int NW, bool WIDE = false>
 __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave &wv, const WavePos wp)
 {
 	constexpr int G = 64;
@@ -1343,7 +1351,7 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 
 	GlobState gs;
 	glob_state_init(gs, ring[0], ring[1], first_blk && lane == 0, fs);
-	const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs);
+	const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs), ge_s = splat16(ge);
 	const char *profb = (const char*)myprof;
 	uint32_t rcur = ring[2];
 	const bool carry_src = seg_start && gc >= slen;              // lanes that feed the carry scan
@@ -1364,7 +1372,7 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 			if (!first_blk) bin = xB[(par ^ 1) * NW + w - 1];
 			const int32_t Hb = lo16((uint32_t)bin.z), h1b = hi16((uint32_t)bin.z), I1b = bin.w;
 			uint32_t dD, dA, dB, dC;
-			const int32_t knon = glob_cands<K>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC);
+			const int32_t knon = glob_cands<K, WIDE>(gs, rcur, S, go_s, io_s, fs_s, dD, dA, dB, dC, ge_s);
 			const int32_t nonI = knon >> 16;
 			const int32_t py = scan_max_i32<G>(nonI + yoff);
 			int32_t pex = shift1_i32<G>(py, NEG32, lane);
@@ -1406,11 +1414,11 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 	if (nl < 3 && wp.tg == 0) a.score[tid] = NEG16;
 }
 
-template<int NW>
+template<int NW, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 {
 	extern __shared__ uint32_t lds_raw[];
-	glob_wide_body<NW>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
+	glob_wide_body<NW, WIDE>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
 }
 
 // ------------------------------------------------------------------------------------------------

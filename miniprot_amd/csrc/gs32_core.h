@@ -30,7 +30,7 @@ namespace mpa {
 
 #define GS32_NEG (-0x40000000)
 
-struct Gs32Params { int32_t go, ge, io, fs; };
+struct Gs32Params { int32_t go, ge, io, fs; int32_t wide_ge = 0; };   // wide_ge: the record's byte 2 is a stop flag, not the row's gap extension (dp_device.h DpConst)
 // int32[W] each, W = 4 * ceil(al / 4): H rows i, i-1, i-2, i-3 (slot = row & 3), D rows (slot = row % 3, updated in place), A, B, C
 // (in place), the best non-I state of the row, the first-pass I of the row; uint16[W]: the row's traceback words
 struct Gs32Scratch { int32_t *H[4], *D[3], *A, *B, *C, *hn, *I1; uint16_t *zw; };
@@ -76,7 +76,7 @@ MPA_HD inline int32_t gs32_sweep(const Gs32Params p, const int32_t nl, const int
 		const int32_t *H1 = S.H[(i - 1) & 3], *H2 = S.H[(i - 2) & 3], *H3 = S.H[(i - 3) & 3];
 		int32_t *Hn = S.H[i & 3], *Dn = S.D[i % 3];
 		const uint32_t r0 = rec[i], r1 = rec[i - 1], r2 = rec[i - 2];
-		const int32_t aa = (int32_t)(r0 & 0xff) >> 1, gei = (int32_t)((r0 >> 16) & 0xff);
+		const int32_t aa = (int32_t)(r0 & 0xff) >> 1, gei_b = (int32_t)((r0 >> 16) & 0xff), gei = p.wide_ge ? (gei_b ? fs : ge) : gei_b;
 		const int32_t dip1 = (int8_t)(r0 >> 8), di = (int8_t)(r1 >> 8), dim1 = (int8_t)(r2 >> 8);
 		const int32_t ai = (int8_t)(r0 >> 24), aim1 = (int8_t)(r1 >> 24), aim2 = (int8_t)(r2 >> 24);
 		// column -1 (NS_GEN_INIT1 for row 2, NS_GEN_INIT2 afterwards: lane 0 of the shifted-in vector is -infinity)

@@ -34,9 +34,10 @@ extern "C" int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt
 		if (n > (1 << 20)) { set_error("mpa_dp_run32: at most 2^20 calls per batch"); return MPA_ERR_ARG; }
 		// the sweep's arithmetic wraps like the reference's _mm_add/_sub_epi32; these bounds keep everything far from wrapping
 		// (|H| <= 2^30 + al * 127 + nl * 2^20) and make the closed form of the gap chain valid (go >= 0)
-		if (opt->go < 0 || opt->go > (1 << 20) || opt->ge < 0 || opt->ge > 255 || opt->fs < 0 || opt->fs > 255) {
-			set_error("32-bit DP parameters outside the supported range (0 <= go <= 2^20, ge/fs <= 255)"); return MPA_ERR_UNSUPPORTED;
+		if (opt->go < 0 || opt->go > (1 << 20) || opt->ge < 0 || opt->ge > (1 << 20) || opt->fs < 0 || opt->fs > (1 << 20)) {
+			set_error("32-bit DP parameters outside the supported range (0 <= go, ge, fs <= 2^20)"); return MPA_ERR_UNSUPPORTED;
 		}
+		const int32_t wide_ge = opt->ge > 255 || opt->fs > 255;   // the records then carry a stop flag in place of the row's gap extension
 		HIP_TRY(hipSetDevice(ctx->device));
 		hipStream_t s = ctx->stream;
 		std::vector<DTask> T((size_t)n);
@@ -90,12 +91,13 @@ extern "C" int mpa_dp_run32(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt
 		dc.go = opt->go, dc.ge = opt->ge, dc.fs = opt->fs, dc.xdrop = opt->xdrop, dc.end_bonus = opt->end_bonus;
 		for (int k = 0; k < 6; ++k) dc.sp[k] = opt->sp[k];
 		dc.sp_null_bonus = opt->sp_null_bonus;
+		dc.wide_ge = wide_ge;
 		DevGenome dg{ mi->dev[ctx->device]->seq, mi->dev[ctx->device]->ctg_off, mi->dev[ctx->device]->ctg_len, mi->dev[ctx->device]->spsc, mi->l_seq };
 		if (!chunks.empty())
 			hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)chunks.size()), dim3(256), 0, s, dg, ctx->tasks.as<DTask>(), ctx->chunks.as<PrepChunk>(), ctx->rec.as<uint32_t>(), dc, tabs);
 		hipLaunchKernelGGL(k_prep_prof, dim3((unsigned)n), dim3(256), 0, s, ctx->tasks.as<DTask>(), ctx->qseq.as<char>(), ctx->prof.as<int16_t>(), tabs);
 		hipLaunchKernelGGL(k_gs32, dim3((unsigned)n), dim3(64), 0, s, ctx->tasks.as<DTask>(), (int32_t)n, ctx->rec.as<uint32_t>(), ctx->prof.as<int16_t>(),
-		                   ctx->bnd.as<int32_t>(), ctx->tb.as<uint16_t>(), ctx->score.as<int32_t>(), Gs32Params{ opt->go, opt->ge, 0, opt->fs });
+		                   ctx->bnd.as<int32_t>(), ctx->tb.as<uint16_t>(), ctx->score.as<int32_t>(), Gs32Params{ opt->go, opt->ge, 0, opt->fs, wide_ge });
 		if (!walk.empty())
 			hipLaunchKernelGGL(k_backtrack, dim3((unsigned)walk.size()), dim3(64), 0, s, ctx->tasks.as<DTask>(), ctx->list.as<int32_t>(), (int32_t)walk.size(),
 			                   ctx->tb.as<uint16_t>(), ctx->cig.as<uint32_t>(), ctx->ncig.as<int32_t>());

@@ -149,7 +149,11 @@ def test_relinked_cli_is_a_drop_in(tmp_path):
     gen_synth.write_fasta_aa(faa, prots, names)
     mpi = str(tmp_path / "g.mpi")
     _run([CLI, "-t4", "-d", mpi, fa])
-    for flags in (["-u"], ["-u", "-I", "--gtf"], ["-u", "--gff", "--outs=0.5", "-N", "50", "-K", "3k"], ["-u", "-S"], ["-u", "-T", "4", "--aln", "--trans"]):
+    # (-E above 255: the reference takes any integer, main.c:133 -- the run is swept by the kernels that keep a stop flag in the row
+    # records' byte; -F is held to an int8 by the reference itself, options.c:26, so a frameshift penalty above 255 can only arrive
+    # through the operator, ns_opt_t: tests/test_dp_gpu.py)
+    for flags in (["-u"], ["-u", "-I", "--gtf"], ["-u", "--gff", "--outs=0.5", "-N", "50", "-K", "3k"], ["-u", "-S"], ["-u", "-T", "4", "--aln", "--trans"],
+                  ["-u", "-E", "300"], ["-u", "-E", "260", "-O", "9"]):     # (with -F 60..100 next to -E 260 the reference aborts in its own mp_extra_cal assertion -- and so does this)
         src = [fa] if "-T" in flags else [mpi]                      # (-T changes the index: build it from the FASTA)
         assert _run([CLI, "-t8"] + flags + src + [faa]) == _run([refbind.REF_BIN, "-t8"] + flags + src + [faa]), " ".join(flags)
 

@@ -67,6 +67,32 @@ def test_xdrop_and_params(ctx, oracle_built):
         run_case(ctx, pairs, P, rng)
 
 
+def test_gap_extension_and_frameshift_penalties_above_255(ctx, oracle_built):
+    """-E / -F of the reference's command line accept any integer (main.c:133,136); above 255 the penalties do not fit the byte the
+    row records give them and the run is swept by the kernels that read that byte as a stop flag (glob_cands<K, true>, k_ext_huge).
+    Checked against the oracle and, where it is built, against the reference's own ns_global_gs16b."""
+    rng = np.random.default_rng(21)
+    for (go, ge, fs) in [(11, 300, 23), (11, 1, 400), (7, 260, 1000), (11, 2, 256), (9, 260, 100)]:
+        P = refbind.DpParams(refbind.mapping_matrix(min(fs, 127)), go=go, ge=ge, io=29, fs=fs, xdrop=100, end_bonus=5)
+        pairs = [make_task(rng, flank=200) for _ in range(60)] + [make_task(rng, al=al, p_indel=0.0) for al in (8, 33, 70, 130, 300)]
+        pairs += [make_task(rng, max_intron=3000, flank=2000) for _ in range(20)]
+        contigs, queries, tasks, meta = build_workload(pairs, rng, io=P.io)
+        idx = mpa.Index.from_nt4(contigs)
+        idx.to_device(ctx)
+        rst, cig = mpa.dp_run(ctx, idx, dpopt_from_params(P), queries, tasks)
+        idx.close()
+        bad, msg = compare(rst, cig, oracle_eval(pairs, meta, P), meta, pairs)
+        assert not bad, "go %d ge %d fs %d: %d/%d DP calls differ from the oracle\n%s" % (go, ge, fs, len(bad), len(tasks), msg)
+        if refbind.have_ref():
+            expect = []
+            for k, fl, io in meta:
+                nt, aa = pairs[k]
+                PP = refbind.DpParams(P.mat, go=P.go, ge=P.ge, io=io, fs=P.fs, xdrop=P.xdrop, end_bonus=P.end_bonus, sp=P.sp, sp_null_bonus=P.sp_null_bonus, ie_coef=P.ie_coef)
+                expect.append(refbind.ref_nasw(nt, aa, PP, fl))
+            bad, msg = compare(rst, cig, expect, meta, pairs)
+            assert not bad, "go %d ge %d fs %d: %d/%d DP calls differ from the REFERENCE\n%s" % (go, ge, fs, len(bad), len(tasks), msg)
+
+
 def test_traceback_rounds(ctx, oracle_built, monkeypatch):
     """force several k_glob rounds by shrinking the traceback budget"""
     monkeypatch.setenv("MPA_TB_BUDGET_MB", "1")
