@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <functional>
 #include <mutex>
+#include <thread>
 #include <atomic>
 #include <cstring>
 #include <cstdlib>
@@ -67,7 +68,7 @@ struct DevBuf {
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases -- but slack and hint
 		// are wishes: when the device cannot give that much, the bare request is tried before the call fails)
 		size_t want = bytes;
-		want += want / 3 + 4096;
+		want += std::max<size_t>(want / 8, std::min<size_t>(want / 3, (size_t)256 << 20)) + 4096;   // a third of slack up to 256 MB, an eighth beyond (round 4: every pool carried a third: 100 GB per rank)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b - (free_b >> 4)) want = asked + 4096;
 		hipError_t e = hipMalloc(&p, want);
@@ -221,6 +222,41 @@ static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 	}
 }
 
+// A large host array into device memory.  The index arrays are views into the mapped .mpi (page cache) or pageable vectors: a
+// plain hipMemcpy stages them through the runtime's own bounce buffer on ONE thread (measured, round 4: the 7.6 GB of a 3 Gbp
+// index cost most of the 4.3 s a cold command-line run spends before it maps anything).  Here four host threads copy 32-MB slices
+// into two pinned buffers in turn while the DMA engine drains the other one.
+static hipError_t upload_large(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+	const size_t kSlice = (size_t)32 << 20;
+	if (bytes < 4 * kSlice) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+	void *pin[2] = { nullptr, nullptr };
+	hipEvent_t done[2] = { nullptr, nullptr };
+	hipError_t e = hipSuccess;
+	for (int k = 0; k < 2 && e == hipSuccess; ++k) { e = hipHostMalloc(&pin[k], kSlice, hipHostMallocDefault); if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming); }
+	if (e == hipSuccess) {
+		const int kThreads = 4;
+		size_t at = 0;
+		for (int k = 0; at < bytes && e == hipSuccess; ++k, at += kSlice) {
+			const int b = k & 1;
+			const size_t n = std::min(kSlice, bytes - at);
+			if (k >= 2) e = hipEventSynchronize(done[b]);              // the copy that last used this buffer has left it
+			if (e != hipSuccess) break;
+			std::thread th[kThreads];
+			const size_t part = (n + kThreads - 1) / kThreads;
+			for (int t = 0; t < kThreads; ++t)
+				th[t] = std::thread([=] { const size_t o = (size_t)t * part; if (o < n) memcpy((char*)pin[b] + o, (const char*)src + at + o, std::min(part, n - o)); });
+			for (auto &t : th) t.join();
+			e = hipMemcpyAsync((char*)dst + at, pin[b], n, hipMemcpyHostToDevice, s);
+			if (e == hipSuccess) e = hipEventRecord(done[b], s);
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+	}
+	for (int k = 0; k < 2; ++k) { if (done[k]) (void)hipEventDestroy(done[k]); if (pin[k]) (void)hipHostFree(pin[k]); }
+	if (e != hipSuccess) { (void)hipGetLastError(); return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }   // (no pinned memory to be had: the plain copy)
+	return hipSuccess;
+}
+
 // The seeding / refinement kernels of a context run on a stream of their own, created with the device's highest priority: they are
 // short and a pipeline stage waits for each of them (MPA_PRIO_SEED=0: normal priority; MPA_PRIO_MAIN=1: the contexts' main streams
 // -- the DP lanes' prep kernels, walks and copies -- get the high priority too).
@@ -250,7 +286,7 @@ int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 	HIP_TRY(hipMalloc((void**)&d->seq, mi->seq.size() + 16));
 	HIP_TRY(hipMalloc((void**)&d->ctg_off, n * 8 + 8));
 	HIP_TRY(hipMalloc((void**)&d->ctg_len, n * 8 + 8));
-	HIP_TRY(hipMemcpy(d->seq, mi->seq.data(), mi->seq.size(), hipMemcpyHostToDevice));
+	{ const double t0 = now_ms(); HIP_TRY(upload_large(d->seq, mi->seq.data(), mi->seq.size(), ctx->stream)); timing_note("index upload: packed genome", now_ms() - t0); }
 	HIP_TRY(hipMemcpy(d->ctg_off, off.data(), n * 8, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(d->ctg_len, len.data(), n * 8, hipMemcpyHostToDevice));
 	if (!mi->spsc.empty()) {
@@ -384,7 +420,6 @@ mpa_ctx_t *mpa_ctx_create(int device)
 	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 	bool ok = (main_high ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) == hipSuccess;
 	for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-	for (auto &st : ctx->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
 	for (auto &e : ctx->lev) ok = ok && hipEventCreate(&e) == hipSuccess;
 	ok = ok && hipEventCreate(&ctx->fork_ev) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
@@ -798,7 +833,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 		if (!d->kb) {
 			uint32_t *p = nullptr;
 			HIP_TRY(hipMalloc((void**)&p, mi->kb.size() * 4 + 16));
-			HIP_TRY(hipMemcpy(p, mi->kb.data(), mi->kb.size() * 4, hipMemcpyHostToDevice));
+			{ const double t0 = now_ms(); HIP_TRY(upload_large(p, mi->kb.data(), mi->kb.size() * 4, ctx->stream)); timing_note("index upload: occurrence lists", now_ms() - t0); }
 			d->kb = p, d->kb_bytes = mi->kb.size() * 4 + 16;
 			g_dev_bytes += (long long)d->kb_bytes;
 		}
@@ -1627,13 +1662,17 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	const int n_streams = mpa_ctx_s::kSide;
 	auto begin_side = [&](bool is_ext) -> hipStream_t {
 		const int k = n_side++;
-		hipStream_t st = ctx->side[(k + ctx->side_off) % n_streams];
+		// (side streams are created when first used: HIP deals hardware queues to streams in creation order, and sixteen idle side
+		// streams per context pushed the main streams of later contexts onto queues that other contexts' long kernels were using)
+		hipStream_t &slot = ctx->side[(k + ctx->side_off) % n_streams];
+		if (!slot && hipStreamCreateWithFlags(&slot, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; }
+		hipStream_t st = slot ? slot : s;
 		(void)hipStreamWaitEvent(st, ctx->fork_ev, 0);
 		(void)hipEventRecord(ctx->lev[2 * k], st);
 		launches.push_back(Launch{ k, is_ext });
 		return st;
 	};
-	auto end_side = [&]() { const int k = launches.back().side; (void)hipEventRecord(ctx->lev[2 * k + 1], ctx->side[(k + ctx->side_off) % n_streams]); };
+	auto end_side = [&]() { const int k = launches.back().side; hipStream_t st = ctx->side[(k + ctx->side_off) % n_streams]; (void)hipEventRecord(ctx->lev[2 * k + 1], st ? st : s); };
 
 	// ---- K1: extension calls
 	ExtArgs ea;
