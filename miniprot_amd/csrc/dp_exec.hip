@@ -586,6 +586,14 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	const int64_t *d_qfirst = (const int64_t*)dm, *d_jfirst = (const int64_t*)(dm + off_jf), *d_sfirst = (const int64_t*)(dm + off_sf);
 	const SiftSeg *d_segs = (const SiftSeg*)(dm + off_seg);
 	const int32_t *d_qseg = (const int32_t*)(dm + off_qs);
+	// (MPA_SIFT_CAP=2048, measurement: ranges of half the size need 18 KB of LDS instead of 37 KB -- a workgroup then fits next to
+	// four DP workgroups on a CU -- and touch the lists twice as often)
+	static const int sift_cap = [] { const char *e = getenv("MPA_SIFT_CAP"); return e ? atoi(e) : 4096; }();
+	if (sift_cap == 2048)
+		hipLaunchKernelGGL(k_seed_sift<2048>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
+		                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
+		                   B.s_flag.as<int32_t>());
+	else
 	hipLaunchKernelGGL(k_seed_sift<4096>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
 	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
 	                   B.s_flag.as<int32_t>());
@@ -1152,7 +1160,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	int64_t n_pos = 0, n_chunk = 0, wg_total = 0;
 	for (int64_t k = 0; k < n_win; ++k) {
 		if (wins[k].len >= (1 << 22)) { set_error("device refinement: a window longer than 2^22 bases"); return MPA_ERR_UNSUPPORTED; }
-		n_pos += wins[k].len, n_chunk += (wins[k].len + REFINE_CHUNK - 1) / REFINE_CHUNK;
+		n_pos += wins[k].len, n_chunk += (wins[k].len + REFINE_SUPER * REFINE_CHUNK - 1) / (REFINE_SUPER * REFINE_CHUNK);   // (a workgroup sweeps REFINE_SUPER chunks of its window)
 	}
 	if (n_chunk == 0) return MPA_OK;
 	const unsigned long long cap = (unsigned long long)(n_pos / 64 + (1 << 20));
@@ -1172,7 +1180,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 		int64_t c = 0;
 		for (int64_t k = 0; k < n_win; ++k) {
 			dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
-			for (int32_t st = 0; st < wins[k].len; st += REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
+			for (int32_t st = 0; st < wins[k].len; st += REFINE_SUPER * REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
 			wg[k] = wg_total;
 			wg_total += G.qg_first[(size_t)wins[k].qid + 1] - G.qg_first[(size_t)wins[k].qid];
 		}

@@ -1414,12 +1414,13 @@ static int mpa_map_batches_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_m
 	// (MPA_PLANNERS, default 2).  The seeder's own streams and buffers, one set per batch that can be between seeding and
 	// the end of planning: the result of batch k is consumed while batches k+1 .. are on the device.
 	// (round 3: with the whole refinement on the device a planner mostly waits for it -- three of them, a third of the threads each)
-	int n_plan = 3;
+	// (round 5, once the contexts' idle side streams no longer took hardware queues away: four planners and three seeders, +5 %)
+	int n_plan = 4;
 	if (const char *e = getenv("MPA_PLANNERS")) n_plan = atoi(e);
 	n_plan = std::max(1, std::min(n_plan, 6));
 	// Seeders: the device-seeding stage of a batch is mostly waiting for its kernels, which share the GPU with the DP rounds in
 	// flight; two batches are seeded side by side (MPA_SEEDERS, default 2)
-	int n_seed = 2;
+	int n_seed = 3;
 	if (const char *e = getenv("MPA_SEEDERS")) n_seed = atoi(e);
 	n_seed = std::max(1, std::min(n_seed, 4));
 	// Depth of the pipeline.  A seeding context is busy from the start of a batch's seeding to the end of its planning, and a

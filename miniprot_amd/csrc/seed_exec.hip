@@ -909,6 +909,7 @@ struct RefineChunk { int32_t win, start; };
 struct RefineTab { uint8_t t[64]; };                  // codon -> reduced residue (ns_tab_codon13), 0xff for a stop codon
 #define REFINE_CHUNK 2048
 #define REFINE_HALO 112
+#define REFINE_SUPER 1                                      /* chunks of one window a workgroup of k_refine_scan_map sweeps (8: measured 10.9 ms against 9.0 alone -- building the map is not what the scan waits for) */
 
 __device__ __forceinline__ uint32_t d_hash32_mask(uint32_t key, uint32_t mask)     // mp_hash32_mask (sketch.c:7-16)
 {
@@ -1023,10 +1024,28 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	const int64_t off = g.ctg_off[cid], clen = g.ctg_len[cid];
 	if (threadIdx.x < 64) tab[threadIdx.x] = rt.t[threadIdx.x];
 	for (int k = threadIdx.x; k < HS; k += 256) tkey[k] = 0xffffffffu;
+	__syncthreads();
+	// the query's k-mer map, once per workgroup; a workgroup sweeps REFINE_SUPER consecutive chunks of its window
+	const int64_t G0 = gr.qg_first[w.qid], G1 = gr.qg_first[w.qid + 1];
+	for (int64_t k = G0 + threadIdx.x; k < G1; k += 256) {
+		const uint32_t word = gr.gword[k];
+		uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);
+		for (;;) {
+			const uint32_t old = atomicCAS(&tkey[slot], 0xffffffffu, word);
+			if (old == 0xffffffffu) { tval[slot] = (uint32_t)(k - G0); break; }     // (the groups' words are distinct)
+			slot = (slot + 1) & (HS - 1);
+		}
+	}
+	__syncthreads();
+	const uint32_t mask = (1u << (4 * kmer)) - 1;
+	auto codon_at = [&](int e) -> uint32_t { return cod[e]; };
+	const int64_t wc0 = wg_first[ch.win];
+	for (int32_t cstart = ch.start; cstart < w.len && cstart < ch.start + REFINE_SUPER * REFINE_CHUNK; cstart += REFINE_CHUNK) {
+	if (cstart != ch.start) __syncthreads();                    // (the scan of the chunk before has finished with base[] and cod[])
 	// the chunk's bases and its halo, sixteen per thread from three aligned words of the packed genome (a byte load per base before)
 	static_assert((REFINE_CHUNK + 2 * REFINE_HALO) % 16 == 0, "chunk + halo must be a multiple of 16");
 	for (int k = threadIdx.x * 16; k < REFINE_CHUNK + 2 * REFINE_HALO; k += 256 * 16) {
-		const int64_t p = (int64_t)ch.start - REFINE_HALO + k;         // window position of base[k]
+		const int64_t p = (int64_t)cstart - REFINE_HALO + k;         // window position of base[k]
 		const int64_t x = w.as + p;                                    // strand position
 		const uint64_t nib = packed_window16(g.seq, g.l_seq, rev ? off + clen - 1 - x : off + x, rev ? -1 : 1, rev);
 		uint32_t o[4];
@@ -1055,24 +1074,11 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 		}
 		cod[e] = (uint8_t)c;
 	}
-	const int64_t G0 = gr.qg_first[w.qid], G1 = gr.qg_first[w.qid + 1];
-	for (int64_t k = G0 + threadIdx.x; k < G1; k += 256) {
-		const uint32_t word = gr.gword[k];
-		uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);
-		for (;;) {
-			const uint32_t old = atomicCAS(&tkey[slot], 0xffffffffu, word);
-			if (old == 0xffffffffu) { tval[slot] = (uint32_t)(k - G0); break; }     // (the groups' words are distinct)
-			slot = (slot + 1) & (HS - 1);
-		}
-	}
 	__syncthreads();
-	const uint32_t mask = (1u << (4 * kmer)) - 1;
-	auto codon_at = [&](int e) -> uint32_t { return cod[e]; };
-	const int64_t wc0 = wg_first[ch.win];
 	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
-		const int32_t pos = ch.start + t * 256 + (int32_t)threadIdx.x;
+		const int32_t pos = cstart + t * 256 + (int32_t)threadIdx.x;
 		if (pos >= w.len) continue;
-		const int e = pos - ch.start + REFINE_HALO;
+		const int e = pos - cstart + REFINE_HALO;
 		uint32_t word = 0;
 		bool ok = true;
 		for (int c = kmer - 1; c >= 0; --c) {
@@ -1096,6 +1102,7 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 		const unsigned long long at = atomicAdd(n_hits, 1ULL);
 		if (at < cap) hits[at] = make_uint4((uint32_t)ch.win, (uint32_t)pos, (uint32_t)(G0 + grp), grp);
 		atomicAdd(&wcnt[wc0 + grp], 1u);
+	}
 	}
 }
 
