@@ -158,3 +158,38 @@ def test_gene_families_with_thirty_secondaries(ctx, tmp_path):
     fam_lines = [l for l in ours.split(b"\n") if l.startswith(b"fam")]
     assert len(fam_lines) >= 16 * 8, "the families did not produce their secondaries (%d lines)" % len(fam_lines)
     idx.close()
+
+
+def test_a_contig_longer_than_2_31_bases(ctx, tmp_path):
+    """One contig of 2.4 Gbp (the reference carries contig offsets and positions as 64-bit integers: ntseq.c, NEWS.md "contigs
+    longer than 2 Gbp"): genes planted on both sides of base 2^31, the k-mer table built on the GPU, the .mpi dumped for the
+    reference to restore.  Every byte equals the reference's, and hits do lie beyond 2^31."""
+    import miniprot_amd.synth as synth
+    rng = np.random.default_rng(2031)
+    L, piece = 2_400_000_000, 300_000_000
+    g = np.concatenate([rng.choice(4, size=piece, p=[0.295, 0.205, 0.205, 0.295]).astype(np.uint8) for _ in range(L // piece)])
+    prots, names = [], []
+    starts = [100_000_000, 900_000_000, 2_000_000_000, 2_147_400_000, 2_147_483_000, 2_150_000_000, 2_200_000_000, 2_300_000_000, 2_390_000_000]
+    for k, st in enumerate(starts * 3):
+        st += 30_000_000 * (k // len(starts))
+        if st + 400_000 > L:
+            st = L - 500_000 - 1000 * k
+        prot, gene = synth.make_gene(rng, int(max(80, rng.normal(380, 120))), 8.0, 1.5, 70, 60000, 1)
+        rev = rng.random() < 0.5
+        seg = synth.COMP[gene[::-1]] if rev else gene
+        g[st:st + len(seg)] = seg
+        prots.append(synth.mutate(rng, prot))
+        names.append("q%02d_%s_%d" % (k, "-" if rev else "+", st))
+    idx = mpa.Index.from_nt4([g], ["chrBig"])
+    del g
+    assert idx.build_kmers(n_threads=min(64, NCPU), ctx=ctx) in ("gpu", "host")
+    idx.to_device(ctx)
+    mo = mpa.default_mapopt()
+    mo.flag |= 4
+    mpa.lib().mpa_mapopt_set_max_intron(C.byref(mo), idx.genome_len())
+    ours = b"".join(mpa.map_batches(ctx, idx, mo, [mpa.Queries(prots, names)], min(32, NCPU)))
+    ref = _reference(tmp_path, idx, prots, names, ["-I", "-u"])
+    assert ours == ref, _first_difference(ours, ref)
+    beyond = [l for l in ours.split(b"\n") if l and l.split(b"\t")[5] == b"chrBig" and int(l.split(b"\t")[7]) > (1 << 31)]
+    assert len(beyond) >= 8, "no hit beyond base 2^31"
+    idx.close()
