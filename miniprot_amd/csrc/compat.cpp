@@ -96,11 +96,29 @@ int default_device()
 }
 std::mutex g_mu;                     // guards the shared context and index uploads
 mpa_ctx_t *g_ctx = nullptr;
+std::vector<mpa_ctx_t*> g_file_ctx;
+// The contexts of the reference-signature entry points live as long as the process (the reference's API has no shutdown call).
+// What their teardown costs at exit is measured here when MPA_TIMING is set (a 100-GB set of device pools, pinned staging,
+// a dozen contexts' streams); MPA_FAST_EXIT=1 leaves all of it to the kernel: stdio is flushed and the process ends with
+// _exit() -- for command-line use where nothing else is registered to run at exit.
+void at_exit(int status, void*)
+{
+	const char *fast = getenv("MPA_FAST_EXIT");
+	if (fast && atoi(fast) != 0) { fflush(nullptr); _exit(status); }
+	if (!timing_on()) return;
+	const double t0 = now_ms();
+	for (mpa_ctx_t *c : g_file_ctx) if (c != g_ctx) mpa_ctx_destroy(c);
+	if (g_ctx) mpa_ctx_destroy(g_ctx);
+	g_file_ctx.clear(), g_ctx = nullptr;
+	fprintf(stderr, "[mpa-timing] at exit: device contexts destroyed in %.1f ms (then the HIP runtime's own teardown)\n", now_ms() - t0);
+}
 mpa_ctx_t *shared_ctx()
 {
 	if (!g_ctx) {
 		g_ctx = mpa_ctx_create(default_device());
 		if (!g_ctx) die("no usable HIP device (there is no CPU fallback)");
+		static bool hooked = false;
+		if (!hooked) hooked = true, on_exit(at_exit, nullptr);
 	}
 	return g_ctx;
 }
@@ -109,7 +127,6 @@ mpa_ctx_t *shared_ctx()
 // MPA_DEVICES = "all" (default), a count ("4": devices 0..3) or a list ("0,2,5"; a device may be named twice: two pipelines on
 // it -- how the single-GPU tests exercise this path).  MPA_DEVICE alone (the device of mp_map / ns_global_gs16b) keeps the file
 // mapper on that one device.
-std::vector<mpa_ctx_t*> g_file_ctx;
 const std::vector<mpa_ctx_t*> &file_ctxs()             // caller holds g_mu
 {
 	if (!g_file_ctx.empty()) return g_file_ctx;

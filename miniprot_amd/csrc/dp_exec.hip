@@ -64,6 +64,9 @@ struct DevBuf {
 		// mapped)
 		if (p) { (void)hipFree(p); g_dev_bytes -= (long long)cap; ++g_pool_growths; }
 		p = nullptr, cap = 0;
+		// (round 5 tried an arena -- a few 8-GB chunks carved up on the host instead of ~180 hipMallocs in a cold run's first second:
+		// no gain, the cost of a cold start is the VOLUME of device memory the driver maps, ~100 GB in ~2.5 s, however it is asked for:
+		// profiles/r05_cli_cold_start.txt)
 		// (generous: growing a pool is a hipFree, which waits for the whole device and stalls every pipeline stage; the batches of a
 		// job are alike, so a third of slack makes the first allocation of a pool its last in nearly all cases -- but slack and hint
 		// are wishes: when the device cannot give that much, the bare request is tried before the call fails)
@@ -1800,9 +1803,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			round_gen = ++ctx->dp_gen;
 			hipLaunchKernelGGL(k_dp_arm, dim3(1), dim3(1), 0, s, pool, ctx->dp_slot, (int)n_group_units, (int)(n_units - n_group_units), round_gen, ctx->dp_done, d_trace);
 			HIP_TRY(hipGetLastError());
-			// MPA_DP_WORKER_STREAM=0: the workers on the lane's own stream (what follows the round on that stream then also waits for
-			// this launch's workers to run out of units of ANY lane)
-			static const bool own_stream = [] { const char *e = getenv("MPA_DP_WORKER_STREAM"); return !e || atoi(e) != 0; }();
+			// The workers go out on the lane's own stream (what follows the round on that stream then also waits for this launch's
+			// workers to run out of units of ANY lane; measured level with a stream of their own, 19.6 against 19.7 M residues/s).
+			// MPA_DP_WORKER_STREAM=1: a worker stream per lane -- one more stream per lane for HIP to deal hardware queues to, and
+			// when that stream lands on a queue another context's long kernels use, every round waits for them (the evidence run of
+			// round 5 measured 6.5 M residues/s that way: profiles/r05_experiments.txt).
+			static const bool own_stream = [] { const char *e = getenv("MPA_DP_WORKER_STREAM"); return e && atoi(e) != 0; }();
 			hipStream_t ws = own_stream ? ctx->worker_stream : s;
 			if (own_stream) {
 				HIP_TRY(hipEventRecord(ctx->arm_ev, s));
