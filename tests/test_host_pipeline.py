@@ -44,6 +44,25 @@ def test_no_device_is_a_loud_error():
     assert rc == -1 and not res.value
 
 
+def test_the_multi_device_mapper_refuses_without_contexts():
+    """mpa_map_batches_multi (one pipeline per device in one process): no context list, a null context or more than eight contexts are
+    errors with a message -- and, like every mapping entry point, it has no CPU fallback to slip into"""
+    L = mpa.lib()
+    L.mpa_map_batches_multi.restype = C.c_int
+    L.mpa_map_batches_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    idx = mpa.Index.from_nt4([np.zeros(500, np.uint8)], ["c"])
+    q = mpa.Queries([b"MKTAYIAKQR"], ["x"])
+    res = (C.c_void_p * 1)()
+    mo = mpa.default_mapopt()
+    assert L.mpa_map_batches_multi(0, None, idx.h, C.byref(mo), 1, C.byref(q.c), None, 1, res, None, None, None) == -1 and b"no device context" in L.mpa_last_error()
+    none = (C.c_void_p * 2)(None, None)
+    assert L.mpa_map_batches_multi(2, none, idx.h, C.byref(mo), 1, C.byref(q.c), None, 1, res, None, None, None) == -1 and b"null context" in L.mpa_last_error()
+    nine = (C.c_void_p * 9)()
+    assert L.mpa_map_batches_multi(9, nine, idx.h, C.byref(mo), 1, C.byref(q.c), None, 1, res, None, None, None) == -5 and b"eight" in L.mpa_last_error()
+    assert not res[0]
+    idx.close()
+
+
 def test_error_paths_report_instead_of_guessing(tmp_path):
     """error behaviour of the C ABI: NULL / negative code + a message, never a silent default"""
     L = mpa.lib()
