@@ -337,6 +337,7 @@ def cli_end_to_end(wl, n_threads, cpu):
         return None
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "miniprot_amd") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env.setdefault("MPA_DEVICES", "1")          # one GPU, like the line's own n_gpus (the file mapper's default is every GPU of the node)
     cmd = [exe, "-t%d" % n_threads] + wl.cfg["flags"] + [wl.mpi, wl.faa]
     t = time.time()
     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -345,7 +346,7 @@ def cli_end_to_end(wl, n_threads, cpu):
         return {"error": "exit %d: %s" % (pr.returncode, pr.stderr.decode(errors="replace")[-300:])}
     md5 = hashlib.md5(pr.stdout).hexdigest()
     return {"command": " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd), "wall_s": wall, "reference_wall_s": cpu["wall_s"],
-            "reference_threads": cpu["cores"], "speedup_end_to_end": cpu["wall_s"] / max(wall, 1e-9), "md5": md5, "identical_to_reference": md5 == cpu["md5"],
+            "reference_threads": cpu["cores"], "devices": env["MPA_DEVICES"], "speedup_end_to_end": cpu["wall_s"] / max(wall, 1e-9), "md5": md5, "identical_to_reference": md5 == cpu["md5"],
             "note": "one cold run each, index load included on both sides (reference: %.1f s of its wall)" % cpu["index_load_s"]}
 
 
