@@ -181,6 +181,9 @@ typedef struct {
 	double ms_round_union;                       /* worker pool: time during which at least one worker launch of the DEVICE was running
 	                                              * (the union of the launches' intervals; the stream's rounds overlap) -- what one
 	                                              * persistent kernel's duration would be.  0 with MPA_DP_POOL=0. */
+	/* checkpointed traceback (traceback calls of <= 64 columns and >= MPA_DP_LITE_MIN rows): calls and padded cells swept by the
+	 * packed sweep, and the blocks of 96 rows whose traceback words the walk recomputed */
+	int64_t n_ckpt, cells_ckpt, walk_blocks;
 } mpa_dp_stats_t;
 void mpa_dp_last_stats(const mpa_ctx_t *ctx, mpa_dp_stats_t *st);
 /* sums over every mpa_dp_run() of this context since the last reset */

@@ -60,7 +60,8 @@ class DpStats(C.Structure):
                 ("ms_prep", C.c_double), ("ms_ext", C.c_double), ("ms_glob", C.c_double),
                 ("ms_backtrack", C.c_double), ("ms_total", C.c_double), ("launches_ext", C.c_int32),
                 ("launches_glob", C.c_int32), ("cells_ext_round", C.c_int64), ("cells_glob_round", C.c_int64),
-                ("ms_round", C.c_double), ("launches_round", C.c_int32), ("pad_", C.c_int32), ("ms_round_union", C.c_double)]
+                ("ms_round", C.c_double), ("launches_round", C.c_int32), ("pad_", C.c_int32), ("ms_round_union", C.c_double),
+                ("n_ckpt", C.c_int64), ("cells_ckpt", C.c_int64), ("walk_blocks", C.c_int64)]
 
 
 def build(verbose=False):

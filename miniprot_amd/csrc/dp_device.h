@@ -55,7 +55,22 @@ struct ExtWave {
 	int32_t max_nl;      // rows this wave iterates
 	int32_t pad_[3];
 	int64_t rec_base;    // smallest rec_off of the wave's tasks (record reads are base + 32-bit offset)
+	int64_t lite_off;    // checkpointed traceback only (below): the wave's extension-bit words / checkpoints in their pools (dwords)
+	int64_t ck_off;
 };
+
+// Checkpointed traceback (round 6).  A traceback call of up to 64 columns and many rows is swept by the PACKED row sweep of the
+// extension kernel (two calls per lane, ~27 VALU instructions per call and row instead of ~105), which keeps, per cell, only the
+// four "extension" bits that the walk follows through deletion and intron runs (bits 5..8 of the reference's traceback word:
+// D, A, B, C carried rather than opened, nasw-sse.c:455-485), and the DP state at the top of every block of MPA_TB_BLOCK rows.
+// The walk (k_walk) follows those runs on the bits alone and recomputes the full traceback words of a block -- with the exact
+// traceback sweep (glob_narrow), restarted from the block's checkpoint -- only when it stands in a block in any other state.
+//   bits:        one dword per lane and three rows at lite_off + ((i - 2) / 3) * 64 + lane: row i's nibble at bit 4 * (2 - (i - 2) % 3)
+//                of the call's half (call slot s of the wave: half s / (64/G), lanes (s % (64/G)) * G + column); nibble = D | A << 1 | B << 2 | C << 3
+//   checkpoints: block k >= 1 (first row 2 + k * MPA_TB_BLOCK) at ck_off + (k - 1) * 9 * 64: nine dwords per lane, packed like the
+//                sweep's registers: H of rows i-1, i-2, i-3; D of rows i-1, i-2, i-3; A; B; C
+#define MPA_TB_BLOCK 96
+#define MPA_LITE_SLOT_SHIFT 8        /* DTask::flag bits 8..11: the call's slot in its wave */
 
 struct ExtOut { int32_t nt_len, aa_len, score, flags; };
 
@@ -78,7 +93,8 @@ enum DpUnitKind : int32_t {
 	U_EXT_SPLIT,                        // a quarter (or half) of a 1024- (512-) column pair of calls: blk of n_blk
 	U_GLOB16, U_GLOB32, U_GLOB64,       // up to four independent traceback waves
 	U_GLOB_MB,                          // ... block-major ones (more than 1024 columns)
-	U_GLOB_W2, U_GLOB_W4                // two two-wave / one four-wave traceback group(s)
+	U_GLOB_W2, U_GLOB_W4,               // two two-wave / one four-wave traceback group(s)
+	U_LITE16, U_LITE32, U_LITE64        // up to four independent waves of the checkpointed traceback's packed sweep (ExtWave descriptors)
 };
 struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; };
 

@@ -157,6 +157,7 @@ struct mpa_ctx_s {
 	hipEvent_t fork_ev = nullptr;
 	hipEvent_t lev[2 * kSide] = {};           // start/stop pair per side-stream launch
 	DevBuf tasks, waves, chunks, qseq, rec, prof, tb, cig, ncig, score, extout, bnd, list, rowkey, cigd, cigoff, hkey, xg, units;
+	DevBuf lite, ckpt, wlist;                 // checkpointed traceback (dp_device.h): extension-bit words, checkpoints, the calls the walk takes
 	HostPinned h_up, h_down, h_pool;          // staging of a DP round's descriptors (host -> device) and of its results: no pageable copies, one wait
 	mpa_dp_stats_t stats = {};
 	mpa_dp_stats_t total = {};
@@ -202,7 +203,8 @@ template<typename F> static void ctx_each_devbuf(mpa_ctx_s *ctx, F f)
 	                  &B.r_win, &B.r_chunk, &B.r_words, &B.r_hits, &B.r_count,
 	                  &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
 	                  &B.pf_qfirst2, &B.val64[0], &B.val64[1],
-	                  &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys };
+	                  &B.s_meta, &B.s_cur, &B.s_cur2, &B.s_kept, &B.s_base, &B.s_out, &B.s_flag, &B.dkey, &B.x_all, &B.rx_all, &B.rx_keys,
+	                  &ctx->lite, &ctx->ckpt, &ctx->wlist };
 	int k = 0;
 	for (DevBuf *b : all) f(*b, k++);
 }
@@ -1497,6 +1499,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			if (!(x.flag & MPA_F_CIGAR)) { set_error("global DP without CIGAR is not part of miniprot's path"); return MPA_ERR_UNSUPPORTED; }
 			t.pw = t.ncol;
 			t.pad_ = t.ncol <= 16 ? 0 : t.ncol <= 32 ? 1 : t.ncol <= 64 ? 2 : t.ncol <= 128 ? 3 : t.ncol <= 256 ? 4 : t.ncol <= 512 ? 5 : t.ncol <= 1024 ? 6 : 7;
+			// Checkpointed traceback (dp_device.h): a call of up to 64 columns and many rows -- the gap fills across introns and the spans
+			// of accepted extensions, where nearly every row lies inside an intron -- is swept by the packed sweep (classes 8, 9, 10: 16,
+			// 32, 64 lanes per call, two calls per lane) and walked by k_walk.  Short calls stay on the plain traceback sweep: the walk
+			// would recompute all of their rows anyway.  MPA_DP_LITE_MIN (rows; 0: never).
+			static const int lite_min = [] { const char *e = getenv("MPA_DP_LITE_MIN"); return e ? atoi(e) : 384; }();
+			if (lite_min > 0 && !wide_ge && t.ncol <= 64 && x.nl >= lite_min && x.nl >= 3) t.pad_ += 8, t.pw = 16 << (t.pad_ - 8);
 			glob_ids.push_back((int32_t)k);
 		}
 	}
@@ -1555,6 +1563,36 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			ewave_cnt[cls] = (int)ewaves.size() - ewave_first[cls];
 		}
 	}
+	// ---- waves of the checkpointed traceback's packed sweep (classes 8, 9, 10 sort behind every other traceback call)
+	size_t n_reg_glob = 0;
+	while (n_reg_glob < glob_ids.size() && T[glob_ids[n_reg_glob]].pad_ < 8) ++n_reg_glob;
+	int lwave_first[3] = { 0, 0, 0 }, lwave_cnt[3] = { 0, 0, 0 };
+	int64_t lite_total = 0, ck_total = 0;
+	{
+		size_t p = n_reg_glob;
+		for (int cls = 0; cls < 3; ++cls) {
+			const int slots = 2 * (64 / (16 << cls));
+			lwave_first[cls] = (int)ewaves.size();
+			while (p < glob_ids.size() && T[glob_ids[p]].pad_ == 8 + cls) {
+				ExtWave w;
+				memset(&w, 0, sizeof(w));
+				for (int k = 0; k < 8; ++k) w.task[k] = -1;
+				w.rec_base = T[glob_ids[p]].rec_off;
+				const size_t p0 = p;
+				for (int k = 0; k < slots && p < glob_ids.size() && T[glob_ids[p]].pad_ == 8 + cls; ++k, ++p) {
+					w.task[k] = glob_ids[p];
+					w.max_nl = std::max(w.max_nl, T[glob_ids[p]].nl);
+					T[glob_ids[p]].flag |= k << MPA_LITE_SLOT_SHIFT;
+				}
+				w.lite_off = lite_total, lite_total += ((int64_t)w.max_nl / 3 + 2) * 64;
+				w.ck_off = ck_total, ck_total += (int64_t)std::max(0, (w.max_nl - 3) / MPA_TB_BLOCK) * 9 * 64;
+				for (size_t q2 = p0; q2 < p; ++q2) T[glob_ids[q2]].tb_off = w.lite_off, T[glob_ids[q2]].bnd_off = w.ck_off;
+				ewaves.push_back(w);
+			}
+			lwave_cnt[cls] = (int)ewaves.size() - lwave_first[cls];
+		}
+	}
+	const size_t n_lite = glob_ids.size() - n_reg_glob;
 	// per-row keys of the wide extension kernels: [group][2 halves][key_stride]
 	int64_t key_stride = 0, n_wide_groups = 0;
 	for (int cls = 3; cls < kNumExtClasses; ++cls)
@@ -1568,9 +1606,9 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	std::vector<GlobRound> rounds;
 	{
 		size_t p = 0;
-		while (p < glob_ids.size()) {
+		while (p < n_reg_glob) {
 			GlobRound r{ p, p, 0 };
-			while (r.last < glob_ids.size()) {
+			while (r.last < n_reg_glob) {
 				DTask &t = T[glob_ids[r.last]];
 				int64_t wds = (int64_t)t.nl * t.ncol;
 				if (r.last > r.first && (size_t)(r.tb_words + wds) * 2 > ctx->tb_budget) break;
@@ -1593,6 +1631,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	    (rc = ctx->qseq.ensure(q_bytes + 16)) || (rc = ctx->rec.ensure((size_t)rec_total * 4)) || (rc = ctx->prof.ensure((size_t)prof_total * 2 + 16)) ||
 	    (rc = ctx->waves.ensure(sizeof(ExtWave) * (ewaves.size() + 1))) || (rc = ctx->extout.ensure(sizeof(ExtOut) * n)) ||
 	    (rc = ctx->tb.ensure((size_t)tb_max * 2 + 16)) || (rc = ctx->cig.ensure((size_t)cig_total * 4 + 16)) || (rc = ctx->ncig.ensure(n * 4)) ||
+	    (rc = ctx->lite.ensure((size_t)lite_total * 4 + 256)) || (rc = ctx->ckpt.ensure((size_t)ck_total * 4 + 256)) || (rc = ctx->wlist.ensure(n_lite * 4 + 128)) ||
 	    (rc = ctx->score.ensure(n * 4)) || (rc = ctx->rowkey.ensure((size_t)(n_wide_groups * 2 * key_stride * 4 + 64))) || (rc = ctx->bnd.ensure((size_t)bnd_total * 16 + 16)) || (rc = ctx->hkey.ensure((size_t)hkey_total * 8 + 16 + (sizeof(GlobWave) + 4) * (huge_ids.size() + 1))) || (rc = ctx->list.ensure(n * 4 + 128 + sizeof(GlobWave) * (glob_ids.size() + 1))))
 		return rc;
 	// Everything the device needs from the host goes through ONE pinned staging buffer (sections below), so that no copy is
@@ -1602,7 +1641,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	             up_waves = up_q + al256((size_t)q_bytes), up_list = up_waves + al256(sizeof(ExtWave) * ewaves.size()),
 	             up_gw = up_list + al256(4 * glob_ids.size()), up_units = up_gw + al256(sizeof(GlobWave) * (glob_ids.size() + 8)),
 	             up_off = up_units + al256(sizeof(DpUnit) * (4 * ewaves.size() + glob_ids.size() + 64)),
-	             up_ids = up_off + al256(8 * glob_ids.size()), up_args = up_ids + al256(4 * glob_ids.size()), up_end = up_args + al256(sizeof(DpRoundArgs));
+	             up_ids = up_off + al256(8 * glob_ids.size()), up_args = up_ids + al256(4 * glob_ids.size()), up_wl = up_args + al256(sizeof(DpRoundArgs)),
+	             up_end = up_wl + al256(4 * n_lite);
 	if ((rc = ctx->h_up.ensure(up_end + 256))) return rc;
 	char *hup = ctx->h_up.as<char>();
 	memcpy(hup + up_tasks, T.data(), sizeof(DTask) * n);
@@ -1689,6 +1729,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	ExtArgs ea;
 	ea.tasks = ctx->tasks.as<DTask>(), ea.rec = ctx->rec.as<uint32_t>(), ea.prof = ctx->prof.as<int16_t>(), ea.out = ctx->extout.as<ExtOut>();
 	ea.c = dc, ea.pen = pen;
+	ea.lite = ctx->lite.as<uint32_t>(), ea.ckpt = ctx->ckpt.as<uint32_t>(), ea.score = ctx->score.as<int32_t>();
 	ExtWideArgs wa;
 	wa.tasks = ea.tasks, wa.rec = ea.rec, wa.prof = ea.prof, wa.out = ea.out, wa.c = dc, wa.pen = pen, wa.key_stride = key_stride;
 	wa.xg = n_split ? ctx->xg.as<unsigned long long>() : nullptr;
@@ -1732,6 +1773,9 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
 		for (int k = 0; k < ewave_cnt[5]; ++k)
 			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 425, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
+		for (int cls = 0; cls < 3; ++cls)                            // the packed sweeps of the checkpointed traceback
+			for (int k = 0; k < lwave_cnt[cls]; k += per_narrow)
+				add(U_LITE16 + cls, lwave_first[cls] + k, std::min(per_narrow, lwave_cnt[cls] - k), (int64_t)ewaves[lwave_first[cls] + k].max_nl * 170);
 		if (gw_first) {
 			static const int kind_of[8] = { U_GLOB16, U_GLOB32, U_GLOB64, U_GLOB_W2, U_GLOB_W4, -1, -1, U_GLOB_MB };
 			for (int cls = 0; cls < 8; ++cls) {
@@ -1773,13 +1817,17 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		wa.waves = ctx->waves.as<ExtWave>();                // absolute descriptor indices: the rowkey slot of group g is g - first wide group
 		wa.rowkey = ctx->rowkey.as<uint32_t>() - (int64_t)ewave_first[3] * 2 * key_stride;
 		ga.waves = d_gw;
-		// Four workgroups of the round kernel per CU, enforced through the LDS it asks for.  Five fit (30.4 KB, 94 VGPRs), but then the
-		// 20 DP waves of a CU hold 480 of each SIMD's 512 registers and the seeding kernels of the next batches cannot be co-resident:
-		// they wait for whole workgroups to retire (measured again in round 4: 5 -> 18.8 M residues/s, 3 -> 18.7 M, 4 -> 19.8 M).
-		// One more workgroup than wanted must NOT fit; what is left (160 KB / 5, less the rounding) stays free for the LDS of the
-		// seeding kernels -- dividing the whole LDS by four would starve them.
+		// Workgroups of the round kernel per CU, enforced through the LDS it asks for (MPA_DP_WG_PER_CU, default 3).  Round 6: the
+		// kernel takes 124 VGPRs (the asm rows of ext_narrow keep the whole DP state of eight calls in registers and nothing is
+		// spilled), so three workgroups hold 372 of each SIMD's 512 registers -- what four workgroups of the 95-register kernel of
+		// rounds 4-5 held (384) -- and the seeding kernels of the next batches stay co-resident.  One more workgroup than wanted must
+		// NOT fit; what is left of the LDS stays free for the seeding kernels.
 		static const size_t round_lds = [] {
-			const size_t pad = (((size_t)160 * 1024 / 5) + 256) & ~(size_t)255;
+			const char *e = getenv("MPA_DP_WG_PER_CU");
+			int want = e ? atoi(e) : 3;
+			if (want < 1) want = 1;
+			if (want > 4) want = 4;
+			const size_t pad = (((size_t)160 * 1024 / (want + 1)) + 256) & ~(size_t)255;
 			return pad > DP_ROUND_LDS ? pad : DP_ROUND_LDS;
 		}();
 		if (use_pool) {
@@ -1986,11 +2034,24 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		if ((rc = wait_round()) != MPA_OK) return rc;
 		if (use_pool) mark("    dp: round (units done)");
 	}
+	// ---- the walk of the checkpointed traceback: behind the round that swept its calls
+	if (n_lite) {
+		memcpy(hup + up_wl, glob_ids.data() + n_reg_glob, 4 * n_lite);
+		HIP_TRY(hipMemcpyAsync(ctx->wlist.p, hup + up_wl, 4 * n_lite, hipMemcpyHostToDevice, s));
+		WalkArgs wk;
+		wk.ga = ga, wk.ga.waves = nullptr, wk.list = ctx->wlist.as<int32_t>(), wk.n_list = (int32_t)n_lite;
+		wk.lite = ctx->lite.as<uint32_t>(), wk.ckpt = ctx->ckpt.as<uint32_t>(), wk.cig = ctx->cig.as<uint32_t>(), wk.n_cigar = ctx->ncig.as<int32_t>();
+		wk.n_blocks = (unsigned long long*)((char*)ctx->wlist.p + ((n_lite * 4 + 63) & ~(size_t)63));
+		HIP_TRY(hipMemsetAsync(wk.n_blocks, 0, 8, s));
+		hipLaunchKernelGGL(k_walk, dim3((unsigned)n_lite), dim3(64), WALK_LDS, s, wk);
+		HIP_TRY(hipGetLastError());
+		ctx->stats.launches_glob++;
+	}
 	// ---- join
 	for (auto &l : launches) (void)hipStreamWaitEvent(s, ctx->lev[2 * l.side + 1], 0);
 	HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	// results into pinned memory behind the last kernel: extension outputs, traceback scores and CIGAR lengths, hand-off error flag
-	const size_t dn_eo = 0, dn_sc = dn_eo + al256(sizeof(ExtOut) * n), dn_nc = dn_sc + al256(4 * n), dn_err = dn_nc + al256(4 * n), dn_end = dn_err + 256;
+	const size_t dn_eo = 0, dn_sc = dn_eo + al256(sizeof(ExtOut) * n), dn_nc = dn_sc + al256(4 * n), dn_err = dn_nc + al256(4 * n), dn_wb = dn_err + 256, dn_end = dn_wb + 256;
 	if ((rc = ctx->h_down.ensure(dn_end))) return rc;
 	char *hdn = ctx->h_down.as<char>();
 	*(int32_t*)(hdn + dn_err) = 0;
@@ -2000,6 +2061,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		HIP_TRY(hipMemcpyAsync(hdn + dn_nc, ctx->ncig.p, n * 4, hipMemcpyDeviceToHost, s));
 	}
 	if (n_split) HIP_TRY(hipMemcpyAsync(hdn + dn_err, wa.err, 4, hipMemcpyDeviceToHost, s));
+	*(unsigned long long*)(hdn + dn_wb) = 0;
+	if (n_lite) HIP_TRY(hipMemcpyAsync(hdn + dn_wb, (char*)ctx->wlist.p + ((n_lite * 4 + 63) & ~(size_t)63), 8, hipMemcpyDeviceToHost, s));
 	mark("    dp: round enqueued");
 	HIP_TRY(wait_stream(ctx, s));
 	mark("    dp: round (wait)");
@@ -2086,11 +2149,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		const DTask &t = T[id];
 		const int64_t cells = (int64_t)std::max(0, t.nl - 2) * t.ncol;
 		// (the first traceback chunk rides in the round's launch, except the 512/1024-thread classes)
-		if (round_launched && !rounds.empty() && gi < rounds[0].last && t.pad_ != 5 && t.pad_ != 6) st.cells_glob_round += cells;
+		if (round_launched && ((!rounds.empty() && gi < rounds[0].last && t.pad_ != 5 && t.pad_ != 6) || gi >= n_reg_glob)) st.cells_glob_round += cells;
 		st.n_glob++, st.cells_glob += cells;
+		if (gi >= n_reg_glob) st.n_ckpt++, st.cells_ckpt += cells;
 		st.alg_bytes_glob += (t.nl + 1) / 2 + t.al + 12 + 2 * cells + 2 * ((int64_t)t.nl + t.al) + 4 * (int64_t)nc[id];
 	}
 	st.rows_prep = rec_total;
+	st.walk_blocks = (int64_t)*(const unsigned long long*)(hdn + dn_wb);
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); st.ms_prep = ms;
 	st.ms_ext = ms_ext_sum;
@@ -2103,6 +2168,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		mpa_dp_stats_t &t = ctx->total;
 		t.n_ext += st.n_ext, t.n_glob += st.n_glob, t.cells_ext += st.cells_ext, t.cells_glob += st.cells_glob, t.rows_prep += st.rows_prep;
 		t.alg_bytes_ext += st.alg_bytes_ext, t.alg_bytes_glob += st.alg_bytes_glob;
+		t.n_ckpt += st.n_ckpt, t.cells_ckpt += st.cells_ckpt, t.walk_blocks += st.walk_blocks;
 		t.ms_prep += st.ms_prep, t.ms_ext += st.ms_ext, t.ms_glob += st.ms_glob, t.ms_backtrack += st.ms_backtrack, t.ms_total += st.ms_total;
 		t.launches_ext += st.launches_ext, t.launches_glob += st.launches_glob;
 		t.cells_ext_round += st.cells_ext_round, t.cells_glob_round += st.cells_glob_round, t.ms_round += st.ms_round, t.launches_round += st.launches_round;

@@ -400,22 +400,29 @@ __global__ __launch_bounds__(256) void k_prep_prof(const DTask *tasks, const cha
 // ------------------------------------------------------------------------------------------------
 // K1: extension (score only).  See file header.
 //
-// A lone wavefront pays >= 4 cycles for every instruction it issues, and at the batch sizes of a 1k-protein
-// step the GPU is latency bound (one 100k-row window per wave decides the wall time), so the row loop is
-// written for a minimal instruction count:
-//   * row records come from a small LDS ring refilled 16 rows at a time (one coalesced global load per
-//     16 rows instead of two dependent loads per row);
-//   * the query profile sits in LDS as int16 [call][column][amino acid], 46 bytes per column (an odd number of
-//     16-bit words: the columns of a lane group fall into distinct banks); a row record carries 2 * amino acid
-//     in its low byte, so a lane's address is `base + byte0(record)` (one SDWA add per half) and the two halves
-//     of the packed register are filled by ds_read_u16_d16 / ds_read_u16_d16_hi -- no combining instruction.
-//     5.9 KB per wave instead of the 23.5 KB of a {score, score << 16} layout: LDS no longer caps a CU at six
-//     of these waves (it was the limiter of this kernel at batch sizes of a few thousand proteins);
-//   * donor/acceptor windows and the H/D rings are register rings indexed at compile time (rows are
-//     processed in groups of three), so no state is ever moved;
-//   * the best-row / x-drop bookkeeping is two saturating subtractions and one compare per row: a lane votes
-//     if it beats the call's best score, and one "witness" lane per call proves the row is not x-dropped;
-//     everything exact happens in a rare slow path.
+// What one row costs (round 6, tools/ubench/valu_rate.hip on the MI355X): every packed-int16 instruction, DPP move, v_perm,
+// SDWA or VOP3 instruction takes 4.15 cycles of its SIMD's VALU (only plain 32-bit VOP2 adds / logic ops take 2.3), and a wave
+// that is alone on its SIMD issues ONE instruction of any kind (VALU, SALU, s_nop, LDS) per ~5 cycles.  A saturated machine
+// is therefore bound by the VALU instructions per row, a lone wave (the 100 000-row calls that set a round's length) by ALL
+// instructions per row -- including the `s_nop 0` hipcc puts between a packed instruction and any VALU instruction that reads
+// its result (LLVM's dst_sel forwarding hazard, which takes VOP3P's default op_sel_hi bit for VOP3's dst op_sel;
+// tools/ubench/pk_hazard.hip: 524 288 lanes x 144 000 dependent packed instructions, identical with and without the nop) and
+// the `s_nop 1` in front of every DPP move (that hazard is real: two wait states between a VALU write and a DPP read).
+// Round 5's row was ~60 VALU + ~17 s_nop + ~20 SALU = ~95 slots (255 ns alone, 554 ns per wave-row on a saturated machine).
+//
+// The row is now two hand-scheduled asm blocks (`row_head`, `row_tail<G>`; 45 VALU + 1 s_nop for 32 lanes per call):
+//   * the row records arrive DECODED: the lanes that refill the LDS ring (12 rows at a time) split a record into packed
+//     {donor, acceptor, gap extension, profile offsets} once, so a row reads one ds_read_b128 and does no v_perm;
+//   * the four frameshift moves use M(r) = max(H(r, j), H(r, j-1)) kept per row (one max when the row is made);
+//   * the horizontal gap chain is a scan inside rows of 16 lanes, then ONE exclusive step (row_shr:1 + row_bcast:15), which
+//     also removes the lane-32 select of a 32-lane group; all fill registers are kept (a DPP move leaves lanes without a
+//     source untouched);
+//   * the two wait states in front of each DPP move are filled with the part of the NEXT row that does not depend on this one
+//     (its D state, its diagonal term, the LDS addresses of the row after), so no slot is idle;
+//   * the best-row / x-drop vote is a clamp and a compare: every lane carries thresholds (lo, hi) such that lo <= H <= hi
+//     proves that the row neither beats the call's best score nor falls below its x-drop line (see repack()).
+// The exact bookkeeping (nasw-sse.c:423-433), task ends, steps of the length penalty and the first rows run through the
+// plain C++ row below ("generic row"), which shares all state with the asm rows.
 // ------------------------------------------------------------------------------------------------
 struct ExtArgs {
 	const DTask *tasks;
@@ -425,48 +432,261 @@ struct ExtArgs {
 	ExtOut *out;
 	DpConst c;
 	PenTable pen;
+	// checkpointed traceback (ext_narrow<G, true>; dp_device.h): extension-bit words, checkpoints, H(nl-1, al-1) per call
+	uint32_t *lite;
+	uint32_t *ckpt;
+	int32_t *score;
 };
 
 #define PROF_AA_STRIDE 2                       /* bytes per amino acid inside one column of the LDS profile */
 #define PROF_COL_STRIDE 46                     /* bytes per column: 22 scores + 1 pad, an odd number of 16-bit words */
 
-// two int16 profile scores into the halves of one register (the compiler emits ds_read_u16_d16 + ds_read_u16_d16_hi)
+// two int16 profile scores into the halves of one register
 __device__ __forceinline__ uint32_t prof2(const char *lo, const char *hi)
 {
 	v2s r;
 	r.x = *(const int16_t*)lo, r.y = *(const int16_t*)hi;
 	return as_u(r);
 }
+__device__ __forceinline__ uint32_t p_min(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_min(as_v(a), as_v(b))); }
 
-#define EXT_NARROW_LDS ((((size_t)2 * 64 * PROF_COL_STRIDE + 7) & ~(size_t)7) + (size_t)4 * 32 * 8 + 2 * MPA_PEN_MAX * 4)   /* bytes per wave */
-template<int G>
+// One decoded row record of a lane group in the LDS ring: the two calls (int16 halves) of the group side by side.
+//   x donor[r+1] (sign-extended)   y acceptor[r]   z gap extension of the row   w byte offset of the row's amino acid in a profile
+//   column, call 0 in the low half, call 1 in the high half
+__device__ __forceinline__ uint4 ring_entry(const uint32_t r0, const uint32_t r1)
+{
+	return make_uint4(__builtin_amdgcn_perm(r1, r0, 0x0a050801u), __builtin_amdgcn_perm(r1, r0, 0x0b070903u),
+	                  __builtin_amdgcn_perm(r1, r0, 0x0c060c02u), __builtin_amdgcn_perm(r1, r0, 0x0c040c00u));
+}
+#define EXT_RING_ROWS 24                       /* two blocks of 12 rows: one is read while the other is refilled */
+#define EXT_RING_SLOTS 25                      /* + a copy of slot 0 behind slot 23: the asm rows fetch three rows ahead with a constant offset */
+#define EXT_BLOCK_ROWS 12
+#define EXT_NARROW_LDS ((size_t)2 * 64 * PROF_COL_STRIDE + (size_t)4 * EXT_RING_SLOTS * 16 + 8 * 32 + 2 * MPA_PEN_MAX * 4)   /* bytes per wave; a multiple of 16 */
+typedef const __attribute__((address_space(3))) int16_t *lds_s16p;
+// two int16 profile scores (absolute LDS byte addresses) into the halves of one register
+__device__ __forceinline__ uint32_t prof2s(const uint32_t lo, const uint32_t hi)
+{
+	v2s r;
+	r.x = *(lds_s16p)(uintptr_t)lo, r.y = *(lds_s16p)(uintptr_t)hi;
+	return as_u(r);
+}
+
+// The first asm block of a row: the three intron states, the frameshift moves and the choice among everything but the
+// horizontal gap.  hD = max(H(i-3,j-1) + s(i,j), D(i,j)) was made during the row before.  x = h + j*ge feeds the scan.
+#define MPA_ROW_HEAD(Hr1, Hs1, dn1, dn2, dn3, ac1, ac2, ac3, M1, M2) \
+	asm volatile( \
+		"v_pk_sub_i16 %[uA], %[hr1], %[io] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[hs1], %[io] clamp\n\t" \
+		"v_pk_sub_i16 %[uA], %[uA], %[d2] clamp\n\t" \
+		"v_pk_sub_i16 %[t1], %[uB], %[d1] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[uB], %[d3] clamp\n\t" \
+		"v_pk_max_i16 %[A], %[uA], %[A]\n\t" \
+		"v_pk_max_i16 %[B], %[t1], %[B]\n\t" \
+		"v_pk_max_i16 %[C], %[uB], %[C]\n\t" \
+		"v_pk_sub_i16 %[uA], %[A], %[a3] clamp\n\t" \
+		"v_pk_sub_i16 %[t1], %[B], %[a2] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[C], %[a1] clamp\n\t" \
+		"v_pk_max_i16 %[uA], %[uA], %[t1]\n\t" \
+		"v_pk_max_i16 %[t1], %[m1], %[m2]\n\t" \
+		"v_pk_sub_i16 %[t1], %[t1], %[fs] clamp\n\t" \
+		"v_pk_max_i16 %[uB], %[uB], %[t1]\n\t" \
+		"v_pk_max_i16 %[h], %[hD], %[uA]\n\t" \
+		"v_pk_max_i16 %[h], %[h], %[uB]\n\t" \
+		"v_pk_add_i16 %[x], %[h], %[jge] clamp" \
+		: [uA] "=&v"(tA_), [uB] "=&v"(tB_), [t1] "=&v"(tC_), [h] "=&v"(h), [x] "=&v"(x), [A] "+v"(A), [B] "+v"(B), [C] "+v"(C) \
+		: [hr1] "v"(Hr1), [hs1] "v"(Hs1), [io] "v"(ioP), [d1] "v"(dn1), [d2] "v"(dn2), [d3] "v"(dn3), [a1] "v"(ac1), [a2] "v"(ac2), [a3] "v"(ac3), \
+		  [m1] "v"(M1), [m2] "v"(M2), [hD] "v"(hD), [jge] "v"(jge), [fs] "s"(fsP))
+
+// The second asm block: the gap scan with the next row's independent part in its wait states (D state from H(i-2), Dr(i-2) and the
+// next record's gap extension; the diagonal term from Hs(i-2) and the two profile scores fetched a row ago; the LDS addresses of
+// the scores of the row after from the record fetched at the top of this row), the final H, the vote clamp, H shifted by one
+// column, and M.  Wait states: a DPP move needs two instructions between it and the VALU write of its source.
+#define MPA_SCAN4 \
+		"v_pk_sub_i16 %[t2], %[hr2], %[go] clamp\n\t" \
+		"v_pk_max_i16 %[t2], %[t2], %[dr2]\n\t" \
+		"v_mov_b32_dpp %[k0], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k0]\n\t" \
+		"v_pk_sub_i16 %[dr2], %[t2], %[gei] clamp\n\t" \
+		"v_perm_b32 %[t2], %[s1], %[s0], %[sel]\n\t" \
+		"v_mov_b32_dpp %[k1], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k1]\n\t" \
+		"v_pk_add_i16 %[t2], %[hs2], %[t2] clamp\n\t" \
+		"v_pk_max_i16 %[hDn], %[t2], %[dr2]\n\t" \
+		"v_mov_b32_dpp %[k2], %[x] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k2]\n\t" \
+		"v_add_u32_sdwa %[a0], %[pb0], %[aw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+		"v_add_u32_sdwa %[a1], %[pb1], %[aw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+		"v_mov_b32_dpp %[k3], %[x] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k3]\n\t"
+#define MPA_EX16 \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t"
+#define MPA_EX32 \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_mov_b32_dpp %[kc], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[t2], %[ke], %[kc]\n\t" \
+		"v_pk_sub_i16 %[t2], %[t2], %[gojge] clamp\n\t"
+#define MPA_EX64 \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t"
+#define MPA_FIN \
+		"v_pk_max_i16 %[h], %[h], %[t2]\n\t" \
+		"v_pk_min_i16 %[vt], %[h], %[gl]\n\t" \
+		"v_pk_max_i16 %[vt], %[vt], %[tl]\n\t"
+#define MPA_HS16 "v_mov_b32_dpp %[hs3], %[h] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define MPA_HS32 "v_mov_b32_dpp %[hs3], %[h] wave_shr:1 row_mask:0xb bank_mask:0xf\n\tv_mov_b32_dpp %[hs3], %[h] row_shr:1 row_mask:0x4 bank_mask:0xf\n\t"
+#define MPA_HS64 "v_mov_b32_dpp %[hs3], %[h] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define MPA_ROW_TAIL(EX, HS, Hr2, Hs2, Dr2, Hs3, M3) \
+	asm volatile(MPA_SCAN4 EX MPA_FIN HS "v_pk_max_i16 %[m3], %[h], %[hs3]" \
+		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [kc] "+v"(kc), [dr2] "+v"(Dr2), [hs3] "+v"(Hs3), \
+		  [t2] "=&v"(tA_), [hDn] "=&v"(hDn), [a0] "=&v"(a0), [a1] "=&v"(a1), [vt] "=&v"(vt), [m3] "=&v"(M3) \
+		: [hr2] "v"(Hr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
+		  [gojge] "v"(gojge), [gl] "v"(GvL), [tl] "v"(TvL), [go] "s"(goP), [sel] "s"(sel_lo))
+
+// The rows of the checkpointed traceback's sweep (ext_narrow<G, true>): the same two blocks without the vote, with the four
+// "fresh value minus carried value" differences whose signs are the extension bits of the reference's traceback word (bit 5: D(i-3,j)
+// > H(i-3,j) - q, nasw-sse.c:455; bits 6..8: A, B, C carried rather than opened, :462-485), and with the new D state in a register
+// of its own (the old one is what a checkpoint stores).  dD belongs to the NEXT row, like the D state it comes with.
+#define MPA_ROW_HEAD_L(Hr1, Hs1, dn1, dn2, dn3, ac1, ac2, ac3, M1, M2) \
+	asm volatile( \
+		"v_pk_sub_i16 %[uA], %[hr1], %[io] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[hs1], %[io] clamp\n\t" \
+		"v_pk_sub_i16 %[uA], %[uA], %[d2] clamp\n\t" \
+		"v_pk_sub_i16 %[t1], %[uB], %[d1] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[uB], %[d3] clamp\n\t" \
+		"v_pk_sub_i16 %[dA], %[uA], %[A] clamp\n\t" \
+		"v_pk_sub_i16 %[dB], %[t1], %[B] clamp\n\t" \
+		"v_pk_sub_i16 %[dC], %[uB], %[C] clamp\n\t" \
+		"v_pk_max_i16 %[A], %[uA], %[A]\n\t" \
+		"v_pk_max_i16 %[B], %[t1], %[B]\n\t" \
+		"v_pk_max_i16 %[C], %[uB], %[C]\n\t" \
+		"v_pk_sub_i16 %[uA], %[A], %[a3] clamp\n\t" \
+		"v_pk_sub_i16 %[t1], %[B], %[a2] clamp\n\t" \
+		"v_pk_sub_i16 %[uB], %[C], %[a1] clamp\n\t" \
+		"v_pk_max_i16 %[uA], %[uA], %[t1]\n\t" \
+		"v_pk_max_i16 %[t1], %[m1], %[m2]\n\t" \
+		"v_pk_sub_i16 %[t1], %[t1], %[fs] clamp\n\t" \
+		"v_pk_max_i16 %[uB], %[uB], %[t1]\n\t" \
+		"v_pk_max_i16 %[h], %[hD], %[uA]\n\t" \
+		"v_pk_max_i16 %[h], %[h], %[uB]\n\t" \
+		"v_pk_add_i16 %[x], %[h], %[jge] clamp" \
+		: [uA] "=&v"(tA_), [uB] "=&v"(tB_), [t1] "=&v"(tC_), [h] "=&v"(h), [x] "=&v"(x), [dA] "=&v"(dA), [dB] "=&v"(dB), [dC] "=&v"(dC), \
+		  [A] "+v"(A), [B] "+v"(B), [C] "+v"(C) \
+		: [hr1] "v"(Hr1), [hs1] "v"(Hs1), [io] "v"(ioP), [d1] "v"(dn1), [d2] "v"(dn2), [d3] "v"(dn3), [a1] "v"(ac1), [a2] "v"(ac2), [a3] "v"(ac3), \
+		  [m1] "v"(M1), [m2] "v"(M2), [hD] "v"(hD), [jge] "v"(jge), [fs] "s"(fsP))
+#define MPA_SCAN4_L \
+		"v_pk_sub_i16 %[t2], %[hr2], %[go] clamp\n\t" \
+		"v_pk_sub_i16 %[dDn], %[t2], %[dr2] clamp\n\t" \
+		"v_mov_b32_dpp %[k0], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k0]\n\t" \
+		"v_pk_max_i16 %[t2], %[t2], %[dr2]\n\t" \
+		"v_pk_sub_i16 %[drn], %[t2], %[gei] clamp\n\t" \
+		"v_mov_b32_dpp %[k1], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k1]\n\t" \
+		"v_perm_b32 %[t2], %[s1], %[s0], %[sel]\n\t" \
+		"v_pk_add_i16 %[t2], %[hs2], %[t2] clamp\n\t" \
+		"v_mov_b32_dpp %[k2], %[x] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k2]\n\t" \
+		"v_pk_max_i16 %[hDn], %[t2], %[drn]\n\t" \
+		"v_add_u32_sdwa %[a0], %[pb0], %[aw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+		"v_mov_b32_dpp %[k3], %[x] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[k3]\n\t" \
+		"v_add_u32_sdwa %[a1], %[pb1], %[aw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+#define MPA_EX16_L \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t"
+#define MPA_EX32_L \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_mov_b32_dpp %[kc], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[t2], %[ke], %[kc]\n\t" \
+		"v_pk_sub_i16 %[t2], %[t2], %[gojge] clamp\n\t"
+#define MPA_EX64_L \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t"
+#define MPA_ROW_TAIL_L(EX, HS, Hr2, Hs2, Dr2, Hs3, M3) \
+	asm volatile(MPA_SCAN4_L EX "v_pk_max_i16 %[h], %[h], %[t2]\n\ts_nop 1\n\t" HS "v_pk_max_i16 %[m3], %[h], %[hs3]" \
+		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [kc] "+v"(kc), [hs3] "+v"(Hs3), \
+		  [t2] "=&v"(tA_), [hDn] "=&v"(hDn), [a0] "=&v"(a0), [a1] "=&v"(a1), [m3] "=&v"(M3), [drn] "=&v"(drn), [dDn] "=&v"(dDn) \
+		: [hr2] "v"(Hr2), [dr2] "v"(Dr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
+		  [gojge] "v"(gojge), [go] "s"(goP), [sel] "s"(sel_lo))
+// the row's nibble (D | A << 1 | B << 2 | C << 3 in bits 0..3 of each half) from the signs of the four differences, pushed into the
+// three-row accumulator (FIRST: the row opens a new word)
+#define MPA_NIBBLE(LAST_OP) \
+	asm volatile( \
+		"v_pk_ashrrev_i16 %[u], 15, %[dD] op_sel_hi:[0,1]\n\t" \
+		"v_pk_ashrrev_i16 %[v], 15, %[dA] op_sel_hi:[0,1]\n\t" \
+		"v_and_b32 %[u], %[c1], %[u]\n\t" \
+		"v_pk_ashrrev_i16 %[w], 15, %[dB] op_sel_hi:[0,1]\n\t" \
+		"v_and_or_b32 %[u], %[v], %[c2], %[u]\n\t" \
+		"v_pk_ashrrev_i16 %[v], 15, %[dC] op_sel_hi:[0,1]\n\t" \
+		"v_and_or_b32 %[u], %[w], %[c4], %[u]\n\t" \
+		LAST_OP \
+		: [u] "=&v"(tA_), [v] "=&v"(tB_), [w] "=&v"(tC_), [acc] "+v"(acc) \
+		: [dD] "v"(dDc), [dA] "v"(dA), [dB] "v"(dB), [dC] "v"(dC), [c1] "s"(nb1), [c2] "s"(nb2), [c4] "s"(nb4), [c8] "s"(nb8))
+#define MPA_NIB_FIRST "v_and_or_b32 %[acc], %[v], %[c8], %[u]"
+#define MPA_NIB_NEXT  "v_and_or_b32 %[u], %[v], %[c8], %[u]\n\tv_lshl_or_b32 %[acc], %[acc], 4, %[u]"
+
+// What the exact bookkeeping keeps per CALL (not per lane): in LDS, read and written only by the rare paths (task ends, steps of
+// the length penalty, rows that vote), so that the sweep's registers hold nothing but the DP state.
+struct ExtCall { int32_t Gs, maxi, maxsc, pk, pen, wit, nl, al; };     // wit: witness lane of the group, -1 none yet, -2 the call is done
+#define EXT_DONE (-2)
+
+// LITE: the packed sweep of the checkpointed traceback (dp_device.h): a global alignment (no best row, no x-drop: every row of
+// every call is swept), extension bits and checkpoints out, H(nl-1, al-1) as the score.
+template<int G, bool LITE = false>
 __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp, const WavePos wp)
 {
 	constexpr int NG = 64 / G;               // lane groups per wave
 	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
 	char *lds_prof = wp.lds;                                           // [NSLOT][G columns][23] int16
-	uint2 *lds_ring = (uint2*)(lds_prof + ((NSLOT * G * PROF_COL_STRIDE + 7) & ~7)); // [NG][32 rows] {record of half 0, record of half 1}
-	int32_t *lds_pen = (int32_t*)(lds_ring + NG * 32);                 // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
+	uint4 *lds_ring = (uint4*)(lds_prof + NSLOT * G * PROF_COL_STRIDE);  // [NG][24 rows] decoded records (ring_entry)
+	ExtCall *lds_call = (ExtCall*)(lds_ring + 4 * EXT_RING_SLOTS);     // [NSLOT]
+	int32_t *lds_pen = (int32_t*)(lds_call + 8);                       // x[MPA_PEN_MAX], val[MPA_PEN_MAX]
 
 	const int lane = wp.lane, grp = lane / G, col = lane % G;
 	const DpConst c = a.c;
 	const uint32_t *recbase = a.rec + wvp->rec_base;
 	const int32_t max_nl = wvp->max_nl;
 
-	int32_t tid[2], nl[2], al[2], ncol[2];
-	uint32_t roff[2];
-	bool done[2];
+	uint32_t roff[2], ioP;
+	{
+		int32_t io[2];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		tid[h] = wvp->task[h * NG + grp];
-		if (tid[h] >= 0) {
-			const DTask *t = &a.tasks[tid[h]];
-			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol;
-			roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
-			done[h] = false;
-		} else nl[h] = 0, al[h] = 1, ncol[h] = G, roff[h] = 0, done[h] = true;
+		for (int h = 0; h < 2; ++h) {
+			const int32_t tid = wvp->task[h * NG + grp];
+			ExtCall e;
+			e.Gs = NEG16, e.maxi = -1, e.maxsc = INT32_MIN, e.pk = 0, e.pen = 0;
+			if (tid >= 0) {
+				const DTask *t = &a.tasks[tid];
+				e.nl = t->nl, e.al = t->al, e.wit = -1, io[h] = t->io;
+				roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
+			} else e.nl = 0, e.al = 1, e.wit = EXT_DONE, io[h] = 0, roff[h] = 0;
+			if (col == 0) lds_call[h * NG + grp] = e;
+		}
+		ioP = pack16(io[0], io[1]);
 	}
-	// ---- stage the profiles: global [22][pw] int16 -> LDS [col][aa]{lo, hi}
+	// ---- stage the profiles: global [22][pw] int16 -> LDS [col][aa]
 	for (int s = 0; s < NSLOT; ++s) {
 		const int t = wvp->task[s];
 		if (t < 0) {   // an empty slot scores zero everywhere (its half never reaches a result)
@@ -481,181 +701,332 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		}
 	}
 	for (int k = lane; k < MPA_PEN_MAX; k += 64) lds_pen[k] = a.pen.x[k], lds_pen[MPA_PEN_MAX + k] = a.pen.val[k];
-	// ---- record ring of 32 rows per lane group.  Lane (grp, col<16) moves row (16k + col): rows [0,16) go in now,
-	// rows [16,32) wait in `pf`; from then on rows [i+16, i+32) are fetched when i%16==0 and published when i%16==12.
-	const bool loader = col < 16;
+	// ---- record ring: 24 decoded rows per lane group, row r in slot (r + 20) % 24, so that the record two rows ahead of row i
+	// is in slot rs = (i - 2) % 24 and a block of 12 rows reads 12 consecutive slots (slot 24 repeats slot 0).  Rows [0, 16) go in now, rows [16, 28) wait in
+	// `pf`; whenever rs reaches 0 or 12 the lanes col < 12 publish the 12 rows in `pf` into the OTHER half of the ring and request
+	// the 12 rows after them (the records are padded behind the last call: dp_exec.hip).
+	uint4 *ring = lds_ring + grp * EXT_RING_SLOTS;
 	uint2 pf = make_uint2(0, 0);
-	if (loader) {
-		lds_ring[grp * 32 + col] = make_uint2(recbase[roff[0] + col], recbase[roff[1] + col]);
-		pf = make_uint2(recbase[roff[0] + 16 + col], recbase[roff[1] + 16 + col]);
-	}
+	if (col < 16) ring[col < 4 ? col + 20 : col - 4] = ring_entry(recbase[roff[0] + col], recbase[roff[1] + col]);
+	if (col < EXT_BLOCK_ROWS) pf = make_uint2(recbase[roff[0] + 16 + col], recbase[roff[1] + 16 + col]);
 	wave_sync();
 
 	// ---- per-lane constants
 	const uint32_t jge = splat16(col * c.ge), gojge = splat16(c.go + col * c.ge);
-	const uint32_t ebv = pack16(col == al[0] - 1 ? c.end_bonus : 0, col == al[1] - 1 ? c.end_bonus : 0);
-	const uint32_t vmskP = (col < ncol[0] ? 0x8000u : 0u) | (col < ncol[1] ? 0x80000000u : 0u);   // sign bits of the live halves
-	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
-	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
+	const uint32_t goP = __builtin_amdgcn_readfirstlane(splat16(c.go)), fsP = __builtin_amdgcn_readfirstlane(splat16(c.fs));
 	const uint32_t pbase0 = (uint32_t)(((0 * NG + grp) * G + col) * PROF_COL_STRIDE);
 	const uint32_t pbase1 = (uint32_t)(((1 * NG + grp) * G + col) * PROF_COL_STRIDE);
-	const uint2 *ring = lds_ring + grp * 32;
+	// (absolute LDS addresses of this lane's two profile columns, for the asm rows)
+	const uint32_t pb0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_prof + pbase0, pb1 = pb0 - pbase0 + pbase1;
+	const uint32_t sel_lo = __builtin_amdgcn_readfirstlane(0x05040100u);   // v_perm_b32: {low half of src0, low half of src1}
+	const uint32_t nb1 = __builtin_amdgcn_readfirstlane(0x00010001u), nb2 = __builtin_amdgcn_readfirstlane(0x00020002u),
+	               nb4 = __builtin_amdgcn_readfirstlane(0x00040004u), nb8 = __builtin_amdgcn_readfirstlane(0x00080008u);
+	// LITE: the three-row accumulator of extension-bit nibbles, the difference that holds row i's D bit, the D state the row before
+	// row i's precomputation replaced (what a checkpoint wants), the wave's slice of the bit words (one dword per lane and 3 rows)
+	uint32_t acc = 0, dDc = 0, Dold = NEGP;
+	uint32_t *lite_p = LITE ? a.lite + wvp->lite_off + lane : nullptr;
 
 	// ---- DP state: rings of three rows (compile-time indexed), A/B/C persist
-	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP, Hbest = NEGP;
+	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], M[3], A = NEGP, B = NEGP, C = NEGP, Hbest = NEGP;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
-	uint32_t kscan[3] = { NEGP, NEGP, NEGP };                        // fill registers of the row's scan (scan_max_pk_keep)
+	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = M[k] = NEGP;
+	uint32_t k0 = NEGP, k1 = NEGP, k2 = NEGP, k3 = NEGP, ke = NEGP, kc = NEGP;   // fill registers of the asm rows' scan: only ever written by DPP moves
 	// virtual column -1 as row 2 sees it (nasw-sse.c:256-258): H(-1,-1)=0, H(0,-1)=H(1,-1)=-fs
 	if (col == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
-	// donor[i-1], donor[i], donor[i+1] live in dn[R1], dn[R2]... : record r carries donor[r+1] and acceptor[r]
+	// record r carries donor[r+1] and acceptor[r]
 	{
-		const uint2 q0 = ring[0], q1 = ring[1];
-		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
-		ac[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0b070903u), ac[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0b070903u);
-		dn[2] = ac[2] = 0;
+		const uint4 q0 = ring[20], q1 = ring[21];
+		dn[1] = q0.x, dn[0] = q1.x, ac[1] = q0.y, ac[0] = q1.y, dn[2] = ac[2] = 0;
 	}
 
-	// ---- bookkeeping of the reference's score-only loop (nasw-sse.c:423-433), per half
-	int32_t Gs[2] = { NEG16, NEG16 }, maxi[2] = { -1, -1 }, maxsc[2] = { INT32_MIN, INT32_MIN };
-	int32_t pk[2] = { 0, 0 }, pen[2] = { 0, 0 }, wit[2] = { -1, -1 };
-	uint32_t Gv = NEGP, Tv = NEGP, penP = 0, witP = 0;
+	// Vote thresholds, per lane and half: the exact bookkeeping (nasw-sse.c:423-433) runs for a row unless TvL <= H <= GvL in every
+	// lane.  Start: always.
+	uint32_t GvL = NEGP, TvL = 0x7fff7fffu;
 	int32_t next_event = 2, limit = max_nl;
 
-	auto repack = [&]() {
-		Gv = pack16(done[0] ? 32767 : Gs[0], done[1] ? 32767 : Gs[1]);
-		Tv = pack16(done[0] ? NEG16 : sat16(Gs[0] - c.xdrop), done[1] ? NEG16 : sat16(Gs[1] - c.xdrop));
-		penP = pack16(pen[0], pen[1]);
-		witP = (!done[0] && wit[0] == col ? 0x8000u : 0u) | (!done[1] && wit[1] == col ? 0x80000000u : 0u);
-		if (__ballot(!done[0] || !done[1]) == 0) limit = 0;                 // every call of the wave has finished
+	// The rare paths work on the two calls of this lane's group, fetched from LDS (every lane of the group computes the same; lane 0
+	// of the group writes back).  The lane index is made opaque in each of them: otherwise their lane-dependent constants (masks,
+	// shuffle addresses) are hoisted out of the sweep and held in registers across it.
+	auto load_calls = [&](ExtCall (&e)[2], int &lane_, int &grp_, int &col_) {
+		lane_ = lane;
+		asm volatile("" : "+v"(lane_));
+		grp_ = lane_ / G, col_ = lane_ % G;
+		e[0] = lds_call[grp_], e[1] = lds_call[NG + grp_];
+	};
+	auto store_calls = [&](const ExtCall (&e)[2], const int grp_, const int col_) {
+		if (col_ == 0) lds_call[grp_] = e[0], lds_call[NG + grp_] = e[1];
+		wave_sync();
 	};
 
-	// task ends and steps of the length penalty: rare, handled before the row is computed
-	auto events = [&](int32_t i) {
+	// For a call that is not done, row i needs the bookkeeping iff some live lane has cand > Gs (a new best row) or the row
+	// maximum m < Gs - xdrop, where cand = sat(sat(H + eb) - pen), eb = the end bonus in column al - 1, pen >= 0.
+	//   * cand <= H + eb - pen unless the lower clamp raised it to -32768, which beats no Gs: cand > Gs implies H > Gs + pen - eb.
+	//   * the witness lane w held the row maximum at the last bookkeeping; cand_w >= min(32767, H_w + eb) - pen, so
+	//     H_w >= Gs - xdrop + pen - eb (and 32767 - pen >= Gs - xdrop) proves m >= cand_w >= Gs - xdrop.
+	// Whenever a bound does not fit int16 (absurd ie_coef / x-drop: never with the reference's defaults), or a call has no witness
+	// yet, the thresholds are set so that EVERY row votes: lo = 32767, hi = -32768 makes the clamp return 32767 in every lane,
+	// and H stays below 32 000 in the packed kernels (dp_exec.hip refuses calls that could saturate).
+	auto repack = [&](const ExtCall (&e)[2], const int col_) {
+		int32_t gl[2], tl[2];
+		bool force = false, any = false;
+		if (LITE) {
+			if (__ballot(e[0].wit != EXT_DONE || e[1].wit != EXT_DONE) == 0) limit = 0;
+			return;
+		}
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			gl[h] = 32767, tl[h] = NEG16;
+			if (e[h].wit == EXT_DONE) continue;
+			any = true;
+			const int32_t eb = col_ == e[h].al - 1 ? c.end_bonus : 0;
+			if (col_ < (e[h].al + 7) / 8 * 8) {
+				const int32_t g = e[h].Gs + e[h].pen - eb;
+				if (g < NEG16) force = true;
+				gl[h] = g < NEG16 ? NEG16 : g > 32767 ? 32767 : g;
+			}
+			if (e[h].wit < 0 || 32767 - e[h].pen < e[h].Gs - c.xdrop) force = true;
+			if (e[h].wit == col_) {
+				const int32_t t = e[h].Gs - c.xdrop + e[h].pen - eb;
+				if (t > 32767 || t < NEG16) force = true;
+				tl[h] = t < NEG16 ? NEG16 : t > gl[h] ? gl[h] : t;
+			}
+		}
+		GvL = pack16(gl[0], gl[1]), TvL = pack16(tl[0], tl[1]);
+		if (__ballot(force) != 0) GvL = NEGP, TvL = 0x7fff7fffu;
+		if (__ballot(any) == 0) limit = 0;                                  // every call of the wave has finished
+	};
+
+	// task ends and steps of the length penalty: rare, handled before the row is computed.  h_prev = the H row of row i - 1.
+	auto events = [&](const int32_t i, const uint32_t h_prev) {
+		ExtCall e[2];
+		int lane_, grp_, col_;
+		load_calls(e, lane_, grp_, col_);
 		int32_t nx = INT32_MAX;
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
-			if (!done[h] && i >= nl[h]) done[h] = true;
-			if (!done[h]) {
-				const int64_t x = (int64_t)i - 3 * (int64_t)al[h];
-				while (x >= (int64_t)lds_pen[pk[h] + 1]) ++pk[h];
-				pen[h] = lds_pen[MPA_PEN_MAX + pk[h]];
-				int64_t e = (int64_t)lds_pen[pk[h] + 1] + 3 * (int64_t)al[h];
-				if (e > nl[h]) e = nl[h];
-				nx = nx < (int32_t)e ? nx : (int32_t)e;
+			if (e[h].wit != EXT_DONE && i >= e[h].nl) {
+				e[h].wit = EXT_DONE;
+				// LITE: row nl - 1 was the call's last: its score is H(nl-1, al-1) (nasw-sse.c:543); a call of fewer than three rows has none
+				if (LITE && col_ == e[h].al - 1) a.score[wvp->task[h * NG + grp_]] = e[h].nl < 3 ? NEG16 : half16(h_prev, h);
+			}
+			if (e[h].wit != EXT_DONE) {
+				int64_t nxt = e[h].nl;
+				if (!LITE) {
+					const int64_t x = (int64_t)i - 3 * (int64_t)e[h].al;
+					while (x >= (int64_t)lds_pen[e[h].pk + 1]) ++e[h].pk;
+					e[h].pen = lds_pen[MPA_PEN_MAX + e[h].pk];
+					nxt = (int64_t)lds_pen[e[h].pk + 1] + 3 * (int64_t)e[h].al;
+					if (nxt > e[h].nl) nxt = e[h].nl;
+				}
+				nx = nx < (int32_t)nxt ? nx : (int32_t)nxt;
 			}
 		}
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_xor(nx, off); nx = nx < o ? nx : o; }
 		next_event = __builtin_amdgcn_readfirstlane(nx);
-		repack();
+		store_calls(e, grp_, col_);
+		repack(e, col_);
 	};
 
-	int32_t i = 2;
-	// software pipeline over LDS latency: the record of row i+2 is in flight while the profile scores of row
-	// i+1 are fetched with the (already landed) record of row i+1 at the very start of row i
-	uint2 rcur = ring[2], rnext = ring[3];                                 // records of rows i and i+1
-	uint32_t S;                                                            // profile scores of row i
-	{
-		S = prof2(lds_prof + pbase0 + (rcur.x & 0xff), lds_prof + pbase1 + (rcur.y & 0xff));
-	}
-
-	auto row = [&](auto kc) {
-		constexpr int K = decltype(kc)::value;
-		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;   // ring slots of rows i-1, i-2, i-3
-		// ring maintenance, 16 rows at a time: fetch rows [i+16, i+32) when i%16==0, publish them when i%16==12
-		if ((i & 15) == 12) {                                              // rows [i+4, i+20) published (the first time: the preloaded rows [16,32)), the next 16 requested
-			if (loader) {
-				lds_ring[grp * 32 + ((i + 4) & 31) + col] = pf;
-				pf = make_uint2(recbase[roff[0] + (uint32_t)i + 20 + col], recbase[roff[1] + (uint32_t)i + 20 + col]);
+	// exact restatement of nasw-sse.c:423-433 for row i, whose final H row is h
+	auto book = [&](const uint32_t h, const int32_t i) {
+		ExtCall e[2];
+		int lane_, grp_, col_;
+		load_calls(e, lane_, grp_, col_);
+		const uint32_t ebv = pack16(col_ == e[0].al - 1 ? c.end_bonus : 0, col_ == e[1].al - 1 ? c.end_bonus : 0);
+		const uint32_t cand = p_subs(p_adds(h, ebv), pack16(e[0].pen, e[1].pen));
+#pragma unroll
+		for (int hh = 0; hh < 2; ++hh) {
+			const int32_t cv = half16(cand, hh);
+			const bool live = col_ < (e[hh].al + 7) / 8 * 8;
+			const int32_t m = group_max<G>(live ? cv : NEG16);
+			if (e[hh].wit == EXT_DONE) continue;
+			if (m > e[hh].Gs) {                                              // new best row
+				e[hh].Gs = m, e[hh].maxi = i, e[hh].maxsc = m + e[hh].pen;
+				Hbest = hh ? ((Hbest & 0xffffu) | (h & 0xffff0000u)) : ((Hbest & 0xffff0000u) | (h & 0xffffu));
+			}
+			if (e[hh].Gs - m > c.xdrop) e[hh].wit = EXT_DONE;                // x-drop
+			else {                                                           // witness: the first lane holding the row maximum
+				const uint64_t at = __ballot(live && cv == m) & group_mask<G>(lane_);
+				e[hh].wit = (__ffsll((unsigned long long)at) - 1) % G;
 			}
 		}
+		store_calls(e, grp_, col_);
+		repack(e, col_);
+	};
+
+	int32_t i = 2, rs = 0;                                                 // rs = (i - 2) % 24: ring slot of the record of row i + 2
+	bool have_hD = false;                                                  // hD (below) already holds row i's max(diagonal, D)
+	uint32_t hD = NEGP;
+	uint4 rcur = ring[22], rnext = ring[23];                               // records of rows i and i + 1
+	uint32_t S = prof2s(pb0 + (rcur.w & 0xffff), pb1 + (rcur.w >> 16));   // profile scores of row i
+
+	auto refill = [&]() {                                                  // rs is 0 or 12: rows [i + 14, i + 26) published, the next 12 requested
+		int lane_ = lane;
+		asm volatile("" : "+v"(lane_));
+		const int col_ = lane_ % G;
+		if (col_ < EXT_BLOCK_ROWS) {
+			const uint4 e = ring_entry(pf.x, pf.y);
+			uint4 *rg = lds_ring + lane_ / G * EXT_RING_SLOTS;
+			rg[(rs ^ 12) + col_] = e;
+			if (rs == 12 && col_ == 0) rg[EXT_RING_ROWS] = e;                // slot 0 again behind slot 23
+			pf = make_uint2(recbase[roff[0] + (uint32_t)i + 26 + col_], recbase[roff[1] + (uint32_t)i + 26 + col_]);
+		}
+	};
+
+	// LITE: the DP state at the top of row i = 2 + k * MPA_TB_BLOCK (a row with K = 0: slots 0, 1, 2 hold rows i-1, i-2, i-3)
+	auto checkpoint = [&](const int32_t i, const uint32_t d3) {
+		uint32_t *p = a.ckpt + wvp->ck_off + (int64_t)((i - 2) / MPA_TB_BLOCK - 1) * 9 * 64 + lane;
+		p[0] = Hr[0], p[64] = Hr[1], p[128] = Hr[2], p[192] = Dr[0], p[256] = Dr[1], p[320] = d3, p[384] = A, p[448] = B, p[512] = C;
+	};
+
+	// ---- the generic row: plain C++, any row.  (The lane index is opaque here as well: the row runs a few dozen times per call, and
+	// what it derives from the lane must not be kept in registers across the asm rows.)
+	auto row = [&](auto kc_) {
+		constexpr int K = decltype(kc_)::value;
+		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;   // ring slots of rows i-1, i-2, i-3
+		int lane_ = lane;
+		asm volatile("" : "+v"(lane_));
+		const int col_ = lane_ % G;
+		if (rs == 0 || rs == 12) refill();
+		if (LITE && K == 0 && i > 2 && (uint32_t)(i - 2) % MPA_TB_BLOCK == 0) checkpoint(i, have_hD ? Dold : Dr[R3]);
 		// next row's profile scores and the record of row i+2: issued first, consumed one row later
-		const uint32_t Snext = prof2(lds_prof + pbase0 + (rnext.x & 0xff), lds_prof + pbase1 + (rnext.y & 0xff));
-		const uint2 rnn = ring[(i + 2) & 31];
-		// unpack the record of row i: donor[i+1], acceptor[i], gap extension of this row
-		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);        // dn: R1 = donor[i-1], R2 = donor[i]... see below
-		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
-		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
-		// after the two assignments: dn[R3]=donor[i+1], dn[R1]=donor[i], dn[R2]=donor[i-1];
-		//                            ac[R3]=acceptor[i], ac[R1]=acceptor[i-1], ac[R2]=acceptor[i-2]
-		uint32_t h, t, u;
-		h = p_adds(Hs[R3], S);                                             // H(i-3,j-1) + s(i,j)
-		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);                     // D
-		t = p_subs(t, gei); Dr[R3] = t; h = p_max(h, t);
+		const uint32_t Snext = prof2s(pb0 + (rnext.w & 0xffff), pb1 + (rnext.w >> 16));
+		const uint4 rnn = ring[rs];
+		dn[R3] = rcur.x, ac[R3] = rcur.y;                                  // donor[i+1], acceptor[i]
+		// now dn[R3]=donor[i+1], dn[R1]=donor[i], dn[R2]=donor[i-1]; ac[R3]=acceptor[i], ac[R1]=acceptor[i-1], ac[R2]=acceptor[i-2]
+		uint32_t h, t, u, dA = 0, dB = 0, dC = 0;
+		if (have_hD) h = hD;
+		else {
+			h = p_adds(Hs[R3], S);                                         // H(i-3,j-1) + s(i,j)
+			u = p_subs(Hr[R3], goP);                                       // D
+			if (LITE) dDc = p_subs(u, Dr[R3]);
+			t = p_max(u, Dr[R3]);
+			t = p_subs(t, rcur.z); Dr[R3] = t; h = p_max(h, t);
+		}
 		u = p_subs(Hr[R1], ioP); t = p_subs(u, dn[R2]);                    // A: phase-0 intron, donor[i-1], acceptor[i]
+		if (LITE) dA = p_subs(t, A);
 		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ac[R3]));
 		u = p_subs(Hs[R1], ioP); t = p_subs(u, dn[R1]);                    // B: phase-1 intron, donor[i], acceptor[i-2]
+		if (LITE) dB = p_subs(t, B);
 		t = p_max(t, B); B = t; h = p_max(h, p_subs(t, ac[R2]));
 		t = p_subs(u, dn[R3]);                                             // C: phase-2 intron, donor[i+1], acceptor[i-1]
+		if (LITE) dC = p_subs(t, C);
 		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, ac[R1]));
+		if (LITE) {                                                        // the row's extension bits into the three-row word
+			const uint32_t nib = (dDc >> 15 & 0x00010001u) | (dA >> 14 & 0x00020002u) | (dB >> 13 & 0x00040004u) | (dC >> 12 & 0x00080008u);
+			acc = K == 0 ? nib : (acc << 4 | nib);
+			if (K == 2) *lite_p = acc, lite_p += 64;
+		}
 		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));          // four frameshift moves
 		h = p_max(h, p_subs(t, fsP));
 		// horizontal gap chain as a prefix max of h + j*ge
-		const uint32_t y = scan_max_pk_keep<G>(p_adds(h, jge), kscan);
-		const uint32_t ex = shift1<G>(y, NEGP, lane);
+		const uint32_t y = scan_max_pk<G>(p_adds(h, jge));
+		const uint32_t ex = shift1<G>(y, NEGP, lane_);
 		h = p_max(h, p_subs(ex, gojge));
-		Hr[R3] = h, Hs[R3] = shift1<G>(h, NEGP, lane);
-		// votes: sign bit of x set <=> this lane beats the call's best; of y <=> below the x-drop threshold
-		const uint32_t cand = p_subs(p_adds(h, ebv), penP);
-		const uint32_t x = p_subs(Gv, cand), yy = p_subs(cand, Tv);
-		const uint32_t vote = (x & vmskP) | (yy & witP);
-		if (__ballot(vote != 0) != 0) {
-			// slow path: exact restatement of nasw-sse.c:423-433 for the calls that need it
-#pragma unroll
-			for (int hh = 0; hh < 2; ++hh) {
-				const int32_t cv = half16(cand, hh);
-				const bool live = col < ncol[hh];
-				const int32_t m = group_max<G>(live ? cv : NEG16);
-				if (!done[hh] && m > Gs[hh]) {                               // new best row
-					Gs[hh] = m, maxi[hh] = i, maxsc[hh] = m + pen[hh];
-					Hbest = hh ? ((Hbest & 0xffffu) | (h & 0xffff0000u)) : ((Hbest & 0xffff0000u) | (h & 0xffffu));
-				}
-				if (!done[hh]) {
-					if (Gs[hh] - m > c.xdrop) done[hh] = true;               // x-drop
-					else {                                                   // witness: the first lane holding the row maximum
-						const uint64_t at = __ballot(live && cv == m) & group_mask<G>(lane);
-						wit[hh] = (__ffsll((unsigned long long)at) - 1) % G;
-					}
-				}
-			}
-			repack();
-		}
-		if (i == 2 && col == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;               // column -1 is -inf from row 3 on
+		Hr[R3] = h, Hs[R3] = shift1<G>(h, NEGP, lane_);
+		if (!LITE) { if (__ballot(p_max(p_min(h, GvL), TvL) != h) != 0) book(h, i); }
+		if (i == 2 && col_ == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;              // column -1 is -inf from row 3 on
 		S = Snext;
 		rcur = rnext, rnext = rnn;
-		++i;
+		++i, rs = rs == EXT_RING_ROWS - 1 ? 0 : rs + 1, have_hD = false;
 	};
 
+	// ---- the asm rows: blocks of 12 rows that contain no event, entered at rs = 0 or 12 (where i - 2 is a multiple of 3)
+	auto fast_blocks = [&]() {
+		uint32_t tA_, tB_, tC_, h, x, hDn, a0, a1, vt, dA, dB, dC, drn, dDn;
+		v2s sraw0, sraw1;                                                  // (.x = a profile score; .y is never set: v_perm_b32 takes the low halves)
+		M[0] = p_max(Hr[0], Hs[0]), M[1] = p_max(Hr[1], Hs[1]);
+		if (!have_hD) {                                                    // row i's diagonal term and D state (slot R3 = 2)
+			const uint32_t u = p_subs(Hr[2], goP), t = p_max(u, Dr[2]);
+			if (LITE) dDc = p_subs(u, Dr[2]), Dold = Dr[2];
+			Dr[2] = p_subs(t, rcur.z);
+			hD = p_max(p_adds(Hs[2], S), Dr[2]);
+		}
+		sraw0.x = *(lds_s16p)(uintptr_t)(pb0 + (rnext.w & 0xffff)), sraw1.x = *(lds_s16p)(uintptr_t)(pb1 + (rnext.w >> 16));
+		uint4 rnn = ring[rs];                                              // record of row i + 2; from here on fetched a row before it is needed
+		do {
+			// (every outstanding global load is 12 rows old here -- or a register reload at the entry: said once, outside the rows, so
+			// that no row waits for the loads refill() is about to issue)
+			__builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0)
+			refill();
+			if (LITE && (uint32_t)(i - 2) % MPA_TB_BLOCK == 0) checkpoint(i, Dold);
+			const uint4 *rb = ring + rs;
+#pragma unroll 1
+			for (int g = 0; g < EXT_BLOCK_ROWS / 3; ++g, rb += 3) {
+#define MPA_FAST_ROW(K, R1, R2, R3) { \
+				if constexpr (!LITE) { \
+					MPA_ROW_HEAD(Hr[R1], Hs[R1], dn[R1], dn[R2], rcur.x, ac[R1], ac[R2], rcur.y, M[R1], M[R2]); \
+					dn[R3] = rcur.x, ac[R3] = rcur.y; \
+					if constexpr (G == 16) MPA_ROW_TAIL(MPA_EX16, MPA_HS16, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else if constexpr (G == 32) MPA_ROW_TAIL(MPA_EX32, MPA_HS32, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else MPA_ROW_TAIL(MPA_EX64, MPA_HS64, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+				} else { \
+					MPA_ROW_HEAD_L(Hr[R1], Hs[R1], dn[R1], dn[R2], rcur.x, ac[R1], ac[R2], rcur.y, M[R1], M[R2]); \
+					dn[R3] = rcur.x, ac[R3] = rcur.y; \
+					if constexpr (G == 16) MPA_ROW_TAIL_L(MPA_EX16_L, MPA_HS16, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else if constexpr (G == 32) MPA_ROW_TAIL_L(MPA_EX32_L, MPA_HS32, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else MPA_ROW_TAIL_L(MPA_EX64_L, MPA_HS64, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					if constexpr (K == 0) MPA_NIBBLE(MPA_NIB_FIRST); else MPA_NIBBLE(MPA_NIB_NEXT); \
+					Dold = Dr[R2], Dr[R2] = drn, dDc = dDn; \
+					if constexpr (K == 2) *lite_p = acc, lite_p += 64; \
+				} \
+				sraw0.x = *(lds_s16p)(uintptr_t)a0, sraw1.x = *(lds_s16p)(uintptr_t)a1; \
+				rcur = rnext, rnext = rnn, rnn = rb[K + 1]; \
+				Hr[R3] = h, hD = hDn; \
+				if constexpr (!LITE) { if (__ballot(vt != h) != 0) book(h, i); } \
+				++i; }
+				MPA_FAST_ROW(0, 0, 1, 2)
+				MPA_FAST_ROW(1, 2, 0, 1)
+				MPA_FAST_ROW(2, 1, 2, 0)
+#undef MPA_FAST_ROW
+			}
+			rs ^= 12;
+		} while (i + EXT_BLOCK_ROWS <= (limit < next_event ? limit : next_event));
+		have_hD = true;
+	};
+
+	// (slot of row i - 1 before a row with K = 0, 1, 2: 0, 2, 1)
 	while (i < limit) {
-		if (i >= next_event) { events(i); if (i >= limit) break; }
+		if (i >= next_event) { events(i, Hr[0]); if (i >= limit) break; }
+		if ((rs == 0 || rs == 12) && i >= 14 && i + EXT_BLOCK_ROWS <= (limit < next_event ? limit : next_event)) { fast_blocks(); continue; }
 		row(std::integral_constant<int, 0>());
 		if (i >= limit) break;
-		if (i >= next_event) { events(i); if (i >= limit) break; }
+		if (i >= next_event) { events(i, Hr[2]); if (i >= limit) break; }
 		row(std::integral_constant<int, 1>());
 		if (i >= limit) break;
-		if (i >= next_event) { events(i); if (i >= limit) break; }
+		if (i >= next_event) { events(i, Hr[1]); if (i >= limit) break; }
 		row(std::integral_constant<int, 2>());
+	}
+	if (LITE) {
+		// the last word may be partial (the sweep ended inside a group of three rows), and calls that end with the wave's last row
+		// have not met their task-end event yet
+		const int32_t part = (i - 2) % 3;
+		if (part != 0) *lite_p = acc << (4 * (3 - part));
+		if (i >= next_event && limit != 0) events(i, part == 0 ? Hr[0] : part == 1 ? Hr[2] : Hr[1]);
+		return;
 	}
 
 	// ---- results (nasw-sse.c:435-443): first column of the best row that attains the best score
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		if (tid[h] < 0) continue;
+		const int32_t tid = wvp->task[h * NG + grp];
+		if (tid < 0) continue;
+		const ExtCall e = lds_call[h * NG + grp];
 		int32_t first = INT32_MAX;
-		if (maxi[h] >= 0) {
+		if (e.maxi >= 0) {
 			int32_t v = half16(Hbest, h);
-			if (col == al[h] - 1) v += c.end_bonus;
-			const uint64_t m = __ballot(col < al[h] && v == maxsc[h]) & group_mask<G>(lane);
+			if (col == e.al - 1) v += c.end_bonus;
+			const uint64_t m = __ballot(col < e.al && v == e.maxsc) & group_mask<G>(lane);
 			if (m != 0) first = (__ffsll((unsigned long long)m) - 1) % G;
 		}
 		if (col == 0) {
 			ExtOut o;
-			o.nt_len = maxi[h] + 1;
-			o.aa_len = maxi[h] < 0 ? 0 : (first == INT32_MAX ? al[h] + 1 : first + 1);
-			o.score = maxsc[h];
-			o.flags = (maxi[h] >= 0 && first == INT32_MAX) ? 1 : 0;       // the reference assert()s here
-			a.out[tid[h]] = o;
+			o.nt_len = e.maxi + 1;
+			o.aa_len = e.maxi < 0 ? 0 : (first == INT32_MAX ? e.al + 1 : first + 1);
+			o.score = e.maxsc;
+			o.flags = (e.maxi >= 0 && first == INT32_MAX) ? 1 : 0;        // the reference assert()s here
+			a.out[tid] = o;
 		}
 	}
 }
@@ -1094,8 +1465,17 @@ __device__ __forceinline__ int32_t glob_cands(GlobState &s, const uint32_t rcur,
 // kernel's exact int32 arithmetic (calls wider than the 1024 columns k_ext_wide covers): no traceback words, instead the
 // per-row key (best H + end bonus, first column) that k_ext_replay consumes.
 #define GLOB_NARROW_LDS ((size_t)22 * 64 * 2 + (size_t)4 * 32 * 4)   /* bytes per wave */
+// One block of rows of a call swept again from a checkpoint of the packed sweep (the checkpointed traceback, dp_device.h; k_walk):
+// the sweep's row 2 is the call's row row_off + 2, the state comes from the checkpoint (nullptr: the call's first block, standard
+// start), the traceback words go to tb[(row - 2) * ncol + column] in LDS.  One call, in lane group 0.
+struct GlobResume {
+	int32_t row_off, n_rows;
+	const uint32_t *ck;
+	int32_t ck_lane0, half;
+	uint16_t *tb;
+};
 template<int G, bool MB, bool EXT = false, bool WIDE = false>
-__device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv, const WavePos wp)
+__device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv, const WavePos wp, const GlobResume *rz = nullptr)
 {
 	constexpr int NG = 64 / G;
 	int16_t *lds_prof = (int16_t*)wp.lds;            // [NG][22][G] for the current column block
@@ -1105,11 +1485,11 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 	DTask t;
 	if (tid >= 0) t = a.tasks[tid];
 	else { t.nl = 0, t.al = 1, t.ncol = 8, t.pw = G, t.rec_off = 0, t.prof_off = 0, t.tb_off = 0, t.bnd_off = 0, t.io = 0; }
-	const int32_t nl = t.nl, ncol = t.ncol, slen = ncol >> 3;
+	const int32_t nl = rz ? (t.nl - rz->row_off < rz->n_rows + 2 ? t.nl - rz->row_off : rz->n_rows + 2) : t.nl, ncol = t.ncol, slen = ncol >> 3;
 	const int32_t nblk = MB ? (ncol + 63) / 64 : 1;
 	const int32_t go = c.go, ge = c.ge, goe = (int16_t)(c.go + c.ge), io = t.io, fs = c.fs;
-	const uint32_t *rec = a.rec + t.rec_off;
-	uint16_t *tb = a.tb + (EXT ? 0 : t.tb_off);
+	const uint32_t *rec = a.rec + t.rec_off + (rz ? rz->row_off : 0);
+	uint16_t *tb = rz ? rz->tb - 2 * ncol : a.tb + (EXT ? 0 : t.tb_off);          // (rz: row 2 of the sweep is the block's first row)
 	unsigned long long *rowkey = EXT ? a.rowkey64 + t.tb_off : nullptr;
 	int4 *bnd = a.bnd + t.bnd_off;
 
@@ -1144,7 +1524,19 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		const bool first_blk = !MB || blk == 0, last_blk = !MB || blk == nblk - 1;
 
 		GlobState gs;
-		glob_state_init(gs, ring[0], ring[1], first_blk && col == 0, fs);
+		glob_state_init(gs, ring[0], ring[1], first_blk && col == 0 && !(rz && rz->ck), fs);
+		if (rz && rz->ck) {
+			// the packed sweep's registers at the top of this row: H and D of rows i-1, i-2, i-3 (this sweep's slots 1, 0, 2), A, B, C;
+			// H shifted by one column follows (column -1 is -inf behind row 2)
+			const uint32_t *p = rz->ck + rz->ck_lane0 + (col < ncol ? col : 0);
+			const int sh = rz->half * 16;
+			auto half_splat = [&](const uint32_t x) { return spl((int32_t)(x >> sh)); };
+			gs.H[1] = half_splat(p[0]), gs.H[0] = half_splat(p[64]), gs.H[2] = half_splat(p[128]);
+			gs.D[1] = half_splat(p[192]), gs.D[0] = half_splat(p[256]), gs.D[2] = half_splat(p[320]);
+			gs.A = half_splat(p[384]), gs.B = half_splat(p[448]), gs.C = half_splat(p[512]);
+			if (!live) { for (int k = 0; k < 3; ++k) gs.H[k] = gs.D[k] = NEGP; gs.A = gs.B = gs.C = NEGP; }
+			for (int k = 0; k < 3; ++k) gs.Hs[k] = shift1<G>(gs.H[k], NEGP, lane);
+		}
 		const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs), ge_s = splat16(ge);
 		const char *profb = (const char*)myprof;                // + byte0(record) * G = this lane's score for the row's amino acid
 		uint32_t r[3];                                          // records of rows i, i+1 (and, once fetched, i+2) at slot row mod 3
@@ -1153,7 +1545,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		uint32_t keep_py = (uint32_t)NEG32, keep_h1 = (uint32_t)NEG16, keep_i1 = (uint32_t)NEG16, keep_hs = NEGP;   // !MB: see shift1_keep
 		int32_t hfin = NEG16;                                   // H of the last live row
 
-		const int32_t max_nl = wv.max_nl;                 // (a register copy: through the reference it is re-loaded, and waited for, every row)
+		const int32_t max_nl = rz ? nl : wv.max_nl;        // (a register copy: through the reference it is re-loaded, and waited for, every row)
 		auto row = [&](auto kc, const int32_t i) {
 			constexpr int K = decltype(kc)::value;
 			const bool rowlive = i < nl;
@@ -1220,9 +1612,9 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 			if (i + 1 < max_nl) row(std::integral_constant<int, 0>(), i + 1);
 			if (i + 2 < max_nl) row(std::integral_constant<int, 1>(), i + 2);
 		}
-		if (!EXT && tid >= 0 && nl >= 3 && gc == t.al - 1) a.score[tid] = hfin;
+		if (!EXT && !rz && tid >= 0 && nl >= 3 && gc == t.al - 1) a.score[tid] = hfin;
 	}
-	if (!EXT && tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
+	if (!EXT && !rz && tid >= 0 && nl < 3 && col == 0) a.score[tid] = NEG16;
 }
 
 // one launch for the narrow traceback shapes (classes 16 / 32 / 64 lanes and the block-major one), see k_ext_narrow
@@ -1230,7 +1622,7 @@ template<bool WIDE>
 __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 {
 	int b = blockIdx.x;
-	extern __shared__ uint32_t lds_raw[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
 	const WavePos wp = whole_block((char*)lds_raw);
 	if (b < m.cnt[0]) { glob_narrow<16, false, false, WIDE>(a, a.waves[m.first[0] + b], wp); return; }
 	b -= m.cnt[0];
@@ -1246,7 +1638,7 @@ __global__ __launch_bounds__(64) void k_glob_narrow(GlobArgs a, NarrowMap m)
 template<bool WIDE>
 __global__ __launch_bounds__(64) void k_ext_huge(GlobArgs a)
 {
-	extern __shared__ uint32_t lds_raw[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
 	glob_narrow<64, true, true, WIDE>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
 }
 
@@ -1417,7 +1809,7 @@ __device__ __forceinline__ void glob_wide_body(const GlobArgs &a, const GlobWave
 template<int NW, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void k_glob_wide(GlobArgs a)
 {
-	extern __shared__ uint32_t lds_raw[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
 	glob_wide_body<NW, WIDE>(a, a.waves[blockIdx.x], whole_block((char*)lds_raw));
 }
 
@@ -1464,14 +1856,17 @@ __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, 
 		if (!WG_ONLY && g < u.count) glob_wide_body<2>(ga, ga.waves[u.first + g], WavePos{ lds + g * GLOB_WIDE_LDS(2), lane, w, w * 64 + lane });
 	} break;
 	case U_GLOB_W4: glob_wide_body<4>(ga, ga.waves[u.first], WavePos{ lds, lane, wv, tid }); break;
+	case U_LITE16: if (!WG_ONLY && wv < u.count) ext_narrow<16, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_LITE32: if (!WG_ONLY && wv < u.count) ext_narrow<32, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_LITE64: if (!WG_ONLY && wv < u.count) ext_narrow<64, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	default: break;
 	}
 }
 
 // (MPA_DP_POOL=0: one launch per round, one workgroup per unit, the hardware's in-order dispatcher as the task queue)
-__global__ __launch_bounds__(256) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
 {
-	extern __shared__ uint32_t lds_raw[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
 	const DpUnit u = units[blockIdx.x];
 	dp_run_unit<false>(u, ea, wa, ga, (char*)lds_raw, (int)threadIdx.x);
 }
@@ -1593,9 +1988,9 @@ __device__ __forceinline__ DpUnit dp_load_unit(const DpUnit *up)
 // groups: bodies that use the workgroup barrier) until no slot has one left; then every wave goes its own way and takes one-wave
 // units (up to eight narrow extension calls or four traceback calls each) until no slot has one of those left -- a wave whose
 // calls are x-dropped after a few hundred rows is on its next unit while its neighbour sweeps 100 000 rows.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dp_worker(DpPool *pool, const int home, const int n_slots)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_dp_worker(DpPool *pool, const int home, const int n_slots)
 {
-	extern __shared__ uint32_t lds_raw[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
 	__shared__ int32_t pick[4];                                   // slot, unit, generation (thread 0 -> the workgroup), admission
 	__shared__ int32_t seen[4];                                   // dp_acquire; [3]: waves that have left
 	char *lds = (char*)lds_raw;
@@ -1680,6 +2075,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 		case U_GLOB32: glob_narrow<32, false>(ra.ga, ra.ga.waves[u.first], wp); break;
 		case U_GLOB64: glob_narrow<64, false>(ra.ga, ra.ga.waves[u.first], wp); break;
 		case U_GLOB_MB: glob_narrow<64, true>(ra.ga, ra.ga.waves[u.first], wp); break;
+		case U_LITE16: ext_narrow<16, true>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_LITE32: ext_narrow<32, true>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_LITE64: ext_narrow<64, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		default: break;
 		}
 		__builtin_amdgcn_s_setprio(0);
@@ -1777,6 +2175,129 @@ __global__ __launch_bounds__(64) void k_backtrack(const DTask *tasks, const int3
 		if ((op == 12 || op == 13) && cig[x] >> 4 < 3) cig[x] = cig[x] >> 4 << 4 | 11;
 	}
 	if (lane == 0) n_cigar[tid] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The walk of the checkpointed traceback (dp_device.h): ns_backtrack (nasw-sse.c:40-89) over a call whose sweep kept only the four
+// extension bits per cell and a checkpoint per block of MPA_TB_BLOCK rows.  One wave per call.  Deletion and intron runs (states 2..5)
+// are followed on the bits, 64 cells at a time; in any other state the wave first recomputes the traceback words of the block it
+// stands in (glob_narrow restarted from the block's checkpoint, words into LDS) and walks those, exactly like k_backtrack -- a run
+// that leaves the block is simply continued in the next iteration.  A call is swept twice only where its path is not in a run.
+// ------------------------------------------------------------------------------------------------
+struct WalkArgs {
+	GlobArgs ga;                 // tasks, records, profiles, scoring
+	const int32_t *list;         // the calls
+	int32_t n_list;
+	const uint32_t *lite, *ckpt; // extension-bit words and checkpoints of the packed sweeps
+	uint32_t *cig;
+	int32_t *n_cigar;
+	unsigned long long *n_blocks; // (statistics) blocks recomputed
+};
+#define WALK_LDS (GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 64 * 2)
+template<int G>
+__device__ __forceinline__ void walk_call(const WalkArgs &wa, const DTask &t, const int32_t tid, char *lds, const int lane)
+{
+	constexpr int NG = 64 / G;
+	const int slot = (t.flag >> MPA_LITE_SLOT_SHIFT) & 15, half = slot / NG, lane0 = (slot % NG) * G;
+	const uint32_t *lite = wa.lite + t.tb_off + lane0;
+	uint16_t *tbs = (uint16_t*)(lds + GLOB_NARROW_LDS);            // [MPA_TB_BLOCK][ncol] words of the block that is materialised
+	uint32_t *cig = wa.cig + t.cig_off;
+	const int32_t ncol = t.ncol, cap = t.cig_cap;
+	int32_t blk = -1, blk_lo = 0, blk_hi = 0;                      // the materialised block and its rows [blk_lo, blk_hi)
+	auto ensure = [&](const int32_t row) {
+		if (blk >= 0 && row >= blk_lo && row < blk_hi) return;
+		const int32_t b = (row - 2) / MPA_TB_BLOCK;
+		GlobResume rz;
+		rz.row_off = b * MPA_TB_BLOCK, rz.n_rows = t.nl - 2 - rz.row_off < MPA_TB_BLOCK ? t.nl - 2 - rz.row_off : MPA_TB_BLOCK;
+		rz.ck = b ? wa.ckpt + t.bnd_off + (int64_t)(b - 1) * 9 * 64 : nullptr, rz.ck_lane0 = lane0, rz.half = half, rz.tb = tbs;
+		GlobWave gw;
+		gw.task[0] = tid, gw.task[1] = gw.task[2] = gw.task[3] = -1, gw.max_nl = rz.n_rows + 2;
+		wave_sync();
+		glob_narrow<G, false, false, false>(wa.ga, gw, WavePos{ lds, lane, 0, lane }, &rz);
+		wave_sync();
+		blk = b, blk_lo = 2 + rz.row_off, blk_hi = blk_lo + rz.n_rows;
+		if (lane == 0) atomicAdd(wa.n_blocks, 1ULL);
+	};
+	auto full = [&](const int32_t ii, const int32_t jj) -> int32_t { return tbs[(ii - blk_lo) * ncol + jj]; };
+	auto nibble = [&](const int32_t ii, const int32_t jj) -> int32_t {
+		const uint32_t r = (uint32_t)(ii - 2);
+		return (int32_t)(lite[(int64_t)(r / 3) * 64 + jj] >> (16 * half + 4 * (2 - r % 3))) & 0xf;
+	};
+	int32_t i = t.nl - 1, j = t.al - 1, carry = 0, n = 0;
+	int32_t cur_op = -1, cur_len = 0;                              // (ns_push_cigar merges equal neighbours except F/G, nasw.h:141-152)
+	auto push = [&](int32_t op, int32_t len) {
+		if (cur_op == op && op != 10 && op != 11) { cur_len += len; return; }
+		if (cur_op >= 0) { if (lane == 0 && n < cap) cig[n] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n; }
+		cur_op = op, cur_len = len;
+	};
+	auto state_of = [](int32_t w) { return (w >> 9 & 1) ? 1 : (w & 0xf); };
+	while (i >= 2 && j >= 0) {
+		int32_t st = carry;
+		if (st == 0) { ensure(i); st = state_of(full(i, j)); }          // fresh cell: its own state decides the direction
+		if (st == 0) {                                               // run of matches on the diagonal (i-3l, j-l), inside the block
+			const int32_t ii = i - 3 * lane, jj = j - lane;
+			const bool ok = ii >= blk_lo && jj >= 0;
+			const int32_t w = ok ? full(ii, jj) : 0xf;
+			const uint64_t stop = __ballot(!ok || state_of(w) != 0);
+			const int32_t run = stop ? __ffsll((unsigned long long)stop) - 1 : 64;
+			push(0, run), i -= 3 * run, j -= run, carry = 0;
+		} else if (st <= 5) {                                        // extension runs: I along the row (words), D/N/U/V along the column (bits)
+			const int32_t di = st == 1 ? 0 : st == 2 ? 3 : 1, dj = st == 1 ? 1 : 0;
+			if (st == 1) ensure(i);
+			const int32_t ii = i - di * lane, jj = j - dj * lane;
+			const bool ok = ii >= 2 && jj >= 0;
+			bool ext = false;
+			if (ok) ext = st == 1 ? (full(ii, jj) >> 4 & 1) != 0 : (nibble(ii, jj) >> (st - 2) & 1) != 0;
+			const uint64_t inval = __ballot(!ok), noext = __ballot(!ext);
+			const int32_t first_noext = noext ? __ffsll((unsigned long long)noext) - 1 : 64;
+			const int32_t first_inval = inval ? __ffsll((unsigned long long)inval) - 1 : 64;
+			int32_t run;
+			bool closed;
+			if (first_noext < first_inval) run = first_noext + 1, closed = true;
+			else run = first_inval, closed = false;
+			static const int32_t op_of[6] = { 0, 1, 2, 3, 12, 13 };
+			push(op_of[st], run);
+			i -= di * run, j -= dj * run;
+			if (closed && (st == 4 || st == 5)) --j;
+			carry = closed ? 0 : st;
+			if (run == 0) break;
+		} else {                                                     // frameshifts: one cell
+			if (st == 6) push(10, 1), i -= 1;
+			else if (st == 7) push(10, 2), i -= 2;
+			else if (st == 8) push(11, 1), i -= 1, j -= 1;
+			else push(11, 2), i -= 2, j -= 1;
+			carry = 0;
+		}
+	}
+	if (j > 0) push(1, j);
+	if (i >= 0) {
+		const int32_t l = (i + 1) / 3 * 3, r = (i + 1) % 3;
+		if (l > 0) push(2, l);
+		if (r != 0) push(10, r);
+	}
+	push(-2, 0);                                                 // flush
+	if (n > cap) n = cap;
+	__syncthreads();
+	for (int32_t x = lane; x < n >> 1; x += 64) { uint32_t tmp = cig[x]; cig[x] = cig[n - 1 - x], cig[n - 1 - x] = tmp; }
+	__syncthreads();
+	for (int32_t x = lane; x < n; x += 64) {                      // ns_fix_tiny_UV
+		const uint32_t op = cig[x] & 0xf;
+		if ((op == 12 || op == 13) && cig[x] >> 4 < 3) cig[x] = cig[x] >> 4 << 4 | 11;
+	}
+	if (lane == 0) wa.n_cigar[tid] = n;
+}
+__global__ __launch_bounds__(64) void k_walk(WalkArgs wa)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+	if ((int32_t)blockIdx.x >= wa.n_list) return;
+	const int32_t tid = wa.list[blockIdx.x];
+	const DTask t = wa.ga.tasks[tid];
+	const int lane = (int)threadIdx.x;
+	switch (t.pad_) {                                            // (class of the call's packed sweep: 8 + {16, 32, 64 lanes per call})
+	case 8: walk_call<16>(wa, t, tid, (char*)lds_raw, lane); break;
+	case 9: walk_call<32>(wa, t, tid, (char*)lds_raw, lane); break;
+	default: walk_call<64>(wa, t, tid, (char*)lds_raw, lane); break;
+	}
 }
 
 // dense copy of the CIGARs: every call's slot was sized for the worst case, only n_cigar words are real

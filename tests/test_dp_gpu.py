@@ -230,3 +230,32 @@ def test_antidiagonal_prototype_equals_the_oracle(oracle_built):
     assert c2.dp_stats()["launches_ext"] >= 1
     assert n > 400
     c2.close()
+
+
+def test_checkpointed_traceback(oracle_built, monkeypatch):
+    """Traceback calls of up to 64 columns and many rows take the checkpointed path (dp_device.h): the packed sweep keeps four
+    extension bits per cell and a checkpoint per 96 rows, k_walk follows deletion / intron runs on the bits and recomputes the
+    traceback words of a block only where the path needs them.  CIGARs and scores against the oracle for every lane class (16 /
+    32 / 64 lanes per call, full and partly filled waves), paths that change state right at block boundaries (several block
+    phases through the flank), introns of all phases, frameshifts, indels, N runs; and with the row threshold lowered so that
+    calls of a single block and of two blocks go the same way."""
+    P = refbind.DpParams(refbind.mapping_matrix(23))
+    for lite_min, seed in (("384", 31), ("3", 32), ("100", 33)):
+        monkeypatch.setenv("MPA_DP_LITE_MIN", lite_min)
+        rng = np.random.default_rng(seed)
+        pairs = []
+        for al in (1, 5, 8, 9, 16, 17, 23, 24, 25, 31, 32, 33, 40, 47, 48, 49, 56, 57, 63, 64):
+            for flank in (3, 90, 200, 700):
+                pairs.append(make_task(rng, al=al, max_intron=int(rng.choice([300, 1500, 5000])), flank=flank, p_intron=0.15))
+        pairs += [make_task(rng, max_intron=2500, flank=400, p_fs=0.05, p_indel=0.06, p_n=0.01) for _ in range(150)]
+        pairs += [make_task(rng, al=int(rng.integers(1, 65)), max_intron=20000, flank=50, p_intron=0.1) for _ in range(12)]
+        c2 = mpa.Context(0)
+        run_case(c2, pairs, P, rng, modes=("cigar",))
+        c2.close()
+    # other scoring: the bits follow the penalties (gap extension 2, intron open 40, mammalian splice model)
+    monkeypatch.setenv("MPA_DP_LITE_MIN", "200")
+    rng = np.random.default_rng(34)
+    P2 = refbind.DpParams(refbind.mapping_matrix(17), go=5, ge=2, io=40, fs=17, xdrop=50, end_bonus=0, sp=(8, 15, 21, 30, 4, 4), ie_coef=1.0)
+    c2 = mpa.Context(0)
+    run_case(c2, [make_task(rng, max_intron=3000, flank=300) for _ in range(200)], P2, rng)
+    c2.close()
