@@ -369,6 +369,26 @@ def main():
                     "one-GPU box; the line is NOT a scaling measurement")
     a = ap.parse_args()
 
+    # --gpus N is a promise about the line's n_gpus.  Started plainly (no RANK in the environment) with N > 1 the script launches
+    # its own N ranks -- one process per GPU, torch.distributed.run on this node -- and started under a launcher it insists that the
+    # launcher's world is the N that was asked for; either way fewer than N visible devices is an error, not a smaller run.
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus and not a.debug_shared_gpu:
+            raise SystemExit("bench.py: --gpus %d asked for, %d GPU(s) visible" % (a.gpus, have))
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s rank(s)" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -384,6 +404,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DP kernels have no CPU fallback")
+    if not a.debug_shared_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d rank(s), %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cpu") if a.debug_shared_gpu else torch.device("cuda", local_rank)
 

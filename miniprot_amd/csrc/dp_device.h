@@ -94,7 +94,8 @@ enum DpUnitKind : int32_t {
 	U_GLOB16, U_GLOB32, U_GLOB64,       // up to four independent traceback waves
 	U_GLOB_MB,                          // ... block-major ones (more than 1024 columns)
 	U_GLOB_W2, U_GLOB_W4,               // two two-wave / one four-wave traceback group(s)
-	U_LITE16, U_LITE32, U_LITE64        // up to four independent waves of the checkpointed traceback's packed sweep (ExtWave descriptors)
+	U_LITE16, U_LITE32, U_LITE64,       // up to four independent waves of the checkpointed traceback's packed sweep (ExtWave descriptors)
+	U_LITE128                           // ... one call of 65..128 columns per wave (column c + 64 in the high half of lane c)
 };
 struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; };
 

@@ -1504,7 +1504,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			// 32, 64 lanes per call, two calls per lane) and walked by k_walk.  Short calls stay on the plain traceback sweep: the walk
 			// would recompute all of their rows anyway.  MPA_DP_LITE_MIN (rows; 0: never).
 			static const int lite_min = [] { const char *e = getenv("MPA_DP_LITE_MIN"); return e ? atoi(e) : 384; }();
-			if (lite_min > 0 && !wide_ge && t.ncol <= 64 && x.nl >= lite_min && x.nl >= 3) t.pad_ += 8, t.pw = 16 << (t.pad_ - 8);
+			if (lite_min > 0 && !wide_ge && t.ncol <= 128 && x.nl >= lite_min && x.nl >= 3) t.pad_ += 8, t.pw = 16 << (t.pad_ - 8);   // (class 11: 65..128 columns, one call per wave)
 			glob_ids.push_back((int32_t)k);
 		}
 	}
@@ -1566,12 +1566,12 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	// ---- waves of the checkpointed traceback's packed sweep (classes 8, 9, 10 sort behind every other traceback call)
 	size_t n_reg_glob = 0;
 	while (n_reg_glob < glob_ids.size() && T[glob_ids[n_reg_glob]].pad_ < 8) ++n_reg_glob;
-	int lwave_first[3] = { 0, 0, 0 }, lwave_cnt[3] = { 0, 0, 0 };
+	int lwave_first[4] = { 0, 0, 0, 0 }, lwave_cnt[4] = { 0, 0, 0, 0 };
 	int64_t lite_total = 0, ck_total = 0;
 	{
 		size_t p = n_reg_glob;
-		for (int cls = 0; cls < 3; ++cls) {
-			const int slots = 2 * (64 / (16 << cls));
+		for (int cls = 0; cls < 4; ++cls) {
+			const int slots = cls == 3 ? 1 : 2 * (64 / (16 << cls));
 			lwave_first[cls] = (int)ewaves.size();
 			while (p < glob_ids.size() && T[glob_ids[p]].pad_ == 8 + cls) {
 				ExtWave w;
@@ -1763,7 +1763,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		const int per_narrow = use_pool ? 1 : 4;
 		for (int cls = 0; cls < 3; ++cls)
 			for (int k = 0; k < ewave_cnt[cls] && !(cls == 1 && ctx->antidiag); k += per_narrow)
-				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(per_narrow, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 270);
+				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(per_narrow, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 160);
 		// (worker pool: a workgroup goes on to its next unit, so all four waves must leave a unit through the same barriers -- a
 		// 65..128-column group then takes a whole workgroup on the four-wave body, its waves 2 and 3 on dead columns)
 		if (use_pool) for (int k = 0; k < ewave_cnt[3]; ++k) add(U_EXT_W4, ewave_first[3] + k, 1, (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
@@ -1773,9 +1773,9 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
 		for (int k = 0; k < ewave_cnt[5]; ++k)
 			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 425, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
-		for (int cls = 0; cls < 3; ++cls)                            // the packed sweeps of the checkpointed traceback
+		for (int cls = 0; cls < 4; ++cls)                            // the packed sweeps of the checkpointed traceback
 			for (int k = 0; k < lwave_cnt[cls]; k += per_narrow)
-				add(U_LITE16 + cls, lwave_first[cls] + k, std::min(per_narrow, lwave_cnt[cls] - k), (int64_t)ewaves[lwave_first[cls] + k].max_nl * 170);
+				add(U_LITE16 + cls, lwave_first[cls] + k, std::min(per_narrow, lwave_cnt[cls] - k), (int64_t)ewaves[lwave_first[cls] + k].max_nl * (cls == 3 ? 200 : 170));
 		if (gw_first) {
 			static const int kind_of[8] = { U_GLOB16, U_GLOB32, U_GLOB64, U_GLOB_W2, U_GLOB_W4, -1, -1, U_GLOB_MB };
 			for (int cls = 0; cls < 8; ++cls) {
@@ -1791,6 +1791,16 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		}
 		if (cu.empty()) return MPA_OK;
 		std::stable_sort(cu.begin(), cu.end(), [](const Cost &x, const Cost &y) { return x.cost > y.cost; });   // (stable: the workgroups of a split group stay adjacent, in column order)
+		static const bool show_top = [] { const char *e = getenv("MPA_DP_TOP"); return e && atoi(e) != 0; }();
+		if (show_top) {                                       // (measurement) what bounds the round: the costliest units by kind
+			int64_t by_kind[16] = { 0 }, n_kind[16] = { 0 };
+			for (const Cost &c : cu) by_kind[c.u.kind & 15] += c.cost, ++n_kind[c.u.kind & 15];
+			fprintf(stderr, "[mpa-dp-top] units %zu; longest:", cu.size());
+			for (size_t k = 0; k < cu.size() && k < 6; ++k) fprintf(stderr, " kind %d %.1f ms;", cu[k].u.kind, cu[k].cost * 1e-6);
+			fprintf(stderr, " | wave-ms by kind:");
+			for (int k = 0; k < 16; ++k) if (n_kind[k]) fprintf(stderr, " %d: %ld units %.0f ms;", k, (long)n_kind[k], by_kind[k] * 1e-6);
+			fprintf(stderr, "\n");
+		}
 		// worker pool: the units that take a whole workgroup first (queue 0), then the one-wave units (queue 1), each longest first;
 		// priorities stay relative to the round's longest unit of either kind
 		const int64_t cost_max = cu[0].cost;

@@ -624,6 +624,40 @@ __device__ __forceinline__ uint32_t prof2s(const uint32_t lo, const uint32_t hi)
 		"s_nop 1\n\t" \
 		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
 		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t"
+// DUAL (one call of 65..128 columns in a wave: column c in the low half of lane c, column c + 64 in the high half of the same lane):
+// the gap scan's total over the low halves (lane 63) is the carry into every high half, and H of column 63 is the left neighbour
+// of column 64 (lane 0, high half); one v_readlane each (one wait state behind the VALU write of what it reads: gfx940 family),
+// the two scalar instructions that move the value into the high half sit in the DPP move's wait states.
+#define MPA_EX64_LD \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"s_nop 0\n\t" \
+		"v_readlane_b32 %[st], %[x], 63\n\t" \
+		"s_lshl_b32 %[st], %[st], 16\n\t" \
+		"s_or_b32 %[st], %[st], 0x8000\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[t2], %[ke], %[st]\n\t" \
+		"v_pk_sub_i16 %[t2], %[t2], %[gojge] clamp\n\t"
+#define MPA_FIN_HS64_LD \
+		"v_pk_max_i16 %[h], %[h], %[t2]\n\t" \
+		"s_nop 0\n\t" \
+		"v_readlane_b32 %[st], %[h], 63\n\t" \
+		"s_lshl_b32 %[st], %[st], 16\n\t" \
+		"s_or_b32 %[st], %[st], 0x8000\n\t" \
+		"v_mov_b32_dpp %[hs3], %[h] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_writelane_b32 %[hs3], %[st], 0\n\t"
+#define MPA_ROW_TAIL_LD(Hr2, Hs2, Dr2, Hs3, M3) \
+	asm volatile(MPA_SCAN4_L MPA_EX64_LD MPA_FIN_HS64_LD "v_pk_max_i16 %[m3], %[h], %[hs3]" \
+		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [hs3] "+v"(Hs3), \
+		  [t2] "=&v"(tA_), [hDn] "=&v"(hDn), [a0] "=&v"(a0), [a1] "=&v"(a1), [m3] "=&v"(M3), [drn] "=&v"(drn), [dDn] "=&v"(dDn), [st] "=&s"(stmp) \
+		: [hr2] "v"(Hr2), [dr2] "v"(Dr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
+		  [gojge] "v"(gojge), [go] "s"(goP), [sel] "s"(sel_lo) \
+		: "scc")
 #define MPA_ROW_TAIL_L(EX, HS, Hr2, Hs2, Dr2, Hs3, M3) \
 	asm volatile(MPA_SCAN4_L EX "v_pk_max_i16 %[h], %[h], %[t2]\n\ts_nop 1\n\t" HS "v_pk_max_i16 %[m3], %[h], %[hs3]" \
 		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [kc] "+v"(kc), [hs3] "+v"(Hs3), \
@@ -654,9 +688,11 @@ struct ExtCall { int32_t Gs, maxi, maxsc, pk, pen, wit, nl, al; };     // wit: w
 
 // LITE: the packed sweep of the checkpointed traceback (dp_device.h): a global alignment (no best row, no x-drop: every row of
 // every call is swept), extension bits and checkpoints out, H(nl-1, al-1) as the score.
-template<int G, bool LITE = false>
+// DUAL (with LITE, G = 64): ONE call of 65..128 columns per wave, column c + 64 in the high half of lane c (slot 0 of the wave).
+template<int G, bool LITE = false, bool DUAL = false>
 __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp, const WavePos wp)
 {
+	static_assert(!DUAL || (LITE && G == 64), "DUAL is the 128-column class of the checkpointed traceback");
 	constexpr int NG = 64 / G;               // lane groups per wave
 	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
 	char *lds_prof = wp.lds;                                           // [NSLOT][G columns][23] int16
@@ -674,7 +710,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		int32_t io[2];
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
-			const int32_t tid = wvp->task[h * NG + grp];
+			const int32_t tid = wvp->task[DUAL ? 0 : h * NG + grp];
 			ExtCall e;
 			e.Gs = NEG16, e.maxi = -1, e.maxsc = INT32_MIN, e.pk = 0, e.pen = 0;
 			if (tid >= 0) {
@@ -682,13 +718,15 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 				e.nl = t->nl, e.al = t->al, e.wit = -1, io[h] = t->io;
 				roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
 			} else e.nl = 0, e.al = 1, e.wit = EXT_DONE, io[h] = 0, roff[h] = 0;
+			if (DUAL && h == 1) e.nl = 0, e.al = 1, e.wit = EXT_DONE;        // (the high halves belong to the call of slot 0)
 			if (col == 0) lds_call[h * NG + grp] = e;
 		}
 		ioP = pack16(io[0], io[1]);
 	}
 	// ---- stage the profiles: global [22][pw] int16 -> LDS [col][aa]
 	for (int s = 0; s < NSLOT; ++s) {
-		const int t = wvp->task[s];
+		const int t = wvp->task[DUAL ? 0 : s];
+		const int c0 = DUAL ? s * G : 0;                                   // first profile column of the slot
 		if (t < 0) {   // an empty slot scores zero everywhere (its half never reaches a result)
 			for (int k = lane; k < G * PROF_COL_STRIDE / 2; k += 64) ((uint16_t*)(lds_prof + s * G * PROF_COL_STRIDE))[k] = 0;
 			continue;
@@ -697,7 +735,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		const int16_t *src = a.prof + tt->prof_off;
 		for (int k = lane; k < 22 * G; k += 64) {
 			const int aa = k / G, cc = k - aa * G;
-			*(int16_t*)(lds_prof + (s * G + cc) * PROF_COL_STRIDE + aa * PROF_AA_STRIDE) = src[aa * tt->pw + cc];
+			*(int16_t*)(lds_prof + (s * G + cc) * PROF_COL_STRIDE + aa * PROF_AA_STRIDE) = src[aa * tt->pw + c0 + cc];
 		}
 	}
 	for (int k = lane; k < MPA_PEN_MAX; k += 64) lds_pen[k] = a.pen.x[k], lds_pen[MPA_PEN_MAX + k] = a.pen.val[k];
@@ -712,7 +750,9 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 	wave_sync();
 
 	// ---- per-lane constants
-	const uint32_t jge = splat16(col * c.ge), gojge = splat16(c.go + col * c.ge);
+	const uint32_t jge = DUAL ? pack16(col * c.ge, (col + 64) * c.ge) : splat16(col * c.ge);
+	const uint32_t gojge = DUAL ? pack16(c.go + col * c.ge, c.go + (col + 64) * c.ge) : splat16(c.go + col * c.ge);
+	uint32_t stmp;                                                         // (DUAL: scalar scratch of the asm rows)
 	const uint32_t goP = __builtin_amdgcn_readfirstlane(splat16(c.go)), fsP = __builtin_amdgcn_readfirstlane(splat16(c.fs));
 	const uint32_t pbase0 = (uint32_t)(((0 * NG + grp) * G + col) * PROF_COL_STRIDE);
 	const uint32_t pbase1 = (uint32_t)(((1 * NG + grp) * G + col) * PROF_COL_STRIDE);
@@ -732,7 +772,10 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = M[k] = NEGP;
 	uint32_t k0 = NEGP, k1 = NEGP, k2 = NEGP, k3 = NEGP, ke = NEGP, kc = NEGP;   // fill registers of the asm rows' scan: only ever written by DPP moves
 	// virtual column -1 as row 2 sees it (nasw-sse.c:256-258): H(-1,-1)=0, H(0,-1)=H(1,-1)=-fs
-	if (col == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
+	if (col == 0) {
+		if (DUAL) Hs[2] = pack16(0, NEG16), Hs[1] = Hs[0] = pack16(-c.fs, NEG16);   // (lane 0's high half is column 64)
+		else Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
+	}
 	// record r carries donor[r+1] and acceptor[r]
 	{
 		const uint4 q0 = ring[20], q1 = ring[21];
@@ -807,7 +850,8 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 			if (e[h].wit != EXT_DONE && i >= e[h].nl) {
 				e[h].wit = EXT_DONE;
 				// LITE: row nl - 1 was the call's last: its score is H(nl-1, al-1) (nasw-sse.c:543); a call of fewer than three rows has none
-				if (LITE && col_ == e[h].al - 1) a.score[wvp->task[h * NG + grp_]] = e[h].nl < 3 ? NEG16 : half16(h_prev, h);
+				if (LITE && !DUAL && col_ == e[h].al - 1) a.score[wvp->task[h * NG + grp_]] = e[h].nl < 3 ? NEG16 : half16(h_prev, h);
+				if (DUAL && col_ == (e[h].al - 1) % 64) a.score[wvp->task[0]] = e[h].nl < 3 ? NEG16 : half16(h_prev, (e[h].al - 1) / 64);
 			}
 			if (e[h].wit != EXT_DONE) {
 				int64_t nxt = e[h].nl;
@@ -922,9 +966,11 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		h = p_max(h, p_subs(t, fsP));
 		// horizontal gap chain as a prefix max of h + j*ge
 		const uint32_t y = scan_max_pk<G>(p_adds(h, jge));
-		const uint32_t ex = shift1<G>(y, NEGP, lane_);
+		uint32_t ex = shift1<G>(y, NEGP, lane_);
+		if (DUAL) ex = p_max(ex, (uint32_t)__builtin_amdgcn_readlane((int)y, 63) << 16 | 0x8000u);   // the low halves' total into every high half
 		h = p_max(h, p_subs(ex, gojge));
 		Hr[R3] = h, Hs[R3] = shift1<G>(h, NEGP, lane_);
+		if (DUAL) { const uint32_t h63 = (uint32_t)__builtin_amdgcn_readlane((int)h, 63); if (lane_ == 0) Hs[R3] = (Hs[R3] & 0xffffu) | h63 << 16; }
 		if (!LITE) { if (__ballot(p_max(p_min(h, GvL), TvL) != h) != 0) book(h, i); }
 		if (i == 2 && col_ == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;              // column -1 is -inf from row 3 on
 		S = Snext;
@@ -966,6 +1012,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 					dn[R3] = rcur.x, ac[R3] = rcur.y; \
 					if constexpr (G == 16) MPA_ROW_TAIL_L(MPA_EX16_L, MPA_HS16, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 					else if constexpr (G == 32) MPA_ROW_TAIL_L(MPA_EX32_L, MPA_HS32, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else if constexpr (DUAL) MPA_ROW_TAIL_LD(Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 					else MPA_ROW_TAIL_L(MPA_EX64_L, MPA_HS64, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 					if constexpr (K == 0) MPA_NIBBLE(MPA_NIB_FIRST); else MPA_NIBBLE(MPA_NIB_NEXT); \
 					Dold = Dr[R2], Dr[R2] = drn, dDc = dDn; \
@@ -1471,8 +1518,9 @@ __device__ __forceinline__ int32_t glob_cands(GlobState &s, const uint32_t rcur,
 struct GlobResume {
 	int32_t row_off, n_rows;
 	const uint32_t *ck;
-	int32_t ck_lane0, half;
+	int32_t ck_lane0, half;      // (block-major sweep of a 65..128-column call: lanes from 0, the column block is the half)
 	uint16_t *tb;
+	int4 *bnd;                   // block-major sweep: the boundary records of the block's rows, [n_rows + 2]
 };
 template<int G, bool MB, bool EXT = false, bool WIDE = false>
 __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &wv, const WavePos wp, const GlobResume *rz = nullptr)
@@ -1491,7 +1539,7 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 	const uint32_t *rec = a.rec + t.rec_off + (rz ? rz->row_off : 0);
 	uint16_t *tb = rz ? rz->tb - 2 * ncol : a.tb + (EXT ? 0 : t.tb_off);          // (rz: row 2 of the sweep is the block's first row)
 	unsigned long long *rowkey = EXT ? a.rowkey64 + t.tb_off : nullptr;
-	int4 *bnd = a.bnd + t.bnd_off;
+	int4 *bnd = rz ? rz->bnd : a.bnd + t.bnd_off;
 
 	for (int32_t blk = 0; blk < nblk; ++blk) {
 		const int32_t gc = blk * G + col;                 // global column of this lane
@@ -1528,14 +1576,15 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 		if (rz && rz->ck) {
 			// the packed sweep's registers at the top of this row: H and D of rows i-1, i-2, i-3 (this sweep's slots 1, 0, 2), A, B, C;
 			// H shifted by one column follows (column -1 is -inf behind row 2)
-			const uint32_t *p = rz->ck + rz->ck_lane0 + (col < ncol ? col : 0);
-			const int sh = rz->half * 16;
+			const uint32_t *p = rz->ck + rz->ck_lane0 + (gc < ncol ? col : 0);
+			const int sh = (MB ? blk : rz->half) * 16;
 			auto half_splat = [&](const uint32_t x) { return spl((int32_t)(x >> sh)); };
 			gs.H[1] = half_splat(p[0]), gs.H[0] = half_splat(p[64]), gs.H[2] = half_splat(p[128]);
 			gs.D[1] = half_splat(p[192]), gs.D[0] = half_splat(p[256]), gs.D[2] = half_splat(p[320]);
 			gs.A = half_splat(p[384]), gs.B = half_splat(p[448]), gs.C = half_splat(p[512]);
 			if (!live) { for (int k = 0; k < 3; ++k) gs.H[k] = gs.D[k] = NEGP; gs.A = gs.B = gs.C = NEGP; }
-			for (int k = 0; k < 3; ++k) gs.Hs[k] = shift1<G>(gs.H[k], NEGP, lane);
+			// (block-major: the left neighbour of a later block's first column is the last column of the block before, lane 63's lower half)
+			for (int k = 0; k < 3; ++k) gs.Hs[k] = shift1<G>(gs.H[k], MB && blk > 0 ? spl((int32_t)(rz->ck[(k == 0 ? 64 : k == 1 ? 0 : 128) + 63] >> ((blk - 1) * 16))) : NEGP, lane);
 		}
 		const uint32_t go_s = splat16(go), io_s = splat16(io), fs_s = splat16(fs), ge_s = splat16(ge);
 		const char *profb = (const char*)myprof;                // + byte0(record) * G = this lane's score for the row's amino acid
@@ -1859,6 +1908,7 @@ __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, 
 	case U_LITE16: if (!WG_ONLY && wv < u.count) ext_narrow<16, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_LITE32: if (!WG_ONLY && wv < u.count) ext_narrow<32, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_LITE64: if (!WG_ONLY && wv < u.count) ext_narrow<64, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_LITE128: if (!WG_ONLY && wv < u.count) ext_narrow<64, true, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	default: break;
 	}
 }
@@ -2078,6 +2128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		case U_LITE16: ext_narrow<16, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		case U_LITE32: ext_narrow<32, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		case U_LITE64: ext_narrow<64, true>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_LITE128: ext_narrow<64, true, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		default: break;
 		}
 		__builtin_amdgcn_s_setprio(0);
@@ -2193,14 +2244,17 @@ struct WalkArgs {
 	int32_t *n_cigar;
 	unsigned long long *n_blocks; // (statistics) blocks recomputed
 };
-#define WALK_LDS (GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 64 * 2)
-template<int G>
+#define WALK_LDS (GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 128 * 2 + (size_t)(MPA_TB_BLOCK + 2) * 16)
+// DUAL: a call of 65..128 columns, swept with column c + 64 in the high half of lane c (ext_narrow<64, true, true>) and recomputed
+// by the block-major traceback sweep (two blocks of 64 columns, boundary records in LDS)
+template<int G, bool DUAL = false>
 __device__ __forceinline__ void walk_call(const WalkArgs &wa, const DTask &t, const int32_t tid, char *lds, const int lane)
 {
 	constexpr int NG = 64 / G;
-	const int slot = (t.flag >> MPA_LITE_SLOT_SHIFT) & 15, half = slot / NG, lane0 = (slot % NG) * G;
+	const int slot = DUAL ? 0 : (t.flag >> MPA_LITE_SLOT_SHIFT) & 15, half = slot / NG, lane0 = (slot % NG) * G;
 	const uint32_t *lite = wa.lite + t.tb_off + lane0;
 	uint16_t *tbs = (uint16_t*)(lds + GLOB_NARROW_LDS);            // [MPA_TB_BLOCK][ncol] words of the block that is materialised
+	int4 *bnds = (int4*)(lds + GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 128 * 2);
 	uint32_t *cig = wa.cig + t.cig_off;
 	const int32_t ncol = t.ncol, cap = t.cig_cap;
 	int32_t blk = -1, blk_lo = 0, blk_hi = 0;                      // the materialised block and its rows [blk_lo, blk_hi)
@@ -2209,11 +2263,11 @@ __device__ __forceinline__ void walk_call(const WalkArgs &wa, const DTask &t, co
 		const int32_t b = (row - 2) / MPA_TB_BLOCK;
 		GlobResume rz;
 		rz.row_off = b * MPA_TB_BLOCK, rz.n_rows = t.nl - 2 - rz.row_off < MPA_TB_BLOCK ? t.nl - 2 - rz.row_off : MPA_TB_BLOCK;
-		rz.ck = b ? wa.ckpt + t.bnd_off + (int64_t)(b - 1) * 9 * 64 : nullptr, rz.ck_lane0 = lane0, rz.half = half, rz.tb = tbs;
+		rz.ck = b ? wa.ckpt + t.bnd_off + (int64_t)(b - 1) * 9 * 64 : nullptr, rz.ck_lane0 = lane0, rz.half = half, rz.tb = tbs, rz.bnd = bnds;
 		GlobWave gw;
 		gw.task[0] = tid, gw.task[1] = gw.task[2] = gw.task[3] = -1, gw.max_nl = rz.n_rows + 2;
 		wave_sync();
-		glob_narrow<G, false, false, false>(wa.ga, gw, WavePos{ lds, lane, 0, lane }, &rz);
+		glob_narrow<G, DUAL, false, false>(wa.ga, gw, WavePos{ lds, lane, 0, lane }, &rz);
 		wave_sync();
 		blk = b, blk_lo = 2 + rz.row_off, blk_hi = blk_lo + rz.n_rows;
 		if (lane == 0) atomicAdd(wa.n_blocks, 1ULL);
@@ -2221,7 +2275,7 @@ __device__ __forceinline__ void walk_call(const WalkArgs &wa, const DTask &t, co
 	auto full = [&](const int32_t ii, const int32_t jj) -> int32_t { return tbs[(ii - blk_lo) * ncol + jj]; };
 	auto nibble = [&](const int32_t ii, const int32_t jj) -> int32_t {
 		const uint32_t r = (uint32_t)(ii - 2);
-		return (int32_t)(lite[(int64_t)(r / 3) * 64 + jj] >> (16 * half + 4 * (2 - r % 3))) & 0xf;
+		return (int32_t)(lite[(int64_t)(r / 3) * 64 + (DUAL ? jj & 63 : jj)] >> (16 * (DUAL ? jj >> 6 : half) + 4 * (2 - r % 3))) & 0xf;
 	};
 	int32_t i = t.nl - 1, j = t.al - 1, carry = 0, n = 0;
 	int32_t cur_op = -1, cur_len = 0;                              // (ns_push_cigar merges equal neighbours except F/G, nasw.h:141-152)
@@ -2296,7 +2350,8 @@ __global__ __launch_bounds__(64) void k_walk(WalkArgs wa)
 	switch (t.pad_) {                                            // (class of the call's packed sweep: 8 + {16, 32, 64 lanes per call})
 	case 8: walk_call<16>(wa, t, tid, (char*)lds_raw, lane); break;
 	case 9: walk_call<32>(wa, t, tid, (char*)lds_raw, lane); break;
-	default: walk_call<64>(wa, t, tid, (char*)lds_raw, lane); break;
+	case 10: walk_call<64>(wa, t, tid, (char*)lds_raw, lane); break;
+	default: walk_call<64, true>(wa, t, tid, (char*)lds_raw, lane); break;   // 11: 65..128 columns
 	}
 }
 

@@ -233,10 +233,10 @@ def test_antidiagonal_prototype_equals_the_oracle(oracle_built):
 
 
 def test_checkpointed_traceback(oracle_built, monkeypatch):
-    """Traceback calls of up to 64 columns and many rows take the checkpointed path (dp_device.h): the packed sweep keeps four
+    """Traceback calls of up to 128 columns and many rows take the checkpointed path (dp_device.h): the packed sweep keeps four
     extension bits per cell and a checkpoint per 96 rows, k_walk follows deletion / intron runs on the bits and recomputes the
     traceback words of a block only where the path needs them.  CIGARs and scores against the oracle for every lane class (16 /
-    32 / 64 lanes per call, full and partly filled waves), paths that change state right at block boundaries (several block
+    32 / 64 lanes per call, full and partly filled waves; 65..128 columns: one call per wave, column c + 64 in the high half of lane c), paths that change state right at block boundaries (several block
     phases through the flank), introns of all phases, frameshifts, indels, N runs; and with the row threshold lowered so that
     calls of a single block and of two blocks go the same way."""
     P = refbind.DpParams(refbind.mapping_matrix(23))
@@ -244,11 +244,12 @@ def test_checkpointed_traceback(oracle_built, monkeypatch):
         monkeypatch.setenv("MPA_DP_LITE_MIN", lite_min)
         rng = np.random.default_rng(seed)
         pairs = []
-        for al in (1, 5, 8, 9, 16, 17, 23, 24, 25, 31, 32, 33, 40, 47, 48, 49, 56, 57, 63, 64):
+        for al in (1, 5, 8, 9, 16, 17, 23, 24, 25, 31, 32, 33, 40, 47, 48, 49, 56, 57, 63, 64, 65, 66, 72, 73, 90, 104, 120, 121, 127, 128):
             for flank in (3, 90, 200, 700):
                 pairs.append(make_task(rng, al=al, max_intron=int(rng.choice([300, 1500, 5000])), flank=flank, p_intron=0.15))
         pairs += [make_task(rng, max_intron=2500, flank=400, p_fs=0.05, p_indel=0.06, p_n=0.01) for _ in range(150)]
-        pairs += [make_task(rng, al=int(rng.integers(1, 65)), max_intron=20000, flank=50, p_intron=0.1) for _ in range(12)]
+        pairs += [make_task(rng, al=int(rng.integers(1, 129)), max_intron=20000, flank=50, p_intron=0.1) for _ in range(16)]
+        pairs += [make_task(rng, al=int(rng.integers(65, 129)), max_intron=2500, flank=400, p_fs=0.05, p_indel=0.06, p_n=0.01) for _ in range(60)]
         c2 = mpa.Context(0)
         run_case(c2, pairs, P, rng, modes=("cigar",))
         c2.close()
