@@ -1162,10 +1162,11 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	hipStream_t s = ctx->seed_stream;
 	const double t0 = now_ms();
 	// ---- one pinned block up: windows | chunks | wg_first | qg_first | gword | gfirst | gcount | qpos
+	static const int n_super = [] { const char *e = getenv("MPA_REFINE_SUPER"); const int v = e ? atoi(e) : REFINE_SUPER; return v < 1 ? 1 : v > 16 ? 16 : v; }();
 	int64_t n_pos = 0, n_chunk = 0, wg_total = 0;
 	for (int64_t k = 0; k < n_win; ++k) {
 		if (wins[k].len >= (1 << 22)) { set_error("device refinement: a window longer than 2^22 bases"); return MPA_ERR_UNSUPPORTED; }
-		n_pos += wins[k].len, n_chunk += (wins[k].len + REFINE_SUPER * REFINE_CHUNK - 1) / (REFINE_SUPER * REFINE_CHUNK);   // (a workgroup sweeps REFINE_SUPER chunks of its window)
+		n_pos += wins[k].len, n_chunk += (wins[k].len + n_super * REFINE_CHUNK - 1) / (n_super * REFINE_CHUNK);   // (a workgroup sweeps n_super chunks of its window)
 	}
 	if (n_chunk == 0) return MPA_OK;
 	const unsigned long long cap = (unsigned long long)(n_pos / 64 + (1 << 20));
@@ -1185,7 +1186,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 		int64_t c = 0;
 		for (int64_t k = 0; k < n_win; ++k) {
 			dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
-			for (int32_t st = 0; st < wins[k].len; st += REFINE_SUPER * REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
+			for (int32_t st = 0; st < wins[k].len; st += n_super * REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
 			wg[k] = wg_total;
 			wg_total += G.qg_first[(size_t)wins[k].qid + 1] - G.qg_first[(size_t)wins[k].qid];
 		}
@@ -1215,7 +1216,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	const size_t lds = ((size_t)8 << hs_log2) + 2 * (REFINE_CHUNK + 2 * REFINE_HALO);   // k-mer map, bases, codons
 	HIP_TRY(ensure_dynamic_lds((const void*)k_refine_scan_map, ctx->device, lds > 48 * 1024 ? lds : 48 * 1024));
 	hipLaunchKernelGGL(k_refine_scan_map, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk), gr, d_wg, rt,
-	                   kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt);
+	                   kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt, (int32_t)n_super);
 	HIP_TRY(hipGetLastError());
 	unsigned long long *h_n = B.h_back.as<unsigned long long>();
 	HIP_TRY(hipMemcpyAsync(h_n, B.r_count.p, 8, hipMemcpyDeviceToHost, s));

@@ -909,7 +909,8 @@ struct RefineChunk { int32_t win, start; };
 struct RefineTab { uint8_t t[64]; };                  // codon -> reduced residue (ns_tab_codon13), 0xff for a stop codon
 #define REFINE_CHUNK 2048
 #define REFINE_HALO 112
-#define REFINE_SUPER 1                                      /* chunks of one window a workgroup of k_refine_scan_map sweeps (8: measured 10.9 ms against 9.0 alone -- building the map is not what the scan waits for) */
+#define REFINE_LCAP 384                                     /* hits a workgroup of k_refine_scan_map collects in LDS per chunk before it asks for room in the global list */
+#define REFINE_SUPER 4                                      /* chunks of one window a workgroup of k_refine_scan_map sweeps (round 5, one atomic per hit: 8 chunks measured 10.9 ms against 9.0 alone; round 6, hits collected per workgroup: see profiles/r06_experiments.txt) */
 
 __device__ __forceinline__ uint32_t d_hash32_mask(uint32_t key, uint32_t mask)     // mp_hash32_mask (sketch.c:7-16)
 {
@@ -1009,7 +1010,8 @@ struct RefineGroups {
 };
 
 __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const RefineWindowDev *wins, const RefineChunk *chunks, RefineGroups gr, const int64_t *wg_first, RefineTab rt,
-                                                         int32_t kmer, int32_t min_aa_len, int32_t hs_log2, uint4 *hits, unsigned long long *n_hits, unsigned long long cap, uint32_t *wcnt)
+                                                         int32_t kmer, int32_t min_aa_len, int32_t hs_log2, uint4 *hits, unsigned long long *n_hits, unsigned long long cap, uint32_t *wcnt,
+                                                         const int32_t n_super)
 {
 	MPA_SHORT_KERNEL();
 	extern __shared__ uint32_t lds_refine[];
@@ -1018,6 +1020,14 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	uint8_t *base = (uint8_t*)(tval + HS);                          // [REFINE_CHUNK + 2 * REFINE_HALO] nt4 codes, 15 = outside the window
 	uint8_t *cod = base + REFINE_CHUNK + 2 * REFINE_HALO;           // [same] reduced-alphabet code of the codon ENDING at each position, 0xff = none
 	__shared__ uint8_t tab[64];
+	// The hits of a chunk are collected in LDS and get their places in the global list with ONE returning atomic per workgroup and
+	// chunk that has any (round 5: one per hit -- 3.5 M returning atomics on one address per launch, which IS the 8 ms the kernel
+	// took: profiles/r05_pmc_summary.json, 72 % of the wave cycles waiting).  A hit beyond REFINE_LCAP takes its place directly, as
+	// before.  The order of the list means nothing: its consumers index it (k_refine_pair_count / _emit) and sort what they emit.
+	__shared__ uint4 l_hit[REFINE_LCAP];
+	__shared__ uint32_t l_n;
+	__shared__ unsigned long long l_base;
+	if (threadIdx.x == 0) l_n = 0;
 	const RefineChunk ch = chunks[blockIdx.x];
 	const RefineWindowDev w = wins[ch.win];
 	const int cid = w.vid >> 1, rev = w.vid & 1;
@@ -1040,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 	const uint32_t mask = (1u << (4 * kmer)) - 1;
 	auto codon_at = [&](int e) -> uint32_t { return cod[e]; };
 	const int64_t wc0 = wg_first[ch.win];
-	for (int32_t cstart = ch.start; cstart < w.len && cstart < ch.start + REFINE_SUPER * REFINE_CHUNK; cstart += REFINE_CHUNK) {
+	for (int32_t cstart = ch.start; cstart < w.len && cstart < ch.start + n_super * REFINE_CHUNK; cstart += REFINE_CHUNK) {
 	if (cstart != ch.start) __syncthreads();                    // (the scan of the chunk before has finished with base[] and cod[])
 	// the chunk's bases and its halo, sixteen per thread from three aligned words of the packed genome (a byte load per base before)
 	static_assert((REFINE_CHUNK + 2 * REFINE_HALO) % 16 == 0, "chunk + halo must be a multiple of 16");
@@ -1099,9 +1109,25 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 		for (int q = e - 3 * kmer; n < min_aa_len && q >= 2 && codon_at(q) != 0xffu; q -= 3) ++n;
 		for (int q = e + 3; n < min_aa_len && q < REFINE_CHUNK + 2 * REFINE_HALO && codon_at(q) != 0xffu; q += 3) ++n;
 		if (n < min_aa_len) continue;
-		const unsigned long long at = atomicAdd(n_hits, 1ULL);
-		if (at < cap) hits[at] = make_uint4((uint32_t)ch.win, (uint32_t)pos, (uint32_t)(G0 + grp), grp);
+		const uint4 hit = make_uint4((uint32_t)ch.win, (uint32_t)pos, (uint32_t)(G0 + grp), grp);
+		const uint32_t li = atomicAdd(&l_n, 1u);
+		if (li < REFINE_LCAP) l_hit[li] = hit;
+		else {
+			const unsigned long long at = atomicAdd(n_hits, 1ULL);
+			if (at < cap) hits[at] = hit;
+		}
 		atomicAdd(&wcnt[wc0 + grp], 1u);
+	}
+	__syncthreads();
+	// (the buffer is emptied when a chunk leaves it more than half full, and behind the workgroup's last chunk)
+	const bool last_chunk = cstart + REFINE_CHUNK >= w.len || cstart + REFINE_CHUNK >= ch.start + n_super * REFINE_CHUNK;
+	const uint32_t ln = (l_n >= REFINE_LCAP / 2 || last_chunk) ? (l_n < REFINE_LCAP ? l_n : REFINE_LCAP) : 0u;
+	if (ln) {                                                   // (uniform: every thread sees the same count behind the barrier)
+		if (threadIdx.x == 0) l_base = atomicAdd(n_hits, (unsigned long long)ln);
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < ln; k += 256) { const unsigned long long at = l_base + k; if (at < cap) hits[at] = l_hit[k]; }
+		__syncthreads();
+		if (threadIdx.x == 0) l_n = 0;
 	}
 	}
 }
