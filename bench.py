@@ -337,7 +337,7 @@ def cli_end_to_end(wl, n_threads, cpu):
         return None
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "miniprot_amd") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
-    env.setdefault("MPA_DEVICES", "1")          # one GPU, like the line's own n_gpus (the file mapper's default is every GPU of the node)
+    env.setdefault("MPA_DEVICES", "0")          # one GPU, like the line's own n_gpus (the file mapper's own default is one device as well)
     cmd = [exe, "-t%d" % n_threads] + wl.cfg["flags"] + [wl.mpi, wl.faa]
     t = time.time()
     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)

@@ -172,15 +172,15 @@ typedef struct {
 	int64_t alg_bytes_ext, alg_bytes_glob; /* algorithmic HBM bytes, SURVEY.md 8(d) */
 	double ms_prep, ms_ext, ms_glob, ms_backtrack, ms_total; /* HIP-event timings on the context's stream */
 	int32_t launches_ext, launches_glob;
-	/* the DP round kernel: k_dp_worker launches of the device's worker pool (default; one launch of workers per DP round, the
-	 * workers of all lanes serve the units of all rounds in flight), or k_dp_round (MPA_DP_POOL=0: one launch per round).  A round
+	/* the DP round kernel: k_dp_round (the default: one launch per DP round), or with MPA_DP_POOL=1 the k_dp_worker launches of the
+	 * device's worker pool (one launch of workers per round; the workers of all lanes serve the units of all rounds in flight).  A round
 	 * = every extension call + the traceback calls of the first traceback chunk. */
 	int64_t cells_ext_round, cells_glob_round;   /* padded DP cells those launches swept */
 	double ms_round;                             /* sum of their HIP-event durations */
 	int32_t launches_round, pad_;
 	double ms_round_union;                       /* worker pool: time during which at least one worker launch of the DEVICE was running
 	                                              * (the union of the launches' intervals; the stream's rounds overlap) -- what one
-	                                              * persistent kernel's duration would be.  0 with MPA_DP_POOL=0. */
+	                                              * persistent kernel's duration would be.  0 unless MPA_DP_POOL=1. */
 	/* checkpointed traceback (traceback calls of <= 64 columns and >= MPA_DP_LITE_MIN rows): calls and padded cells swept by the
 	 * packed sweep, and the blocks of 96 rows whose traceback words the walk recomputed */
 	int64_t n_ckpt, cells_ckpt, walk_blocks;

@@ -91,8 +91,16 @@ inline CompatIndex *owner(const mp_idx_t *mi) { return reinterpret_cast<CompatIn
 // ---- device contexts ----------------------------------------------------------------------------------
 int default_device()
 {
-	const char *e = getenv("MPA_DEVICE");
-	return e ? atoi(e) : 0;
+	// MPA_DEVICE names the device; without it a process started by a one-process-per-GPU launcher (torchrun, mpirun, srun) takes
+	// the GPU of its local rank, so that N ranks do not all sit on device 0 -- or, worse, each on every GPU of the node
+	for (const char *name : { "MPA_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID" }) {
+		const char *e = getenv(name);
+		if (e && *e) {
+			const int d = atoi(e), n = mpa_device_count();
+			return n > 0 ? (d % n + n) % n : d;
+		}
+	}
+	return 0;
 }
 std::mutex g_mu;                     // guards the shared context and index uploads
 mpa_ctx_t *g_ctx = nullptr;
@@ -112,36 +120,49 @@ void at_exit(int status, void*)
 	g_file_ctx.clear(), g_ctx = nullptr;
 	fprintf(stderr, "[mpa-timing] at exit: device contexts destroyed in %.1f ms (then the HIP runtime's own teardown)\n", now_ms() - t0);
 }
+void hook_exit();
 mpa_ctx_t *shared_ctx()
 {
 	if (!g_ctx) {
 		g_ctx = mpa_ctx_create(default_device());
 		if (!g_ctx) die("no usable HIP device (there is no CPU fallback)");
-		static bool hooked = false;
-		if (!hooked) hooked = true, on_exit(at_exit, nullptr);
+		hook_exit();
 	}
 	return g_ctx;
 }
 
-// mp_map_file() maps on every visible GPU (the reference's kt_for over threads, map.c:291, becomes one pipeline per device):
-// MPA_DEVICES = "all" (default), a count ("4": devices 0..3) or a list ("0,2,5"; a device may be named twice: two pipelines on
-// it -- how the single-GPU tests exercise this path).  MPA_DEVICE alone (the device of mp_map / ns_global_gs16b) keeps the file
-// mapper on that one device.
+void hook_exit()
+{
+	static bool hooked = false;
+	if (!hooked) hooked = true, on_exit(at_exit, nullptr);
+}
+
+// mp_map_file() maps on ONE device unless told otherwise (the reference's kt_for over threads, map.c:291, becomes one pipeline per
+// device NAMED): MPA_DEVICES = "all" (every visible GPU), or a list ("0,2,5"; a single id is a list of one; a device may be named
+// twice: two pipelines on it -- how the single-GPU tests exercise this path).  Every id is checked against the visible devices; a
+// malformed value is an error, not a silent default.  Without MPA_DEVICES: the default device (MPA_DEVICE, or the launcher's local
+// rank) -- a process on a shared node, or one rank of a multi-rank launch, must not take every GPU just because it can see them.
+// (Round 5 mapped on all of them by default, before the multi-device path had run on more than one device.)
 const std::vector<mpa_ctx_t*> &file_ctxs()             // caller holds g_mu
 {
 	if (!g_file_ctx.empty()) return g_file_ctx;
 	std::vector<int> devs;
 	const int n_dev = mpa_device_count();
+	if (n_dev <= 0) die("mp_map_file: no usable HIP device (there is no CPU fallback)");
 	const char *e = getenv("MPA_DEVICES");
-	if (!e || !*e) {
-		if (getenv("MPA_DEVICE")) devs.push_back(default_device());
-		else for (int d = 0; d < n_dev; ++d) devs.push_back(d);
-	} else if (strcmp(e, "all") == 0) {
-		for (int d = 0; d < n_dev; ++d) devs.push_back(d);
-	} else if (strchr(e, ',')) {
-		for (const char *p = e; *p; ) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
-	} else {
-		for (int d = 0; d < atoi(e) && d < n_dev; ++d) devs.push_back(d);
+	if (!e || !*e) devs.push_back(default_device());
+	else if (strcmp(e, "all") == 0) { for (int d = 0; d < n_dev; ++d) devs.push_back(d); }
+	else {
+		for (const char *p = e; *p; ) {
+			char *end = nullptr;
+			const long d = strtol(p, &end, 10);
+			if (end == p || (*end && *end != ',') || d < 0 || d >= n_dev) {
+				fprintf(stderr, "[mpamd] MPA_DEVICES=\"%s\": expected \"all\" or a comma-separated list of device ids below %d\n", e, n_dev);
+				exit(1);
+			}
+			devs.push_back((int)d);
+			p = *end ? end + 1 : end;
+		}
 	}
 	if (devs.size() > 8) devs.resize(8);
 	bool shared_used = false;
@@ -153,6 +174,7 @@ const std::vector<mpa_ctx_t*> &file_ctxs()             // caller holds g_mu
 		g_file_ctx.push_back(c);
 	}
 	if (g_file_ctx.empty()) g_file_ctx.push_back(shared_ctx());
+	hook_exit();                                         // (also when none of the devices is the default one: MPA_FAST_EXIT / MPA_TIMING apply)
 	return g_file_ctx;
 }
 

@@ -277,8 +277,8 @@ static void ensure_seed_stream(mpa_ctx_t *ctx)
 int dev_upload_index(mpa_ctx_t *ctx, mpa_idx_s *mi)
 {
 	if (ctx->device < 0 || ctx->device >= mpa_idx_s::kMaxDevices) { set_error("device number beyond what an index keeps copies for"); return MPA_ERR_UNSUPPORTED; }
-	static std::mutex mu;                                     // (the pipelines of several devices may get here together)
-	std::lock_guard<std::mutex> g(mu);
+	static std::mutex mu[mpa_idx_s::kMaxDevices];             // one per device: the pipelines of several devices upload side by side
+	std::lock_guard<std::mutex> g(mu[ctx->device]);
 	if (mi->dev[ctx->device]) return MPA_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
 	DeviceIndex *d = new DeviceIndex();
@@ -841,8 +841,8 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 	if (dev_upload_index(ctx, mi) != MPA_OK) return MPA_ERR_HIP;
 	DeviceIndex *d = mi->dev[ctx->device];
 	if (!d->kb) {
-		static std::mutex mu;
-		std::lock_guard<std::mutex> g(mu);
+		static std::mutex mu[mpa_idx_s::kMaxDevices];            // (per device, like dev_upload_index)
+		std::lock_guard<std::mutex> g(mu[ctx->device]);
 		if (!d->kb) {
 			uint32_t *p = nullptr;
 			HIP_TRY(hipMalloc((void**)&p, mi->kb.size() * 4 + 16));
@@ -1481,12 +1481,15 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		t.ncol = (x.al + 7) / 8 * 8;
 		t.out_idx = (int32_t)k;
 		// (the int32 sweeps keep the striped reference's lane segments apart by offsets of 2^20 in their scans: column * ge must stay below)
-		if ((int64_t)t.ncol * opt->ge >= (1 << 19)) { set_error("DP call too wide for this gap-extension penalty (columns x ge must stay below 2^19)"); return MPA_ERR_UNSUPPORTED; }
+		// (checked below where it matters: the traceback sweeps and the block-major extension sweep; the packed extension kernels
+		// have their own bound, may_saturate)
+		const bool seg_overflow = (int64_t)t.ncol * opt->ge >= (1 << 19);
 		const bool is_ext = (x.flag & (MPA_F_EXT_LEFT | MPA_F_EXT_RIGHT)) != 0;
 		if (is_ext) {
 			int cls = ext_class_of(t.ncol);                        // -1: wider than k_ext_wide<16> covers -> k_ext_huge (class 7)
 			if (ctx->no_split && cls >= 5) cls = -1;               // repeated round: no inter-workgroup hand-off (see mpa_dp_run)
 			if (wide_ge) cls = -1;
+			if (cls < 0 && seg_overflow) { set_error("DP call " + std::to_string(k) + ": too wide for this gap-extension penalty (columns x ge must stay below 2^19 in the int32 sweeps)"); return MPA_ERR_UNSUPPORTED; }
 			// The packed kernels run their gap scan on h + j*ge with saturating adds, which is only the reference's value while
 			// nothing can reach the int16 limits; calls that could (more than ~2900 columns with BLOSUM62, hence always of the
 			// "huge" class) are swept by k_ext_huge, whose int32 arithmetic clamps every operation like the reference does.
@@ -1498,6 +1501,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			max_nl_ext = std::max(max_nl_ext, x.nl);
 		} else {
 			if (!(x.flag & MPA_F_CIGAR)) { set_error("global DP without CIGAR is not part of miniprot's path"); return MPA_ERR_UNSUPPORTED; }
+			if (seg_overflow) { set_error("DP call " + std::to_string(k) + ": too wide for this gap-extension penalty (columns x ge must stay below 2^19 in the int32 sweeps)"); return MPA_ERR_UNSUPPORTED; }
 			t.pw = t.ncol;
 			t.pad_ = t.ncol <= 16 ? 0 : t.ncol <= 32 ? 1 : t.ncol <= 64 ? 2 : t.ncol <= 128 ? 3 : t.ncol <= 256 ? 4 : t.ncol <= 512 ? 5 : t.ncol <= 1024 ? 6 : 7;
 			// Checkpointed traceback (dp_device.h): a call of up to 64 columns and many rows -- the gap fills across introns and the spans
@@ -1748,6 +1752,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 	bool round_launched = false;
 	const bool use_pool = dp_pool_enabled();
 	bool round_pending = false;                              // (worker pool) a round is armed and not yet known to be complete
+	hipStream_t round_ws = s;                                // ... and the stream its workers were launched on
 	unsigned int round_gen = 0;
 	size_t round_units = 0;
 	const DpUnit *round_unit_list = nullptr;
@@ -1906,7 +1911,7 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			if (polls >= 8) { struct timespec ts = { 0, 100000L }; nanosleep(&ts, nullptr); }
 			if ((polls & 1023) == 1023) {
 				if (now_ms() - t0 > 120000.0) { set_error("DP worker pool: a round did not complete within two minutes"); return MPA_ERR_HIP; }
-				const hipError_t e = hipStreamQuery(ctx->worker_stream);           // (a fault in a worker kernel shows up here, not in the word)
+				const hipError_t e = hipStreamQuery(round_ws);                     // (a fault in a worker kernel shows up here, not in the word)
 				if (e != hipSuccess && e != hipErrorNotReady) { set_error(std::string("DP worker launch: ") + hipGetErrorString(e)); return MPA_ERR_HIP; }
 			}
 		}

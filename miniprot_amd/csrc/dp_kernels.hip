@@ -1913,7 +1913,7 @@ __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, 
 	}
 }
 
-// (MPA_DP_POOL=0: one launch per round, one workgroup per unit, the hardware's in-order dispatcher as the task queue)
+// (the default executor: one launch per round, one workgroup per unit, the hardware's in-order dispatcher as the task queue)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_dp_round(ExtArgs ea, ExtWideArgs wa, GlobArgs ga, const DpUnit *units)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 }
 
 // ------------------------------------------------------------------------------------------------
-// The DP worker pool (the default): the units of ALL batches in their DP rounds on a device are served by one bounded
+// The DP worker pool (MPA_DP_POOL=1; off by default -- measured level to 10 % behind the launches): the units of ALL batches in their DP rounds on a device are served by one bounded
 // population of worker workgroups instead of one launch per round.
 //
 // Why.  A round's units are a few thousand short ones and a handful that sweep 100 000 - 190 000 rows (25 - 50 ms at one row per

@@ -5,8 +5,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-# the file mapper (mp_map_file) takes every GPU of the node by default; the tests are written for one (tests/test_multi_gpu.py names its own list)
-os.environ.setdefault("MPA_DEVICES", "1")
+# the tests are written for one GPU, device 0 (tests/test_multi_gpu.py names its own list)
+os.environ.setdefault("MPA_DEVICES", "0")
 
 
 def pytest_configure(config):
