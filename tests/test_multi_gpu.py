@@ -73,3 +73,42 @@ def test_relinked_reference_cli_maps_on_a_device_list(tmp_path):
         r = subprocess.run([ref, "-t4", "-K", "20k", "--gff", mpi, faa], capture_output=True, timeout=600)
         assert r.returncode == 0
         assert outs["0,0"] == r.stdout
+
+
+def test_eight_pipelines_on_one_device(tmp_path):
+    """What a node with eight GPUs runs, on the one GPU the box has: MPA_DEVICES=0,0,0,0,0,0,0,0 through the relinked reference
+    command line -- eight pipelines (eight root contexts, ~100 stage threads) claiming from one counter: no deadlock, the bytes of
+    the one-pipeline run and of the reference, and the host CPU the eight pipelines take (recorded, not asserted)."""
+    import time
+    import resource
+    exe = os.path.join(refbind.ROOT, "examples", "_relink", "miniprot")
+    if not os.path.exists(exe):
+        pytest.skip("examples/_relink/miniprot is built where /root/reference exists")
+    mpa, golden, case, idx, batches, prots, names = _job()
+    mpi = str(tmp_path / "g.mpi")
+    faa = str(tmp_path / "p.faa")
+    idx.dump(mpi)
+    idx.close()
+    with open(faa, "w") as f:
+        for rep in range(4):                                      # enough mini-batches for eight pipelines to share
+            for nm, p in zip(names, prots):
+                f.write(">%s_%d\n%s\n" % (nm, rep, p if isinstance(p, str) else p.decode()))
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(refbind.ROOT, "miniprot_amd") + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    outs, cpu = {}, {}
+    for devs in ("0", "0,0,0,0,0,0,0,0"):
+        e = dict(env, MPA_DEVICES=devs)
+        r0, t0 = resource.getrusage(resource.RUSAGE_CHILDREN), time.time()
+        r = subprocess.run([exe, "-t16", "-K", "10k", "--gff", mpi, faa], env=e, capture_output=True, timeout=900)
+        r1, t1 = resource.getrusage(resource.RUSAGE_CHILDREN), time.time()
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+        outs[devs] = r.stdout
+        cpu[devs] = ((r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime), t1 - t0)
+    assert outs["0,0,0,0,0,0,0,0"] == outs["0"]
+    assert outs["0"].count(b"\n") > 40
+    print("host CPU-s / wall-s: one pipeline %.2f / %.2f, eight pipelines %.2f / %.2f" % (cpu["0"] + cpu["0,0,0,0,0,0,0,0"]))
+    ref = os.path.join(refbind.ROOT, "oracle", "_ref", "miniprot")
+    if os.path.exists(ref):
+        r = subprocess.run([ref, "-t4", "-K", "10k", "--gff", mpi, faa], capture_output=True, timeout=900)
+        assert r.returncode == 0
+        assert outs["0"] == r.stdout
