@@ -95,7 +95,8 @@ enum DpUnitKind : int32_t {
 	U_GLOB_MB,                          // ... block-major ones (more than 1024 columns)
 	U_GLOB_W2, U_GLOB_W4,               // two two-wave / one four-wave traceback group(s)
 	U_LITE16, U_LITE32, U_LITE64,       // up to four independent waves of the checkpointed traceback's packed sweep (ExtWave descriptors)
-	U_LITE128                           // ... one call of 65..128 columns per wave (column c + 64 in the high half of lane c)
+	U_LITE128,                          // ... one call of 65..128 columns per wave (column c + 64 in the high half of lane c)
+	U_EXT128                            // up to four independent extension waves of one 65..128-column call each (same layout)
 };
 struct DpUnit { int32_t kind, first, count, blk, n_blk, sgroup, xg_first, pad_; };
 

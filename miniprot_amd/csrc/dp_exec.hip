@@ -223,7 +223,11 @@ static hipError_t wait_stream(mpa_ctx_t *ctx, hipStream_t s)
 	for (int polls = 0;; ++polls) {
 		e = hipEventQuery(ctx->wait_ev);
 		if (e != hipErrorNotReady) return e;
-		if (polls >= 8) { struct timespec ts = { 0, 100000L }; nanosleep(&ts, nullptr); }
+		if (polls >= 8) {
+			static const long nap_ns = [] { const char *e = getenv("MPA_POLL_US"); const long v = e ? atol(e) : 100; return (v < 1 ? 1 : v > 5000 ? 5000 : v) * 1000L; }();
+			struct timespec ts = { 0, nap_ns };
+			nanosleep(&ts, nullptr);
+		}
 	}
 }
 
@@ -1497,6 +1501,10 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			if (may_saturate && cls >= 0) { set_error("extension call could saturate int16 in the packed kernels; not supported with these scores"); return MPA_ERR_UNSUPPORTED; }
 			t.pw = cls >= 0 ? kExtClasses[cls].G * kExtClasses[cls].NB : t.ncol;
 			t.pad_ = cls >= 0 ? cls : 7;
+			// 65..128 columns: one wave per call, column c + 64 in the high half of lane c (ext_narrow<64, false, true>, class 8), instead
+			// of a two-wave group per pair of calls (MPA_DP_EXT_DUAL=0: the two-wave groups of rounds 2-5)
+			static const bool ext_dual = [] { const char *e = getenv("MPA_DP_EXT_DUAL"); return !e || atoi(e) != 0; }();
+			if (cls == 3 && ext_dual && !ctx->antidiag) t.pad_ = 8;
 			ext_ids.push_back((int32_t)k);
 			max_nl_ext = std::max(max_nl_ext, x.nl);
 		} else {
@@ -1567,6 +1575,16 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			}
 			ewave_cnt[cls] = (int)ewaves.size() - ewave_first[cls];
 		}
+	}
+	// ---- one-call waves of the 65..128-column extension class (8: sorts behind the huge class 7)
+	int dwave_first = (int)ewaves.size(), dwave_cnt = 0;
+	for (size_t p = 0; p < ext_ids.size(); ++p) {
+		if (T[ext_ids[p]].pad_ != 8) continue;
+		ExtWave w;
+		memset(&w, 0, sizeof(w));
+		for (int k = 0; k < 8; ++k) w.task[k] = -1;
+		w.task[0] = ext_ids[p], w.rec_base = T[ext_ids[p]].rec_off, w.max_nl = T[ext_ids[p]].nl;
+		ewaves.push_back(w), ++dwave_cnt;
 	}
 	// ---- waves of the checkpointed traceback's packed sweep (classes 8, 9, 10 sort behind every other traceback call)
 	size_t n_reg_glob = 0;
@@ -1779,6 +1797,8 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
 		for (int k = 0; k < ewave_cnt[5]; ++k)
 			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 425, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
+		for (int k = 0; k < dwave_cnt; k += per_narrow)              // 65..128-column extension calls, one per wave
+			add(U_EXT128, dwave_first + k, std::min(per_narrow, dwave_cnt - k), (int64_t)ewaves[dwave_first + k].max_nl * 200);
 		for (int cls = 0; cls < 4; ++cls)                            // the packed sweeps of the checkpointed traceback
 			for (int k = 0; k < lwave_cnt[cls]; k += per_narrow)
 				add(U_LITE16 + cls, lwave_first[cls] + k, std::min(per_narrow, lwave_cnt[cls] - k), (int64_t)ewaves[lwave_first[cls] + k].max_nl * (cls == 3 ? 200 : 170));

@@ -554,6 +554,38 @@ __device__ __forceinline__ uint32_t prof2s(const uint32_t lo, const uint32_t hi)
 		: [hr2] "v"(Hr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
 		  [gojge] "v"(gojge), [gl] "v"(GvL), [tl] "v"(TvL), [go] "s"(goP), [sel] "s"(sel_lo))
 
+// DUAL extension rows (one call of 65..128 columns per wave, see MPA_EX64_LD below): the tail with the vote and the two carries
+#define MPA_ROW_TAIL_D(Hr2, Hs2, Dr2, Hs3, M3) \
+	asm volatile(MPA_SCAN4 \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"s_nop 0\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"s_nop 0\n\t" \
+		"v_readlane_b32 %[st], %[x], 63\n\t" \
+		"s_lshl_b32 %[st], %[st], 16\n\t" \
+		"s_or_b32 %[st], %[st], 0x8000\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[t2], %[ke], %[st]\n\t" \
+		"v_pk_sub_i16 %[t2], %[t2], %[gojge] clamp\n\t" \
+		"v_pk_max_i16 %[h], %[h], %[t2]\n\t" \
+		"v_pk_min_i16 %[vt], %[h], %[gl]\n\t" \
+		"v_pk_max_i16 %[vt], %[vt], %[tl]\n\t" \
+		"v_readlane_b32 %[st], %[h], 63\n\t" \
+		"s_lshl_b32 %[st], %[st], 16\n\t" \
+		"s_or_b32 %[st], %[st], 0x8000\n\t" \
+		"v_mov_b32_dpp %[hs3], %[h] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_writelane_b32 %[hs3], %[st], 0\n\t" \
+		"v_pk_max_i16 %[m3], %[h], %[hs3]" \
+		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [dr2] "+v"(Dr2), [hs3] "+v"(Hs3), \
+		  [t2] "=&v"(tA_), [hDn] "=&v"(hDn), [a0] "=&v"(a0), [a1] "=&v"(a1), [vt] "=&v"(vt), [m3] "=&v"(M3), [st] "=&s"(stmp) \
+		: [hr2] "v"(Hr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
+		  [gojge] "v"(gojge), [gl] "v"(GvL), [tl] "v"(TvL), [go] "s"(goP), [sel] "s"(sel_lo) \
+		: "scc")
 // The rows of the checkpointed traceback's sweep (ext_narrow<G, true>): the same two blocks without the vote, with the four
 // "fresh value minus carried value" differences whose signs are the extension bits of the reference's traceback word (bit 5: D(i-3,j)
 // > H(i-3,j) - q, nasw-sse.c:455; bits 6..8: A, B, C carried rather than opened, :462-485), and with the new D state in a register
@@ -688,11 +720,11 @@ struct ExtCall { int32_t Gs, maxi, maxsc, pk, pen, wit, nl, al; };     // wit: w
 
 // LITE: the packed sweep of the checkpointed traceback (dp_device.h): a global alignment (no best row, no x-drop: every row of
 // every call is swept), extension bits and checkpoints out, H(nl-1, al-1) as the score.
-// DUAL (with LITE, G = 64): ONE call of 65..128 columns per wave, column c + 64 in the high half of lane c (slot 0 of the wave).
+// DUAL (G = 64): ONE call of 65..128 columns per wave, column c + 64 in the high half of lane c (slot 0 of the wave).
 template<int G, bool LITE = false, bool DUAL = false>
 __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp, const WavePos wp)
 {
-	static_assert(!DUAL || (LITE && G == 64), "DUAL is the 128-column class of the checkpointed traceback");
+	static_assert(!DUAL || G == 64, "DUAL is the 128-column class: both halves of the 64 lanes");
 	constexpr int NG = 64 / G;               // lane groups per wave
 	constexpr int NSLOT = 2 * NG;            // calls per wave: two int16 halves per group
 	char *lds_prof = wp.lds;                                           // [NSLOT][G columns][23] int16
@@ -819,17 +851,19 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			gl[h] = 32767, tl[h] = NEG16;
-			if (e[h].wit == EXT_DONE) continue;
+			const ExtCall &ec = e[DUAL ? 0 : h];                             // (DUAL: both halves are columns of the call in slot 0)
+			const int cidx = DUAL ? col_ + 64 * h : col_;
+			if (ec.wit == EXT_DONE) continue;
 			any = true;
-			const int32_t eb = col_ == e[h].al - 1 ? c.end_bonus : 0;
-			if (col_ < (e[h].al + 7) / 8 * 8) {
-				const int32_t g = e[h].Gs + e[h].pen - eb;
+			const int32_t eb = cidx == ec.al - 1 ? c.end_bonus : 0;
+			if (cidx < (ec.al + 7) / 8 * 8) {
+				const int32_t g = ec.Gs + ec.pen - eb;
 				if (g < NEG16) force = true;
 				gl[h] = g < NEG16 ? NEG16 : g > 32767 ? 32767 : g;
 			}
-			if (e[h].wit < 0 || 32767 - e[h].pen < e[h].Gs - c.xdrop) force = true;
-			if (e[h].wit == col_) {
-				const int32_t t = e[h].Gs - c.xdrop + e[h].pen - eb;
+			if (ec.wit < 0 || 32767 - ec.pen < ec.Gs - c.xdrop) force = true;
+			if (ec.wit == cidx) {
+				const int32_t t = ec.Gs - c.xdrop + ec.pen - eb;
 				if (t > 32767 || t < NEG16) force = true;
 				tl[h] = t < NEG16 ? NEG16 : t > gl[h] ? gl[h] : t;
 			}
@@ -851,7 +885,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 				e[h].wit = EXT_DONE;
 				// LITE: row nl - 1 was the call's last: its score is H(nl-1, al-1) (nasw-sse.c:543); a call of fewer than three rows has none
 				if (LITE && !DUAL && col_ == e[h].al - 1) a.score[wvp->task[h * NG + grp_]] = e[h].nl < 3 ? NEG16 : half16(h_prev, h);
-				if (DUAL && col_ == (e[h].al - 1) % 64) a.score[wvp->task[0]] = e[h].nl < 3 ? NEG16 : half16(h_prev, (e[h].al - 1) / 64);
+				if (LITE && DUAL && col_ == (e[h].al - 1) % 64) a.score[wvp->task[0]] = e[h].nl < 3 ? NEG16 : half16(h_prev, (e[h].al - 1) / 64);
 			}
 			if (e[h].wit != EXT_DONE) {
 				int64_t nxt = e[h].nl;
@@ -877,6 +911,26 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 		ExtCall e[2];
 		int lane_, grp_, col_;
 		load_calls(e, lane_, grp_, col_);
+		if (DUAL) {
+			// one call in both halves: its row maximum is over the live columns of both, the witness the first column holding it
+			ExtCall &ec = e[0];
+			const uint32_t ebv = pack16(col_ == ec.al - 1 ? c.end_bonus : 0, col_ + 64 == ec.al - 1 ? c.end_bonus : 0);
+			const uint32_t cand = p_subs(p_adds(h, ebv), splat16(ec.pen));
+			const int32_t ncol_ = (ec.al + 7) / 8 * 8, cv0 = lo16(cand), cv1 = hi16(cand);
+			const bool live0 = col_ < ncol_, live1 = col_ + 64 < ncol_;
+			const int32_t m = group_max<G>(imax(live0 ? cv0 : NEG16, live1 ? cv1 : NEG16));
+			if (ec.wit != EXT_DONE) {
+				if (m > ec.Gs) ec.Gs = m, ec.maxi = i, ec.maxsc = m + ec.pen, Hbest = h;
+				if (ec.Gs - m > c.xdrop) ec.wit = EXT_DONE;
+				else {
+					const uint64_t at0 = __ballot(live0 && cv0 == m), at1 = __ballot(live1 && cv1 == m);
+					ec.wit = at0 ? __ffsll((unsigned long long)at0) - 1 : 64 + __ffsll((unsigned long long)at1) - 1;
+				}
+			}
+			store_calls(e, grp_, col_);
+			repack(e, col_);
+			return;
+		}
 		const uint32_t ebv = pack16(col_ == e[0].al - 1 ? c.end_bonus : 0, col_ == e[1].al - 1 ? c.end_bonus : 0);
 		const uint32_t cand = p_subs(p_adds(h, ebv), pack16(e[0].pen, e[1].pen));
 #pragma unroll
@@ -1006,6 +1060,7 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 					dn[R3] = rcur.x, ac[R3] = rcur.y; \
 					if constexpr (G == 16) MPA_ROW_TAIL(MPA_EX16, MPA_HS16, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 					else if constexpr (G == 32) MPA_ROW_TAIL(MPA_EX32, MPA_HS32, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
+					else if constexpr (DUAL) MPA_ROW_TAIL_D(Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 					else MPA_ROW_TAIL(MPA_EX64, MPA_HS64, Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3]); \
 				} else { \
 					MPA_ROW_HEAD_L(Hr[R1], Hs[R1], dn[R1], dn[R2], rcur.x, ac[R1], ac[R2], rcur.y, M[R1], M[R2]); \
@@ -1055,6 +1110,29 @@ __device__ __forceinline__ void ext_narrow(const ExtArgs &a, const ExtWave *wvp,
 	}
 
 	// ---- results (nasw-sse.c:435-443): first column of the best row that attains the best score
+	if (DUAL) {
+		const int32_t tid = wvp->task[0];
+		if (tid < 0) return;
+		const ExtCall e = lds_call[0];
+		int32_t first = INT32_MAX;
+		if (e.maxi >= 0) {
+			int32_t v0 = lo16(Hbest), v1 = hi16(Hbest);
+			if (col == e.al - 1) v0 += c.end_bonus;
+			if (col + 64 == e.al - 1) v1 += c.end_bonus;
+			const uint64_t m0 = __ballot(col < e.al && v0 == e.maxsc), m1 = __ballot(col + 64 < e.al && v1 == e.maxsc);
+			if (m0) first = __ffsll((unsigned long long)m0) - 1;
+			else if (m1) first = 64 + __ffsll((unsigned long long)m1) - 1;
+		}
+		if (col == 0) {
+			ExtOut o;
+			o.nt_len = e.maxi + 1;
+			o.aa_len = e.maxi < 0 ? 0 : (first == INT32_MAX ? e.al + 1 : first + 1);
+			o.score = e.maxsc;
+			o.flags = (e.maxi >= 0 && first == INT32_MAX) ? 1 : 0;
+			a.out[tid] = o;
+		}
+		return;
+	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int32_t tid = wvp->task[h * NG + grp];
@@ -1909,6 +1987,7 @@ __device__ __forceinline__ void dp_run_unit(const DpUnit &u, const ExtArgs &ea, 
 	case U_LITE32: if (!WG_ONLY && wv < u.count) ext_narrow<32, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_LITE64: if (!WG_ONLY && wv < u.count) ext_narrow<64, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	case U_LITE128: if (!WG_ONLY && wv < u.count) ext_narrow<64, true, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
+	case U_EXT128: if (!WG_ONLY && wv < u.count) ext_narrow<64, false, true>(ea, ea.waves + u.first + wv, WavePos{ lds + wv * EXT_NARROW_LDS, lane, 0, lane }); break;
 	default: break;
 	}
 }
@@ -2129,6 +2208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 		case U_LITE32: ext_narrow<32, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		case U_LITE64: ext_narrow<64, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		case U_LITE128: ext_narrow<64, true, true>(ra.ea, ra.ea.waves + u.first, wp); break;
+		case U_EXT128: ext_narrow<64, false, true>(ra.ea, ra.ea.waves + u.first, wp); break;
 		default: break;
 		}
 		__builtin_amdgcn_s_setprio(0);
