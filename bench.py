@@ -426,7 +426,9 @@ def main():
     # more than 64 threads lose (measured at config 3 on the 256-thread host: 32 -> 0.98 s, 64 -> 1.00 s, 96 -> 1.10 s, 128 -> 1.22 s)
     # (a rank's pipeline runs about 2.75 x n_threads host threads: two planners with half each, two seeders, four DP lanes and
     # the output stage with a quarter each -- so N ranks share the host's hardware threads without oversubscribing them)
-    n_threads = a.threads if a.threads > 0 else max(4, min(64, int(ncpu / max(world, 1) / 2.75), int(1.5 * ncpu_eff / max(world, 1))))
+    # (round 6, 16-core quota, same-lease repeats: 12 threads 22.4-23.7 M residues/s, 24: 24.0-25.2, 32: 24.2-24.4, 40: 25.0-26.2, 56: 24.8-25.6 --
+    # the host stages are short bursts on the batches' critical path, 7 cores busy on average: 2.5 x the quota)
+    n_threads = a.threads if a.threads > 0 else max(4, min(64, int(ncpu / max(world, 1) / 2.75), int(2.5 * ncpu_eff / max(world, 1))))
 
     def barrier():
         if dist is not None:

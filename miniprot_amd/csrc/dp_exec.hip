@@ -514,9 +514,33 @@ SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k)
 	return ctx->holds[(size_t)k];
 }
 
+// (MPA_TIMING) the device pools of a root context and its siblings, largest first: where the HBM of a pipeline goes
+void ctx_pool_report(mpa_ctx_t *root)
+{
+	static const char *const kName[] = { "tasks", "waves", "chunks", "qseq", "rec", "prof", "tb", "cig", "ncig", "score", "extout", "bnd", "list", "rowkey", "cigd", "cigoff", "hkey", "xg", "units",
+		"s.jobs", "s.key0", "s.key1", "s.f", "s.pred", "s.mark", "s.flag", "s.idx", "s.tmp", "s.cfirst", "s.r_win", "s.r_chunk", "s.r_words", "s.r_hits", "s.r_count",
+		"s.c_a", "s.c_f", "s.c_pred", "s.c_mark", "s.c_flag", "s.c_first", "s.c_long", "s.pf_qfirst2", "s.val64_0", "s.val64_1",
+		"s.s_meta", "s.s_cur", "s.s_cur2", "s.s_kept", "s.s_base", "s.s_out", "s.s_flag", "s.dkey", "s.x_all", "s.rx_all", "s.rx_keys", "lite", "ckpt", "wlist" };
+	std::vector<mpa_ctx_t*> all{ root };
+	for (mpa_ctx_t *sb : root->siblings) all.push_back(sb);
+	size_t grand = 0;
+	for (size_t c = 0; c < all.size(); ++c) {
+		size_t tot = 0;
+		std::vector<std::pair<size_t, int>> big;
+		ctx_each_devbuf(all[c], [&](DevBuf &b, int k) { tot += b.cap; if (b.cap >= ((size_t)64 << 20)) big.push_back({ b.cap, k }); });
+		std::sort(big.rbegin(), big.rend());
+		fprintf(stderr, "[mpa-pools] context %zu: %.2f GB;", c, tot / 1e9);
+		for (auto &x : big) fprintf(stderr, " %s %.2f", x.second < (int)(sizeof(kName) / sizeof(kName[0])) ? kName[x.second] : "?", x.first / 1e9);
+		fprintf(stderr, "\n");
+		grand += tot;
+	}
+	fprintf(stderr, "[mpa-pools] all contexts of the pipeline: %.2f GB of pools (+ the resident index)\n", grand / 1e9);
+}
+
 void pool_harvest(mpa_ctx_t *ctx, bool wait);
 void ctx_absorb_sibling_stats(mpa_ctx_t *ctx)
 {
+	if (timing_on()) ctx_pool_report(ctx->root ? ctx->root : ctx);
 	pool_harvest(ctx, true);
 	for (mpa_ctx_s *sb : ctx->siblings) {
 		pool_harvest(sb, true);

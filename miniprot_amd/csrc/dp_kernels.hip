@@ -1622,8 +1622,10 @@ __device__ __forceinline__ void glob_narrow(const GlobArgs &a, const GlobWave &w
 	for (int32_t blk = 0; blk < nblk; ++blk) {
 		const int32_t gc = blk * G + col;                 // global column of this lane
 		const bool live = tid >= 0 && gc < ncol;
-		// the previous block's boundary records were written by this wave: make them visible (and drop L1)
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+		// the previous block's boundary records were written by this wave: make them visible (and drop L1).  (Not for the walk's
+		// recomputed blocks, whose boundary records are in LDS: an agent-scope release is a write-back of the whole L2, and the walk
+		// recomputes tens of thousands of blocks per round.)
+		if (MB && blk > 0 && !rz) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
 		// stage this block's profile columns
 		wave_sync();
 		for (int s = 0; s < NG; ++s) {
