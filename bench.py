@@ -49,6 +49,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 VALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2 (packed) x 2.4 GHz  (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
 VALU_I16_PEAK = 256 * 4 * 32 * 2 * 2.4e9
+VALU_CYCLES_PER_PK_INST = 4.15   # measured: cycles of a SIMD per wave64 packed-int16 (VOP3P) instruction, 8 resident waves (profiles/r06_valu_rate.txt)
+VALU_I16_MEASURED = 256 * 4 * 64 * 2 * 2.4e9 / VALU_CYCLES_PER_PK_INST
 OPS_PER_CELL_EXT = 32            # int16 ops per DP cell, score-only loop of the reference
 OPS_PER_CELL_GLOB = 65           # with traceback
 
@@ -304,7 +306,9 @@ def roofline_record(st, elapsed, world):
             pass
     cur = cur.hexdigest()
     kname = "k_dp_worker" if pool else "k_dp_round"
-    for name, what in (("r05_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch"),):
+    valu_share = None
+    for name, what in (("r06_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch"),
+                       ("r05_pmc_summary.json", "config 3 at full size, this mini-batch size, two DP rounds per batch")):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
@@ -313,12 +317,21 @@ def roofline_record(st, elapsed, world):
                     src = "profiles/%s was collected on another source of the DP kernels (md5 %s, running %s): not quoted" % (name, str(d.get("dp_kernel_source_md5"))[:8], cur[:8])
                     continue
                 traffic = d["kernels"][kname]["hbm_bytes_per_launch"]
+                k = d["kernels"][kname]
+                if k.get("valu_insts_per_launch") and k.get("avg_us"):
+                    # share of the chip's VALU issue cycles the launch used, at the MEASURED 4.15 cycles per packed instruction
+                    # (profiles/r06_valu_rate.txt), over the launch's whole duration (the PMC passes run the launch alone)
+                    valu_share = k["valu_insts_per_launch"] * VALU_CYCLES_PER_PK_INST / (256 * 4 * k["avg_us"] * 1e-6 * 2.4e9)
                 src = "profiles/%s: separate rocprofv3 --pmc passes (tools/pmc_round.sh) over %s; kernel source md5 %s = the running library's" % (name, what, cur[:8])
                 break
             except Exception:
                 pass
     return {"kernel": kernel, "bound": "valu-int16", "achieved": ach / 1e12, "peak": VALU_I16_PEAK / 1e12, "unit": "Tops/s (packed int16)", "frac": ach / VALU_I16_PEAK,
             "traffic": traffic, "traffic_source": src,
+            # the same achieved rate against what the chip was MEASURED to issue: a packed int16 instruction takes 4.15 cycles of its
+            # SIMD, not the 2 the guide's wave64 rate (and `peak`) assume (tools/ubench/valu_rate.hip, profiles/r06_valu_rate.txt)
+            "measured_issue_peak": VALU_I16_MEASURED / 1e12, "frac_of_measured_issue_peak": ach / VALU_I16_MEASURED,
+            "wall_frac": wall_ops / VALU_I16_PEAK / max(world, 1), "valu_issue_share_over_launch": valu_share,
             "launches": n, "avg_launch_ms": (st["ms_round"] if pool else ms) / n, "kernel_active_ms": ms, "cells_per_launch": cells / n, "ops_per_cell": {"score_only": OPS_PER_CELL_EXT, "traceback": OPS_PER_CELL_GLOB},
             "gcups_per_launch": cells / (ms * 1e-3) / 1e9,          # (worker pool: GCUPS while the pool is running)
             "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes / n,
