@@ -1085,30 +1085,22 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 		cod[e] = (uint8_t)c;
 	}
 	__syncthreads();
-	for (int t = 0; t < REFINE_CHUNK / 256; ++t) {
-		const int32_t pos = cstart + t * 256 + (int32_t)threadIdx.x;
-		if (pos >= w.len) continue;
-		const int e = pos - cstart + REFINE_HALO;
-		uint32_t word = 0;
-		bool ok = true;
-		for (int c = kmer - 1; c >= 0; --c) {
-			const uint32_t r = codon_at(e - 3 * c);
-			if (r == 0xffu) { ok = false; break; }
-			word = word << 4 | r;
-		}
-		if (!ok) continue;
-		word &= mask;
+	// Who scans what: thread 3q + r (q < 85) takes the PER positions 3 PER q + r, + 3, + 6, ... -- one reading frame of a stretch of 3 PER
+	// bases -- so that the k-mer word ROLLS: one codon read per position instead of kmer (round 5: thread t took positions t, t + 256,
+	// ...: five LDS byte reads per k-mer).  Thread 255 takes the chunk's last PER positions the old way.  `run` = valid codons in a row.
+	constexpr int PER = REFINE_CHUNK / 256;
+	auto try_hit = [&](const int32_t pos, const int e, const uint32_t word) {
 		uint32_t grp = 0xffffffffu;
 		for (uint32_t slot = (word * 2654435761u) >> (32 - hs_log2);; slot = (slot + 1) & (HS - 1)) {
 			const uint32_t v = tkey[slot];
 			if (v == word) { grp = tval[slot]; break; }
 			if (v == 0xffffffffu) break;
 		}
-		if (grp == 0xffffffffu) continue;
+		if (grp == 0xffffffffu) return;
 		int32_t n = kmer;
 		for (int q = e - 3 * kmer; n < min_aa_len && q >= 2 && codon_at(q) != 0xffu; q -= 3) ++n;
 		for (int q = e + 3; n < min_aa_len && q < REFINE_CHUNK + 2 * REFINE_HALO && codon_at(q) != 0xffu; q += 3) ++n;
-		if (n < min_aa_len) continue;
+		if (n < min_aa_len) return;
 		const uint4 hit = make_uint4((uint32_t)ch.win, (uint32_t)pos, (uint32_t)(G0 + grp), grp);
 		const uint32_t li = atomicAdd(&l_n, 1u);
 		if (li < REFINE_LCAP) l_hit[li] = hit;
@@ -1117,6 +1109,39 @@ __global__ __launch_bounds__(256) void k_refine_scan_map(DevGenome g, const Refi
 			if (at < cap) hits[at] = hit;
 		}
 		atomicAdd(&wcnt[wc0 + grp], 1u);
+	};
+	if (threadIdx.x < 255) {
+		const int q3 = (int)threadIdx.x / 3, fr = (int)threadIdx.x - 3 * q3;
+		const int e0 = REFINE_HALO + 3 * PER * q3 + fr;              // LDS index of the last base of the thread's first k-mer
+		uint32_t word = 0;
+		int run = 0;
+		for (int c = kmer - 1; c >= 1; --c) {                         // the kmer - 1 codons before it
+			const uint32_t r = codon_at(e0 - 3 * c);
+			if (r == 0xffu) run = 0, word = 0; else word = word << 4 | r, ++run;
+		}
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const int e = e0 + 3 * j;
+			const uint32_t r = codon_at(e);
+			if (r == 0xffu) { run = 0, word = 0; continue; }
+			word = (word << 4 | r) & mask, ++run;
+			const int32_t pos = cstart + e - REFINE_HALO;
+			if (run >= kmer && pos < w.len) try_hit(pos, e, word);
+		}
+	} else {
+		for (int j = 0; j < PER; ++j) {
+			const int e = REFINE_HALO + 3 * PER * 85 + j;
+			const int32_t pos = cstart + e - REFINE_HALO;
+			if (pos >= w.len) continue;
+			uint32_t word = 0;
+			bool ok = true;
+			for (int c = kmer - 1; c >= 0; --c) {
+				const uint32_t r = codon_at(e - 3 * c);
+				if (r == 0xffu) { ok = false; break; }
+				word = word << 4 | r;
+			}
+			if (ok) try_hit(pos, e, word & mask);
+		}
 	}
 	__syncthreads();
 	// (the buffer is emptied when a chunk leaves it more than half full, and behind the workgroup's last chunk)

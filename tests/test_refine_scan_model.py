@@ -85,21 +85,31 @@ def workgroup(glist, wcnt, win, wg_start, chunk, n_super, win_len, hits_of_windo
     cstart = wg_start
     while cstart < win_len and cstart < wg_start + n_super * chunk:
         mine = [h for h in hits_of_window if cstart <= h[0] < cstart + chunk]
-        by_thread = {}
+        # who finds what (round 6, the rolling k-mer word): thread 3q + r takes the positions 3 PER q + r, + 3, ... of the chunk, one
+        # reading frame of a stretch of 3 PER bases, in PER steps; thread 255 the chunk's last PER positions
+        per = chunk // n_threads
+        by_step = {}
+        covered = set()
         for pos, grp in mine:
-            by_thread.setdefault((pos - cstart) % n_threads, []).append((pos, grp))
-        for t in range(chunk // n_threads):                             # the kernel's t loop: position = start + t * 256 + thread
-            for th in rng.permutation(n_threads):
-                for pos, grp in by_thread.get(int(th), []):
-                    if (pos - cstart) // n_threads != t:
-                        continue
-                    li = l_n
-                    l_n += 1                                            # atomicAdd on the LDS counter
-                    if li < lcap:
-                        l_hit[li] = (win, pos, grp)
-                    else:                                               # the buffer is full: a place of its own, as in round 5
-                        glist.put(glist.fetch_add(1), (win, pos, grp))
-                    wcnt[(win, grp)] = wcnt.get((win, grp), 0) + 1
+            o = pos - cstart
+            if o < 3 * per * 85:
+                th, step = 3 * (o // (3 * per)) + o % 3, (o % (3 * per)) // 3
+            else:
+                th, step = 255, o - 3 * per * 85
+            assert 0 <= th < n_threads and 0 <= step < per and (th, step) not in covered
+            covered.add((th, step))
+            by_step.setdefault(step, []).append((th, pos, grp))
+        for step in range(per):                                         # the threads run their step-th position in any order
+            todo = by_step.get(step, [])
+            for k in rng.permutation(len(todo)):
+                th, pos, grp = todo[int(k)]
+                li = l_n
+                l_n += 1                                                # atomicAdd on the LDS counter
+                if li < lcap:
+                    l_hit[li] = (win, pos, grp)
+                else:                                                   # the buffer is full: a place of its own, as in round 5
+                    glist.put(glist.fetch_add(1), (win, pos, grp))
+                wcnt[(win, grp)] = wcnt.get((win, grp), 0) + 1
         last = cstart + chunk >= win_len or cstart + chunk >= wg_start + n_super * chunk
         ln = min(l_n, lcap) if (l_n >= lcap // 2 or last) else 0       # behind the barrier
         if ln:
