@@ -128,7 +128,7 @@ struct HostPinned {
 struct SeedHold { HostPinned h_pos, h_f, h_pred, h_a, h_U, h_A; };
 
 struct SeedBufs {
-	DevBuf jobs, key[2], f, pred, mark, flag, idx, tmp, cfirst;
+	DevBuf jobs, f, pred, mark, flag, idx, tmp, cfirst;
 	HostPinned h_jobs;
 	SeedHold own;                                                          // results of a call without a holder of its own (blocking path, refinement)
 	DevBuf r_win, r_chunk, r_words, r_hits, r_count;      // refinement scan
@@ -199,7 +199,7 @@ template<typename F> static void ctx_each_devbuf(mpa_ctx_s *ctx, F f)
 	SeedBufs &B = ctx->seed;
 	DevBuf *all[] = { &ctx->tasks, &ctx->waves, &ctx->chunks, &ctx->qseq, &ctx->rec, &ctx->prof, &ctx->tb, &ctx->cig, &ctx->ncig,
 	                  &ctx->score, &ctx->extout, &ctx->bnd, &ctx->list, &ctx->rowkey, &ctx->cigd, &ctx->cigoff, &ctx->hkey, &ctx->xg, &ctx->units,
-	                  &B.jobs, &B.key[0], &B.key[1], &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.cfirst,
+	                  &B.jobs, &B.f, &B.pred, &B.mark, &B.flag, &B.idx, &B.tmp, &B.cfirst,
 	                  &B.r_win, &B.r_chunk, &B.r_words, &B.r_hits, &B.r_count,
 	                  &B.c_a, &B.c_f, &B.c_pred, &B.c_mark, &B.c_flag, &B.c_first, &B.c_long,
 	                  &B.pf_qfirst2, &B.val64[0], &B.val64[1],
@@ -518,7 +518,7 @@ SeedHold *ctx_seed_hold(mpa_ctx_t *ctx, int k)
 void ctx_pool_report(mpa_ctx_t *root)
 {
 	static const char *const kName[] = { "tasks", "waves", "chunks", "qseq", "rec", "prof", "tb", "cig", "ncig", "score", "extout", "bnd", "list", "rowkey", "cigd", "cigoff", "hkey", "xg", "units",
-		"s.jobs", "s.key0", "s.key1", "s.f", "s.pred", "s.mark", "s.flag", "s.idx", "s.tmp", "s.cfirst", "s.r_win", "s.r_chunk", "s.r_words", "s.r_hits", "s.r_count",
+		"s.jobs", "s.f", "s.pred", "s.mark", "s.flag", "s.idx", "s.tmp", "s.cfirst", "s.r_win", "s.r_chunk", "s.r_words", "s.r_hits", "s.r_count",
 		"s.c_a", "s.c_f", "s.c_pred", "s.c_mark", "s.c_flag", "s.c_first", "s.c_long", "s.pf_qfirst2", "s.val64_0", "s.val64_1",
 		"s.s_meta", "s.s_cur", "s.s_cur2", "s.s_kept", "s.s_base", "s.s_out", "s.s_flag", "s.dkey", "s.x_all", "s.rx_all", "s.rx_keys", "lite", "ckpt", "wlist" };
 	std::vector<mpa_ctx_t*> all{ root };
@@ -606,13 +606,17 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	const size_t meta_q = ((size_t)n_query + 1) * 8, seg_bytes = (size_t)n_seg * sizeof(SiftSeg);
 	const size_t off_jf = meta_q, off_sf = 2 * meta_q, off_seg = 3 * meta_q, off_qs = off_seg + seg_bytes, meta_bytes = off_qs + ((size_t)n_query + 1) * 4;
 	int rc;
+	// (round 6: the two staging arrays of the sift -- 8 B per staging slot each, dead once k_sift_copy has packed the kept anchors --
+	// live at the front of the chaining block, which is carved up only behind that copy: 4.4 GB less per seeder at genome scale)
+	const size_t stage_bytes = ((size_t)n_stage * 8 + 64 + 255) & ~(size_t)255;
 	if ((rc = B.h_meta.ensure(meta_bytes))) return rc;
 	char *hm = B.h_meta.as<char>();
 	memcpy(hm, qfirst, meta_q), memcpy(hm + off_jf, jfirst.data(), meta_q), memcpy(hm + off_sf, sfirst.data(), meta_q), memcpy(hm + off_seg, segs.data(), seg_bytes), memcpy(hm + off_qs, qseg.data(), ((size_t)n_query + 1) * 4);
 	if ((rc = B.s_meta.ensure(meta_bytes)) || (rc = B.s_cur.ensure((size_t)n_cur * 4 + 16)) || (rc = B.s_cur2.ensure((size_t)n_cur * 4 + 16)) ||
 	    (rc = B.s_kept.ensure((size_t)n_seg * 4)) || (rc = B.s_base.ensure((size_t)n_seg * 8)) || (rc = B.s_out.ensure(((size_t)n_seg + 1) * 8)) ||
 	    (rc = B.s_flag.ensure((size_t)n_query * 4 + 16)) || (rc = B.pf_qfirst2.ensure(meta_q)) || (rc = B.cfirst.ensure(meta_q)) ||
-	    (rc = B.key[0].ensure((size_t)n_stage * 8 + 64)) || (rc = B.key[1].ensure((size_t)n_stage * 8 + 64)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;
+	    (rc = B.x_all.ensure(2 * stage_bytes)) || (rc = B.h_back.ensure(2 * meta_q + (size_t)n_query * 4 + 64))) return rc;
+	uint64_t *const stage0 = B.x_all.as<uint64_t>(), *const stage1 = (uint64_t*)(B.x_all.as<char>() + stage_bytes);
 	HIP_TRY(hipMemcpyAsync(B.s_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemsetAsync(B.s_flag.p, 0, (size_t)n_query * 4 + 16, s));
 	const char *dm = B.s_meta.as<char>();
@@ -624,11 +628,11 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	static const int sift_cap = [] { const char *e = getenv("MPA_SIFT_CAP"); return e ? atoi(e) : 4096; }();
 	if (sift_cap == 2048)
 		hipLaunchKernelGGL(k_seed_sift<2048>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
-		                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
+		                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), stage0, stage1, B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
 		                   B.s_flag.as<int32_t>());
 	else
 	hipLaunchKernelGGL(k_seed_sift<4096>, dim3((unsigned)n_seg), dim3(SIFT_THREADS), 0, s, d_segs, B.jobs.as<SeedJobDev>(), d_jfirst, d_qfirst, d_sfirst, d->kb, n_block, nb,
-	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
+	                   B.s_cur.as<int32_t>(), B.s_cur2.as<int32_t>(), stage0, stage1, B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(),
 	                   B.s_flag.as<int32_t>());
 	hipLaunchKernelGGL(k_sift_offsets, dim3(1), dim3(256), 0, s, d_segs, n_seg, n_query, d_qseg, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_out.as<int64_t>(),
 	                   B.pf_qfirst2.as<int64_t>());
@@ -654,7 +658,7 @@ static int dev_prechain_forward_sift(mpa_ctx_t *ctx, DeviceIndex *d, uint32_t n_
 	const uint64_t *key = B.dkey.as<uint64_t>();
 	const uint64_t *val = B.val64[0].as<uint64_t>();
 	hipLaunchKernelGGL(k_sift_copy, dim3((unsigned)n_seg), dim3(256), 0, s, d_segs, B.s_flag.as<int32_t>(), B.s_kept.as<uint32_t>(), B.s_base.as<int64_t>(), B.s_out.as<int64_t>(),
-	                   B.key[0].as<uint64_t>(), B.key[1].as<uint64_t>(), B.dkey.as<uint64_t>(), B.val64[0].as<uint64_t>());
+	                   stage0, stage1, B.dkey.as<uint64_t>(), B.val64[0].as<uint64_t>());
 	hipLaunchKernelGGL(k_seed_fill, dim3(nblk), dim3(256), 0, s, n2, pp.kmer, B.f.as<int32_t>(), B.pred.as<int32_t>(), B.mark.as<int32_t>(), B.flag.as<uint32_t>());
 	hipLaunchKernelGGL(k_prechain_fwd<uint64_t>, dim3(nblk), dim3(256), 0, s, key, val, n2, nb, B.pf_qfirst2.as<int64_t>(), pp, B.f.as<int32_t>(), B.pred.as<int32_t>(),
 	                   B.mark.as<int32_t>(), B.flag.as<uint32_t>());
@@ -894,7 +898,7 @@ int dev_prechain_forward(mpa_ctx_t *ctx, mpa_idx_s *mi, const ChainParams &pre, 
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			const SeedBufs &Bc = ctx->seed;
-			const size_t have = Bc.key[0].cap + Bc.key[1].cap + Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap + Bc.x_all.cap + Bc.dkey.cap + Bc.val64[0].cap;
+			const size_t have = Bc.f.cap + Bc.pred.cap + Bc.mark.cap + Bc.flag.cap + Bc.idx.cap + Bc.tmp.cap + Bc.x_all.cap + Bc.dkey.cap + Bc.val64[0].cap;
 			if ((size_t)n * 40 > have + free_b - (free_b >> 3)) { set_error("GPU seeding: batch too large for device memory"); return MPA_ERR_UNSUPPORTED; }
 		}
 	}
