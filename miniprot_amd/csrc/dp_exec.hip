@@ -1818,13 +1818,13 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 				add(U_EXT16 + cls, ewave_first[cls] + k, std::min(per_narrow, ewave_cnt[cls] - k), (int64_t)ewaves[ewave_first[cls] + k].max_nl * 160);
 		// (worker pool: a workgroup goes on to its next unit, so all four waves must leave a unit through the same barriers -- a
 		// 65..128-column group then takes a whole workgroup on the four-wave body, its waves 2 and 3 on dead columns)
-		if (use_pool) for (int k = 0; k < ewave_cnt[3]; ++k) add(U_EXT_W4, ewave_first[3] + k, 1, (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
-		else for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 370);
-		for (int k = 0; k < ewave_cnt[4]; ++k) add(U_EXT_W4, ewave_first[4] + k, 1, (int64_t)ewaves[ewave_first[4] + k].max_nl * 370);
+		if (use_pool) for (int k = 0; k < ewave_cnt[3]; ++k) add(U_EXT_W4, ewave_first[3] + k, 1, (int64_t)ewaves[ewave_first[3] + k].max_nl * 270);
+		else for (int k = 0; k < ewave_cnt[3]; k += 2) add(U_EXT_W2, ewave_first[3] + k, std::min(2, ewave_cnt[3] - k), (int64_t)ewaves[ewave_first[3] + k].max_nl * 270);
+		for (int k = 0; k < ewave_cnt[4]; ++k) add(U_EXT_W4, ewave_first[4] + k, 1, (int64_t)ewaves[ewave_first[4] + k].max_nl * 270);
 		for (int k = 0; k < ewave_cnt[6]; ++k)
-			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 425, b, 4, k, 3 * k);
+			for (int b = 0; b < 4; ++b) add(U_EXT_SPLIT, ewave_first[6] + k, 1, (int64_t)ewaves[ewave_first[6] + k].max_nl * 310, b, 4, k, 3 * k);
 		for (int k = 0; k < ewave_cnt[5]; ++k)
-			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 425, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
+			for (int b = 0; b < 2; ++b) add(U_EXT_SPLIT, ewave_first[5] + k, 1, (int64_t)ewaves[ewave_first[5] + k].max_nl * 310, b, 2, ewave_cnt[6] + k, 3 * ewave_cnt[6] + k);
 		for (int k = 0; k < dwave_cnt; k += per_narrow)              // 65..128-column extension calls, one per wave
 			add(U_EXT128, dwave_first + k, std::min(per_narrow, dwave_cnt - k), (int64_t)ewaves[dwave_first + k].max_nl * 200);
 		for (int cls = 0; cls < 4; ++cls)                            // the packed sweeps of the checkpointed traceback

@@ -1210,22 +1210,61 @@ __device__ __forceinline__ unsigned long long granule_get(const unsigned long lo
 // owns the columns [256 blk, 256 blk + 256) and receives the carry of the gap scan and the H of the column to its left, row
 // by row, from workgroup blk - 1 through HBM (it runs about fifty rows behind it), so that a 1024-column call occupies four
 // CUs with one wave per SIMD instead of one CU with four (782 -> ~370 ns per row: the tail of a DP round at genome scale).
-#define EXT_WIDE_LDS(NW) ((size_t)(NW) * 2 * 22 * 64 * 2 + 12 * (NW) * 4 + ((NW) <= 4 ? 64 : 128) * 8 + 128 * (2 * (NW) + 1) * 4 + 96 * 8)   /* bytes per group */
+//
+// Round 6: the rows from row 14 on are the hand-scheduled rows of ext_narrow (MPA_ROW_HEAD and a tail without the vote): these
+// calls sweep windows of max_intron / 2 rows (align.c:259-261) that the x-drop practically never cuts short, so a round lasts as
+// long as its longest wide call -- 98 600 rows at 425 ns in the compiled rows of rounds 2-5 (198 instructions per row), which is
+// what the round's other 8 000 units were waiting for.  What a wave takes from its left neighbour -- the carry of the gap scan
+// and H of the column before its first -- enters through LANE 0 only: folded into lane 0's scan input (the inclusive scan then
+// carries it to every lane and lane 63 holds the carry for the wave to the right), and preset in lane 0 of the two registers the
+// wave_shr:1 moves leave untouched there.  Every lane reads the 8-byte exchange slot {carry, H} of its row with one ds_read_b64
+// (lane 0 the neighbour's slot -- or the incoming ring of a split workgroup's first wave --, the others a slot of -inf) and writes
+// {scan, H} with one ds_write_b64 (lane 63 into the wave's slot, the others into a dump area): no exec masking in the rows.
+#define EXT_WIDE_RING 48                       /* rows of decoded records (ring_entry) in LDS; slot 48 repeats slot 0 */
+#define EXT_WIDE_XIN 96                        /* rows of incoming boundary values kept in LDS (two fetches of 48) */
+#define EXT_WIDE_KROWS 96                      /* rows of the key ring: 64 per flush + the lead of the first wave over the last; a multiple of 3 like the other two */
+#define EXT_WIDE_LDS(NW) ((size_t)(NW) * 2 * 64 * PROF_COL_STRIDE + (EXT_WIDE_RING + 1) * 16 + 256 + 32 + (64 * 8 + 32) + EXT_WIDE_XIN * 8 + EXT_WIDE_KROWS * 2 * (NW) * 4)   /* bytes per group; a multiple of 16 */
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2u *lds_u2p;
+#define MPA_ROW_TAIL_W(Hr2, Hs2, Dr2, Hs3, M3, CX, CH) \
+	asm volatile( \
+		"v_pk_max_i16 %[x], %[x], %[cx]\n\t" \
+		MPA_SCAN4 \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"v_mov_b32 %[ke], %[cx]\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"v_mov_b32 %[t2], 0x80008000\n\t" \
+		"v_mov_b32 %[hs3], %[ch]\n\t" \
+		"v_mov_b32_dpp %[t2], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[x], %[x], %[t2]\n\t" \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[ke], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_sub_i16 %[t2], %[ke], %[gojge] clamp\n\t" \
+		"v_pk_max_i16 %[h], %[h], %[t2]\n\t" \
+		"s_nop 1\n\t" \
+		"v_mov_b32_dpp %[hs3], %[h] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+		"v_pk_max_i16 %[m3], %[h], %[hs3]" \
+		: [x] "+v"(x), [h] "+v"(h), [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [ke] "+v"(ke), [dr2] "+v"(Dr2), [hs3] "+v"(Hs3), \
+		  [t2] "=&v"(tA_), [hDn] "=&v"(hDn), [a0] "=&v"(a0), [a1] "=&v"(a1), [m3] "=&v"(M3) \
+		: [hr2] "v"(Hr2), [gei] "v"(rnext.z), [s0] "v"(sraw0), [s1] "v"(sraw1), [hs2] "v"(Hs2), [pb0] "v"(pb0), [pb1] "v"(pb1), [aw] "v"(rnn.w), \
+		  [gojge] "v"(gojge), [cx] "v"(CX), [ch] "v"(CH), [go] "s"(goP), [sel] "s"(sel_lo))
 template<int NWB, bool SPLIT>
 __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int group_idx, const SplitPos pos, const WavePos wp)
 {
 	constexpr int NW = NWB;
-	// per wave: profile of its 64 columns for both halves [2][22][64] int16; then the exchange slots and the record ring
-	int16_t *lds_prof = (int16_t*)wp.lds;
-	constexpr int RING = NW <= 4 ? 64 : 128;                     // rows of records in LDS: the last wave runs 3 (NW - 1) rows behind the first
-	uint32_t *xY = (uint32_t*)(lds_prof + NW * 2 * 22 * 64);      // [2 step parities][3 rows][NW] carry of the I scan
-	uint32_t *xH = xY + 6 * NW;                                  // [2 step parities][3 rows][NW] H of the block's last column
-	uint2 *ring = (uint2*)(xH + 6 * NW);                         // [RING rows] {record of half 0, record of half 1}
-	constexpr int KS = 2 * NW + 1;                               // dwords per row of the key ring (odd: the flush reads it row-parallel)
-	uint32_t *kring = (uint32_t*)(ring + RING);                  // [128 rows][NW][2 halves] per-row, per-block keys (see keys())
-	constexpr int XIN = 96;                                      // rows of incoming boundary values kept in LDS (two fetches of 48)
-	uint2 *xin = (uint2*)(kring + 128 * KS);                     // [XIN] {carry, H} from the workgroup to the left (SPLIT only; 128 KS is even)
-	const int lane = wp.lane, w = wp.w;                          // w: wave index inside the group, scalar
+	// per wave: profile of its 64 columns for both halves [2][64 columns][23] int16; then the record ring, the exchange slots
+	// [2 step parities][NW waves][3 rows] of {scan, H of the wave's last column}, 24 bytes of -inf, the dump area, the incoming
+	// boundary ring and the key ring
+	char *lds_prof = wp.lds;
+	constexpr int RING = EXT_WIDE_RING, XIN = EXT_WIDE_XIN;
+	uint4 *ring = (uint4*)(lds_prof + NW * 2 * 64 * PROF_COL_STRIDE);  // [RING + 1] decoded records of both halves
+	uint2 *xch = (uint2*)(ring + RING + 1);                          // [2][16] slots: parity * 16 + 3 w + k
+	uint2 *xneg = xch + 32;                                          // [4] {-inf, -inf}
+	uint2 *xdump = xneg + 4;                                         // [64 + 4]
+	uint2 *xin = xdump + 68;                                         // [XIN] {carry, H} from the workgroup to the left (SPLIT only)
+	uint32_t *kring = (uint32_t*)(xin + XIN);                        // [NW][96 rows][2 halves] per-row, per-block keys (see keys()): row r at (r - 2) % 96
+	const int lane = wp.lane, w = wp.w;                              // w: wave index inside the group, scalar
 	// SPLIT: which column block this workgroup sweeps is decided when it STARTS -- the k-th workgroup of the group to start takes
 	// block k -- not by its position in the grid: the workgroup it will wait for (block k - 1) is then certain to be running
 	// already, whatever order the dispatcher hands workgroups to the XCDs in and whatever else competes for the CUs, so the
@@ -1257,22 +1296,32 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 			nl[h] = t->nl, al[h] = t->al, ncol[h] = t->ncol, roff[h] = (uint32_t)(t->rec_off - wvp->rec_base);
 		} else nl[h] = 0, al[h] = 1, ncol[h] = 0, roff[h] = 0;
 	}
-	// profile columns of this wave
+	// profile columns of this wave: global [22][pw] int16 -> LDS [column][amino acid]
 	for (int h = 0; h < 2; ++h) {
-		if (tid[h] < 0) continue;
+		char *dst = lds_prof + (size_t)(w * 2 + h) * 64 * PROF_COL_STRIDE;
+		if (tid[h] < 0) {   // (an empty half scores zero everywhere; its keys are never read)
+			for (int k = lane; k < 64 * PROF_COL_STRIDE / 2; k += 64) ((uint16_t*)dst)[k] = 0;
+			continue;
+		}
 		const DTask *t = &a.tasks[tid[h]];
 		const int16_t *src = a.prof + t->prof_off;
 		for (int k = lane; k < 22 * 64; k += 64) {
 			const int aidx = k >> 6, cc = k & 63, gcc = gw * 64 + cc;
-			lds_prof[(w * 2 + h) * 22 * 64 + k] = gcc < t->pw ? src[aidx * t->pw + gcc] : (int16_t)NEG16;
+			*(int16_t*)(dst + cc * PROF_COL_STRIDE + aidx * PROF_AA_STRIDE) = gcc < t->pw ? src[aidx * t->pw + gcc] : (int16_t)NEG16;
 		}
 	}
-	if (wp.tg < 12 * NW) xY[wp.tg] = NEGP;                       // xY and xH are contiguous (NW * 64 threads >= 12 NW)
-	// record ring, filled by the leading wave: rows [0,32) now, then 16 rows at a time (see k_ext)
-	const bool loader = w == 0 && lane < 16;
+	if (wp.tg < 36) xch[wp.tg] = make_uint2(NEGP, NEGP);           // the exchange slots and, behind them, the slots of -inf
+	// record ring, filled by the leading wave: row r in slot (r + 44) % 48, so that the record two rows ahead of row i is in slot
+	// (i - 2) % 48; rows [0, 16) now, rows [16, 28) wait in `pf`; at every twelfth row the lanes < 12 publish `pf` and request the
+	// twelve rows after it (ext_narrow's scheme; the last wave runs 3 (NW - 1) rows behind the first)
+	const bool loader = w == 0 && lane < 12;
 	uint2 pf = make_uint2(0, 0);
-	if (w == 0 && lane < 32) ring[lane] = make_uint2(recbase[roff[0] + lane], recbase[roff[1] + lane]);
-	if (loader) pf = make_uint2(recbase[roff[0] + 32 + lane], recbase[roff[1] + 32 + lane]);
+	if (w == 0 && lane < 16) {
+		const uint4 e = ring_entry(recbase[roff[0] + lane], recbase[roff[1] + lane]);
+		ring[lane < 4 ? lane + 44 : lane - 4] = e;
+		if (lane == 4) ring[RING] = e;
+	}
+	if (loader) pf = make_uint2(recbase[roff[0] + 16 + lane], recbase[roff[1] + 16 + lane]);
 	__syncthreads();
 
 	const int gc = gw * 64 + lane;
@@ -1280,24 +1329,33 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 	const uint32_t ebv = pack16(gc == al[0] - 1 ? c.end_bonus : 0, gc == al[1] - 1 ? c.end_bonus : 0);
 	// live halves keep their value, dead halves read as -32768 in the row maximum
 	const uint32_t keepP = (gc < ncol[0] ? 0xffffu : 0u) | (gc < ncol[1] ? 0xffff0000u : 0u);
-	const uint32_t deadP = (gc < ncol[0] ? 0u : 0x8000u) | (gc < ncol[1] ? 0u : 0x80000000u);
-	const uint32_t goP = splat16(c.go), fsP = splat16(c.fs);
+	const uint32_t flipP = ((gc < ncol[0] ? 0u : 0x8000u) | (gc < ncol[1] ? 0u : 0x80000000u)) ^ 0x80008000u;   // (key order: value + 32768, dead halves 0)
+	const uint32_t goP = __builtin_amdgcn_readfirstlane(splat16(c.go)), fsP = __builtin_amdgcn_readfirstlane(splat16(c.fs));
 	const uint32_t ioP = pack16(tid[0] >= 0 ? a.tasks[tid[0]].io : 0, tid[1] >= 0 ? a.tasks[tid[1]].io : 0);
-	const char *ldsb = (const char*)(lds_prof + (w * 2) * 22 * 64) + lane * 2;
+	const uint32_t sel_lo = __builtin_amdgcn_readfirstlane(0x05040100u);
+	// absolute LDS addresses: this lane's two profile columns; the exchange slot it reads / writes in a step of parity 0
+	const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)wp.lds;
+	const uint32_t pb0 = lds0 + (uint32_t)(((w * 2 + 0) * 64 + lane) * PROF_COL_STRIDE), pb1 = pb0 + 64 * PROF_COL_STRIDE;
+	const uint32_t xch0 = lds0 + (uint32_t)((char*)xch - wp.lds), xneg0 = lds0 + (uint32_t)((char*)xneg - wp.lds),
+	               xdump0 = lds0 + (uint32_t)((char*)xdump - wp.lds), xin0 = lds0 + (uint32_t)((char*)xin - wp.lds);
+	const uint32_t xwr_even = lane == 63 ? xch0 + (uint32_t)(3 * w) * 8 : xdump0 + (uint32_t)lane * 8;
+	const uint32_t xwr_flip = lane == 63 ? 128u : 0u;              // (the other parity's slots: + 16 slots)
+	const bool takes_left = lane == 0 && (w > 0 || has_left);
 
-	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], A = NEGP, B = NEGP, C = NEGP;
+	uint32_t Hr[3], Hs[3], Dr[3], dn[3], ac[3], M[3], A = NEGP, B = NEGP, C = NEGP;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = NEGP;
+	for (int k = 0; k < 3; ++k) Hr[k] = Hs[k] = Dr[k] = M[k] = NEGP;
+	uint32_t k0 = NEGP, k1 = NEGP, k2 = NEGP, k3 = NEGP, ke = NEGP;    // fill registers of the asm rows' scan: only ever written by DPP moves
 	if (gw == 0 && lane == 0) Hs[2] = 0u, Hs[1] = splat16(-c.fs), Hs[0] = splat16(-c.fs);
 	{
-		const uint2 q0 = ring[0], q1 = ring[1];
-		dn[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0a050801u), dn[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0a050801u);
-		ac[1] = __builtin_amdgcn_perm(q0.y, q0.x, 0x0b070903u), ac[0] = __builtin_amdgcn_perm(q1.y, q1.x, 0x0b070903u);
-		dn[2] = ac[2] = 0;
+		const uint4 q0 = ring[44], q1 = ring[45];
+		dn[1] = q0.x, dn[0] = q1.x, ac[1] = q0.y, ac[0] = q1.y, dn[2] = ac[2] = 0;
 	}
 	const int32_t max_nl = wvp->max_nl;
-	uint2 rpre = ring[2], rnxt = ring[3];
-	uint32_t Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 64), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 64));
+	uint4 rcur = ring[46], rnext = ring[47];                           // records of rows i and i + 1
+	uint32_t S = prof2s(pb0 + (rcur.w & 0xffff), pb1 + (rcur.w >> 16));   // profile scores of row i (generic rows)
+	bool have_hD = false;                                              // hD already holds row i's max(diagonal, D) (behind the asm rows)
+	uint32_t hD = NEGP;
 
 	uint32_t hxv[3];
 	// Per-row key of this block: the best (H + end bonus) and its column, ties to the smallest column, per half, as
@@ -1307,20 +1365,20 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 	// per-row keys the replay below consumes.  (Global atomics per row and wave, or assembling the key with scalar code in
 	// the row loop, each cost a quarter of this kernel's time.)
 	const uint32_t lane_tag = 63u - (uint32_t)lane;
-	auto keys = [&](int32_t i, int n_rows) {
-		uint32_t k0[3], k1[3];
+	auto keys = [&](const int r96, int n_rows) {                       // r96 = (i - 2) % 96, a multiple of 3: the step's rows are consecutive ring rows
+		uint32_t k0_[3], k1_[3];
 #pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			k0[k] = (((hxv[k] & 0xffffu) ^ 0x8000u) << 6) | lane_tag;
-			k1[k] = (((hxv[k] >> 16) ^ 0x8000u) << 6) | lane_tag;
+		for (int k = 0; k < 3; ++k) {                                      // (hxv holds the values with their sign bits flipped already)
+			k0_[k] = ((hxv[k] & 0xffffu) << 6) | lane_tag;
+			k1_[k] = ((hxv[k] >> 16) << 6) | lane_tag;
 		}
-		reduce_max_u32_x6(k0[0], k1[0], k0[1], k1[1], k0[2], k1[2]);
+		reduce_max_u32_x6(k0_[0], k1_[0], k0_[1], k1_[1], k0_[2], k1_[2]);
 		if (lane == 63) {
+			uint32_t *slot = kring + (w * EXT_WIDE_KROWS + r96) * 2;
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {
 				if (k >= n_rows) break;
-				uint32_t *slot = kring + ((i + k) & 127) * KS + 2 * w;
-				slot[0] = k0[k], slot[1] = k1[k];
+				slot[2 * k] = k0_[k], slot[2 * k + 1] = k1_[k];
 			}
 		}
 	};
@@ -1337,35 +1395,54 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 			if (spin > (1 << 22)) { if (lane == 0) *a.err = 1; break; }    // seconds: the producer is gone; give up loudly
 			__builtin_amdgcn_s_sleep(4);
 		}
-		if (want) xin[r % XIN] = make_uint2((uint32_t)gy, (uint32_t)gh);
+		if (want) xin[(r - 2) % XIN] = make_uint2((uint32_t)gy, (uint32_t)gh);   // (a step's three rows never wrap: 96 = 32 steps)
+		wave_sync();
 	};
-	auto row = [&](auto kc, int32_t i, int par) {                  // par: parity of the (three-row) step this row belongs to
-		constexpr int K = decltype(kc)::value;
-		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
-		if (w == 0) {                                                      // ring maintenance by the leading wave
-			if ((i & 15) == 0) {
-				if (i > 2 && loader) pf = make_uint2(recbase[roff[0] + (uint32_t)i + 32 + lane], recbase[roff[1] + (uint32_t)i + 32 + lane]);
-			} else if ((i & 15) == 12) {
-				if (loader) ring[((i + 20) & (RING - 1)) + lane] = pf;       // rows [i+20, i+36): published steps before any wave reads them
+	// the leading wave, every twelfth row (rs = (i - 2) % 48 is 0, 12, 24 or 36): rows [i + 14, i + 26) published, the next 12 requested
+	auto refill = [&](const int32_t i, const int rs) {
+		if (loader) {
+			const uint4 e = ring_entry(pf.x, pf.y);
+			const int at = (rs + 12) % RING + lane;
+			ring[at] = e;
+			if (at == 0) ring[RING] = e;                                       // slot 0 again behind slot 47
+			pf = make_uint2(recbase[roff[0] + (uint32_t)i + 26 + lane], recbase[roff[1] + (uint32_t)i + 26 + lane]);
+		}
+	};
+	// what the wave to the left produced for the three rows of this step -- in the previous step (same workgroup, through LDS) or
+	// some dozens of rows ago (the workgroup to the left, through HBM and the xin ring): lane 0 takes it, the others take -inf
+	v2u cv[3];
+	uint32_t xwr = 0;
+	auto step_begin = [&](const int r96, const int par) {
+		uint32_t at = xneg0;
+		if (takes_left) at = w > 0 ? xch0 + (uint32_t)(((par ^ 1) * 16 + 3 * (w - 1)) * 8) : xin0 + (uint32_t)r96 * 8;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) cv[k] = *(lds_u2p)(uintptr_t)(at + 8 * k);
+		xwr = xwr_even + (par ? xwr_flip : 0u);
+	};
+	// the workgroup to the right reads the step's boundary values from HBM: lanes 0..5 pass on what lane 63 has just put into LDS
+	auto step_end = [&](const int32_t i, const int par, const int n_rows) {
+		if (has_right && w == NW - 1) {
+			wave_sync();
+			if (lane < 2 * n_rows) {
+				const uint32_t v = ((const uint32_t*)(xch + par * 16 + 3 * w))[lane];
+				granule_put(xg_out + 2 * (int64_t)i + lane, v, (uint32_t)(i + (lane >> 1)) + 1);
 			}
 		}
-		const uint2 rcur = rpre;                                           // records of rows i+1 (rnxt) and i+2 are in flight / landed
-		rpre = rnxt;
-		rnxt = ring[(i + 2) & (RING - 1)];
-		dn[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0a050801u);
-		ac[R3] = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0b070903u);
-		const uint32_t gei = __builtin_amdgcn_perm(rcur.y, rcur.x, 0x0c060c02u);
-		const uint32_t S = Spre;                                           // looked up during the previous row
-		Spre = pack16(*(const int16_t*)(ldsb + (int)(rpre.x & 0xff) * 64), *(const int16_t*)(ldsb + 22 * 128 + (int)(rpre.y & 0xff) * 64));
-		// what the wave to the left produced for this same row: in the previous step (same workgroup, through LDS) or some
-		// dozens of rows ago (the workgroup to the left, through HBM and the xin ring)
-		uint32_t carry_in = NEGP, left_h = NEGP;
-		if (w > 0) carry_in = xY[((par ^ 1) * 3 + K) * NW + w - 1], left_h = xH[((par ^ 1) * 3 + K) * NW + w - 1];
-		else if (has_left) { const uint2 v = xin[i % XIN]; carry_in = v.x, left_h = v.y; }
+	};
+	// the generic row (plain C++): the first twelve rows and the last one or two
+	auto row = [&](auto kc, const int32_t i, const int rs) {
+		constexpr int K = decltype(kc)::value;
+		constexpr int R1 = (3 - K) % 3, R2 = (4 - K) % 3, R3 = (5 - K) % 3;
+		const uint32_t Snext = prof2s(pb0 + (rnext.w & 0xffff), pb1 + (rnext.w >> 16));
+		const uint4 rnn = ring[rs + K];                                    // record of row i + 2
+		dn[R3] = rcur.x, ac[R3] = rcur.y;                                  // donor[i+1], acceptor[i]
 		uint32_t h, t, u;
-		h = p_adds(Hs[R3], S);
-		u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
-		t = p_subs(t, gei); Dr[R3] = t; h = p_max(h, t);
+		if (have_hD) h = hD;
+		else {
+			h = p_adds(Hs[R3], S);
+			u = p_subs(Hr[R3], goP); t = p_max(u, Dr[R3]);
+			t = p_subs(t, rcur.z); Dr[R3] = t; h = p_max(h, t);
+		}
 		u = p_subs(Hr[R1], ioP); t = p_subs(u, dn[R2]);
 		t = p_max(t, A); A = t; h = p_max(h, p_subs(t, ac[R3]));
 		u = p_subs(Hs[R1], ioP); t = p_subs(u, dn[R1]);
@@ -1374,22 +1451,15 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 		t = p_max(t, C); C = t; h = p_max(h, p_subs(t, ac[R1]));
 		t = p_max(p_max(Hr[R1], Hr[R2]), p_max(Hs[R1], Hs[R2]));
 		h = p_max(h, p_subs(t, fsP));
-		const uint32_t y = scan_max_pk<64>(p_adds(h, jge));
-		uint32_t ex = shift1<64>(y, NEGP, lane);
-		ex = p_max(ex, carry_in);
+		const uint32_t y = scan_max_pk<64>(p_max(p_adds(h, jge), cv[K].x));   // (the incoming carry through lane 0)
+		const uint32_t ex = shift1<64>(y, cv[K].x, lane);
 		h = p_max(h, p_subs(ex, gojge));
-		const uint32_t hs = shift1<64>(h, left_h, lane);
-		Hr[R3] = h, Hs[R3] = hs;
-		if (lane == 63) {
-			xY[(par * 3 + K) * NW + w] = p_max(carry_in, y), xH[(par * 3 + K) * NW + w] = h;
-			if (has_right && w == NW - 1) {                                  // the workgroup to the right reads these from HBM
-				granule_put(xg_out + 2 * (int64_t)i, p_max(carry_in, y), (uint32_t)i + 1);
-				granule_put(xg_out + 2 * (int64_t)i + 1, h, (uint32_t)i + 1);
-			}
-		}
-		// per-row key input: (H + end bonus), dead columns as -32768; reduced for the three rows of a step together (keys())
-		hxv[K] = (p_adds(h, ebv) & keepP) | deadP;
+		Hr[R3] = h, Hs[R3] = shift1<64>(h, cv[K].y, lane);
+		*(lds_u2p)(uintptr_t)(xwr + 8 * K) = v2u{ y, h };
+		hxv[K] = (p_adds(h, ebv) & keepP) ^ flipP;
 		if (i == 2 && gw == 0 && lane == 0) Hs[R1] = NEGP, Hs[R2] = NEGP;
+		S = Snext;
+		rcur = rnext, rnext = rnn, have_hD = false;
 	};
 
 	// Wave w runs 3 w rows behind wave 0: one barrier per step of three rows (the exchange slots hold three rows), w
@@ -1398,16 +1468,17 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 	{
 		int par = w & 1;
 		int32_t i = 2, flushed = 2;                                        // keys of rows [2, flushed) are in HBM
+		int rs = 0, rs12 = 0, r96 = 0;                                     // (i - 2) % 48, % 12, % 96 at the top of a step
 		auto flush_keys = [&](int32_t upto) {                              // last wave only: rows [flushed, upto), 64 at a time
 			for (; flushed < upto; flushed += 64) {
 				const int32_t r = flushed + lane;
 				if (r < upto) {
-					const uint32_t *slot = kring + (r & 127) * KS;
+					const uint32_t *slot = kring + ((r - 2) % EXT_WIDE_KROWS) * 2;
 					uint32_t b0 = slot[0], b1 = slot[1];
 					int32_t w0 = 0, w1 = 0;
 #pragma unroll
 					for (int ww = 1; ww < NW; ++ww) {                          // best block, ties to the leftmost
-						const uint32_t v0 = slot[2 * ww], v1 = slot[2 * ww + 1];
+						const uint32_t v0 = slot[ww * 2 * EXT_WIDE_KROWS], v1 = slot[ww * 2 * EXT_WIDE_KROWS + 1];
 						if ((v0 >> 6) > (b0 >> 6)) b0 = v0, w0 = ww;
 						if ((v1 >> 6) > (b1 >> 6)) b1 = v1, w1 = ww;
 					}
@@ -1421,23 +1492,69 @@ __device__ __forceinline__ void ext_wide_body(const ExtWideArgs &a, const int gr
 				}
 			}
 		};
-		hxv[0] = hxv[1] = hxv[2] = NEGP;
-		for (; i + 3 <= max_nl; i += 3, par ^= 1) {
-			if (has_left && w == 0 && (i - 2) % 48 == 0) fetch_left(i);
-			row(std::integral_constant<int, 0>(), i, par);
-			row(std::integral_constant<int, 1>(), i + 1, par);
-			row(std::integral_constant<int, 2>(), i + 2, par);
-			keys(i, 3);
+		auto advance = [&]() { i += 3, par ^= 1, rs = rs == RING - 3 ? 0 : rs + 3, rs12 = rs12 == 9 ? 0 : rs12 + 3, r96 = r96 == EXT_WIDE_KROWS - 3 ? 0 : r96 + 3; };
+		// a step of compiled rows (1..3 of them): rows [2, 14) -- the virtual column -1 of rows 2 and 3 lives there --, and what the
+		// blocks of asm rows leave over at the end
+		auto generic_step = [&](const int n_rows) {
+			if (has_left && w == 0 && rs == 0) fetch_left(i);
+			if (w == 0 && rs12 == 0) refill(i, rs);
+			step_begin(r96, par);
+			row(std::integral_constant<int, 0>(), i, rs);
+			if (n_rows > 1) row(std::integral_constant<int, 1>(), i + 1, rs);
+			if (n_rows > 2) row(std::integral_constant<int, 2>(), i + 2, rs);
+			keys(r96, n_rows);
+			step_end(i, par, n_rows);
 			if (w == NW - 1 && i + 3 - flushed >= 64) flush_keys(flushed + 64);
 			lds_barrier();
+			advance();
+		};
+		hxv[0] = hxv[1] = hxv[2] = NEGP;
+		while (i < 14 && i + 3 <= max_nl) generic_step(3);
+		// ---- the asm rows, in blocks of four steps (i = 2 + 12 k: the record ring is refilled, the boundary values are fetched and
+		// the keys are flushed at block starts only)
+		if (i + 12 <= max_nl) {
+			uint32_t tA_, tB_, tC_, h, x, hDn, a0, a1;
+			v2s sraw0, sraw1;                                              // (.x = a profile score; .y is never set: v_perm_b32 takes the low halves)
+			M[0] = p_max(Hr[0], Hs[0]), M[1] = p_max(Hr[1], Hs[1]);
+			{                                                              // row i's diagonal term and D state (slot R3 = 2)
+				const uint32_t u = p_subs(Hr[2], goP), t = p_max(u, Dr[2]);
+				Dr[2] = p_subs(t, rcur.z);
+				hD = p_max(p_adds(Hs[2], S), Dr[2]);
+			}
+			sraw0.x = *(lds_s16p)(uintptr_t)(pb0 + (rnext.w & 0xffff)), sraw1.x = *(lds_s16p)(uintptr_t)(pb1 + (rnext.w >> 16));
+			uint4 rnn = ring[rs];                                          // record of row i + 2; from here on fetched a row before it is needed
+			do {
+				if (has_left && w == 0 && rs == 0) fetch_left(i);
+				if (w == 0) refill(i, rs);
+				if (w == NW - 1 && i - flushed >= 64) flush_keys(flushed + 64);
+				const uint4 *rb = ring + rs;
+#pragma unroll 1
+				for (int st = 0; st < 4; ++st, rb += 3) {
+					step_begin(r96, par);
+#define MPA_WIDE_ROW(K, R1, R2, R3) { \
+					MPA_ROW_HEAD(Hr[R1], Hs[R1], dn[R1], dn[R2], rcur.x, ac[R1], ac[R2], rcur.y, M[R1], M[R2]); \
+					dn[R3] = rcur.x, ac[R3] = rcur.y; \
+					MPA_ROW_TAIL_W(Hr[R2], Hs[R2], Dr[R2], Hs[R3], M[R3], cv[K].x, cv[K].y); \
+					{ v2s f0, f1; f0.x = *(lds_s16p)(uintptr_t)a0, f1.x = *(lds_s16p)(uintptr_t)a1; sraw0 = f0, sraw1 = f1; } \
+					rcur = rnext, rnext = rnn, rnn = rb[K + 1]; \
+					Hr[R3] = h, hD = hDn; \
+					*(lds_u2p)(uintptr_t)(xwr + 8 * K) = v2u{ x, h }; \
+					hxv[K] = (p_adds(h, ebv) & keepP) ^ flipP; }
+					MPA_WIDE_ROW(0, 0, 1, 2)
+					MPA_WIDE_ROW(1, 2, 0, 1)
+					MPA_WIDE_ROW(2, 1, 2, 0)
+#undef MPA_WIDE_ROW
+					keys(r96, 3);
+					step_end(i, par, 3);
+					lds_barrier();
+					i += 3, par ^= 1, r96 += 3;
+				}
+				rs = rs == RING - 12 ? 0 : rs + 12, r96 = r96 == EXT_WIDE_KROWS ? 0 : r96;
+			} while (i + 12 <= max_nl);
+			have_hD = true;
 		}
-		if (i < max_nl) {                                                  // one or two rows left
-			if (has_left && w == 0 && (i - 2) % 48 == 0) fetch_left(i);
-			row(std::integral_constant<int, 0>(), i, par);
-			if (i + 1 < max_nl) row(std::integral_constant<int, 1>(), i + 1, par);
-			keys(i, max_nl - i);
-			lds_barrier();
-		}
+		while (i + 3 <= max_nl) generic_step(3);
+		if (i < max_nl) generic_step(max_nl - i);
 		if (w == NW - 1) flush_keys(max_nl);
 	}
 	for (int k = w; k < NW - 1; ++k) lds_barrier();

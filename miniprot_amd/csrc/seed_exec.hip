@@ -318,6 +318,9 @@ struct CoopWave {
 __global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)
 {
 	__shared__ uint32_t hist[1280];
+#ifdef MPA_EXTRACT_PRIO
+	__builtin_amdgcn_s_setprio(MPA_EXTRACT_PRIO);     // (experiment: a serial, latency-bound wave next to the DP round's prioritised waves)
+#endif
 	const int32_t q = blockIdx.x;
 	if (q >= n_prob) return;
 	const int64_t off = x.first[q];
@@ -386,6 +389,9 @@ __global__ __launch_bounds__(64) void k_chain_fwd_wave(const uint64_t *a, const 
 {
 	const unsigned int nr = *n_runs < cap ? *n_runs : cap;
 	const int lane = (int)(threadIdx.x & 63);
+#ifdef MPA_EXTRACT_PRIO
+	__builtin_amdgcn_s_setprio(MPA_EXTRACT_PRIO);
+#endif
 	for (unsigned int r = blockIdx.x; r < nr; r += gridDim.x) {
 	const LongRun run = runs[r];
 	const int64_t q0 = run.q0;
