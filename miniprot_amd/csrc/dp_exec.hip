@@ -800,7 +800,7 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 		return MPA_OK;
 	};
 	if ((rc = prof_begin())) return rc;
-	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), EXTRACT_LDS_BYTES, s, xa, n_query);
 	HIP_TRY(hipGetLastError());
 	if ((rc = prof_end("pre-chain"))) return rc;
 	// the main chain over the survivors: forward pass ...
@@ -822,7 +822,7 @@ static int dev_chains_on_device(mpa_ctx_t *ctx, int32_t n_query, int64_t m, int6
 	xa.a_out = (uint64_t*)(X + o_out_a), xa.u_out = (uint64_t*)(X + o_out_u), xa.n_a = (int64_t*)(X + o_na), xa.n_u = (int64_t*)(X + o_nu);
 	xa.p = mainp, xa.set_only = 0;
 	if ((rc = prof_begin())) return rc;
-	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), 0, s, xa, n_query);
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_query), dim3(64), EXTRACT_LDS_BYTES, s, xa, n_query);
 	if ((rc = prof_end("main chain"))) return rc;
 	hipLaunchKernelGGL(k_offsets2, dim3(1), dim3(256), 0, s, (const int64_t*)(X + o_na), (const int64_t*)(X + o_nu), n_query, (int64_t*)(X + o_offa), (int64_t*)(X + o_offu));
 	HIP_TRY(hipGetLastError());
@@ -1327,7 +1327,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	xa.kept = (uint8_t*)(X + x_kept), xa.stack = (SortRange*)(X + x_stack);
 	xa.a_out = (uint64_t*)(X + x_outa), xa.u_out = (uint64_t*)(X + x_outu), xa.n_a = (int64_t*)(X + x_na), xa.n_u = (int64_t*)(X + x_nu);
 	xa.status = (int32_t*)(X + x_status), xa.p = cp, xa.set_only = 0;
-	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_win), dim3(64), 0, s, xa, (int32_t)n_win);
+	hipLaunchKernelGGL(k_chain_extract, dim3((unsigned)n_win), dim3(64), EXTRACT_LDS_BYTES, s, xa, (int32_t)n_win);
 	hipLaunchKernelGGL(k_offsets2, dim3(1), dim3(256), 0, s, (const int64_t*)(X + x_na), (const int64_t*)(X + x_nu), (int32_t)n_win, (int64_t*)(X + x_offa), (int64_t*)(X + x_offu));
 	HIP_TRY(hipGetLastError());
 	const size_t offb = (NW + 1) * 8;

@@ -259,11 +259,16 @@ __device__ long long *g_extract_prof = nullptr;
 __device__ int g_extract_prof_n = 0;         // problems the buffer has room for (launches of other contexts may have more)
 
 // the team's fast scratch memory: 8 KB of LDS per wavefront (k_chain_extract is one wavefront per workgroup)
+#ifndef EXTRACT_STAGE_WORDS
 #define EXTRACT_STAGE_WORDS 1024
+#endif
+// (DYNAMIC LDS: with a static array the compiler knows that LDS allows three waves per SIMD and lets the registers grow to 512 / 3 --
+// 166 VGPRs, a wave that fits next to no DP workgroup's waves; with the size hidden, amdgpu_waves_per_eu below is what it allocates for)
+#define EXTRACT_LDS_BYTES (EXTRACT_STAGE_WORDS * 8 + 1280 * 4)
 __device__ __forceinline__ uint64_t *g_extract_stage()
 {
-	__shared__ uint64_t stage[EXTRACT_STAGE_WORDS];
-	return stage;
+	extern __shared__ __attribute__((aligned(16))) uint64_t mpa_extract_lds[];
+	return mpa_extract_lds;
 }
 
 // the team of chain_core.h on the device: the 64 lanes of one wavefront
@@ -315,12 +320,12 @@ struct CoopWave {
 	static __device__ __forceinline__ void note(int k, int64_t v) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 16 + 8 + k] = (long long)v; }
 };
 
-__global__ __launch_bounds__(64) void k_chain_extract(ExtractArgs x, int32_t n_prob)
-{
-	__shared__ uint32_t hist[1280];
-#ifdef MPA_EXTRACT_PRIO
-	__builtin_amdgcn_s_setprio(MPA_EXTRACT_PRIO);     // (experiment: a serial, latency-bound wave next to the DP round's prioritised waves)
+#ifndef MPA_EXTRACT_WAVES
+#define MPA_EXTRACT_WAVES 4
 #endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPA_EXTRACT_WAVES))) void k_chain_extract(ExtractArgs x, int32_t n_prob)
+{
+	uint32_t *hist = (uint32_t*)(g_extract_stage() + EXTRACT_STAGE_WORDS);   // [1280]
 	const int32_t q = blockIdx.x;
 	if (q >= n_prob) return;
 	const int64_t off = x.first[q];
@@ -389,9 +394,6 @@ __global__ __launch_bounds__(64) void k_chain_fwd_wave(const uint64_t *a, const 
 {
 	const unsigned int nr = *n_runs < cap ? *n_runs : cap;
 	const int lane = (int)(threadIdx.x & 63);
-#ifdef MPA_EXTRACT_PRIO
-	__builtin_amdgcn_s_setprio(MPA_EXTRACT_PRIO);
-#endif
 	for (unsigned int r = blockIdx.x; r < nr; r += gridDim.x) {
 	const LongRun run = runs[r];
 	const int64_t q0 = run.q0;
