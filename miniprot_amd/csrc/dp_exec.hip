@@ -2107,7 +2107,16 @@ static int mpa_dp_run_impl(mpa_ctx_t *ctx, const mpa_idx_t *mi, const mpa_dpopt_
 		wk.lite = ctx->lite.as<uint32_t>(), wk.ckpt = ctx->ckpt.as<uint32_t>(), wk.cig = ctx->cig.as<uint32_t>(), wk.n_cigar = ctx->ncig.as<int32_t>();
 		wk.n_blocks = (unsigned long long*)((char*)ctx->wlist.p + ((n_lite * 4 + 63) & ~(size_t)63));
 		HIP_TRY(hipMemsetAsync(wk.n_blocks, 0, 8, s));
-		hipLaunchKernelGGL(k_walk, dim3((unsigned)n_lite), dim3(64), WALK_LDS, s, wk);
+		// (the list is sorted by class: one launch per class, with the LDS that class's block of direction words needs)
+		size_t at = 0;
+		for (int cls = 0; cls < 4; ++cls) {
+			size_t n_c = 0;
+			while (at + n_c < n_lite && T[glob_ids[n_reg_glob + at + n_c]].pad_ == 8 + cls) ++n_c;
+			if (n_c == 0) continue;
+			wk.list = ctx->wlist.as<int32_t>() + at, wk.n_list = (int32_t)n_c;
+			hipLaunchKernelGGL(k_walk, dim3((unsigned)n_c), dim3(64), cls == 0 ? WALK_LDS(16) : cls == 1 ? WALK_LDS(32) : cls == 2 ? WALK_LDS(64) : WALK_LDS(128), s, wk);
+			at += n_c;
+		}
 		HIP_TRY(hipGetLastError());
 		ctx->stats.launches_glob++;
 	}

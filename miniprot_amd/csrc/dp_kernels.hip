@@ -2443,7 +2443,9 @@ struct WalkArgs {
 	int32_t *n_cigar;
 	unsigned long long *n_blocks; // (statistics) blocks recomputed
 };
-#define WALK_LDS (GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 128 * 2 + (size_t)(MPA_TB_BLOCK + 2) * 16)
+// (per class of the packed sweep -- 16 / 32 / 64 / 128 columns at most: 8 / 11 / 17 / 29 KB; one launch per class, so that the narrow calls'
+// walks, most of them, take LDS for their own block of direction words and not for a 128-column one)
+#define WALK_LDS(NC) (GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * (NC) * 2 + (size_t)(MPA_TB_BLOCK + 2) * 16)
 // DUAL: a call of 65..128 columns, swept with column c + 64 in the high half of lane c (ext_narrow<64, true, true>) and recomputed
 // by the block-major traceback sweep (two blocks of 64 columns, boundary records in LDS)
 template<int G, bool DUAL = false>
@@ -2453,7 +2455,7 @@ __device__ __forceinline__ void walk_call(const WalkArgs &wa, const DTask &t, co
 	const int slot = DUAL ? 0 : (t.flag >> MPA_LITE_SLOT_SHIFT) & 15, half = slot / NG, lane0 = (slot % NG) * G;
 	const uint32_t *lite = wa.lite + t.tb_off + lane0;
 	uint16_t *tbs = (uint16_t*)(lds + GLOB_NARROW_LDS);            // [MPA_TB_BLOCK][ncol] words of the block that is materialised
-	int4 *bnds = (int4*)(lds + GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * 128 * 2);
+	int4 *bnds = (int4*)(lds + GLOB_NARROW_LDS + (size_t)MPA_TB_BLOCK * (DUAL ? 128 : G) * 2);
 	uint32_t *cig = wa.cig + t.cig_off;
 	const int32_t ncol = t.ncol, cap = t.cig_cap;
 	int32_t blk = -1, blk_lo = 0, blk_hi = 0;                      // the materialised block and its rows [blk_lo, blk_hi)

@@ -258,9 +258,13 @@ struct ExtractArgs {
 __device__ long long *g_extract_prof = nullptr;
 __device__ int g_extract_prof_n = 0;         // problems the buffer has room for (launches of other contexts may have more)
 
-// the team's fast scratch memory: 8 KB of LDS per wavefront (k_chain_extract is one wavefront per workgroup)
+// the team's fast scratch memory: 2 KB of LDS per wavefront (k_chain_extract is one wavefront per workgroup).  Round 6: 8 KB -> 2 KB.
+// With the 5 KB of digit tables a wave then takes 7.2 KB, so that LDS allows the five waves per SIMD the 85 VGPRs do (8 KB: three), all
+// 4 000 problems of a launch are resident at once and a wave's footprint next to the DP round's workgroups is half of what it was:
+// lone launch 11.9 -> 10.6 ms, stream +5 % (3 of 3 interleaved repeats; 512 words: the same; profiles/r06_experiments.txt).  Buckets
+// that do not fit are walked in place, as before.
 #ifndef EXTRACT_STAGE_WORDS
-#define EXTRACT_STAGE_WORDS 1024
+#define EXTRACT_STAGE_WORDS 256
 #endif
 // (DYNAMIC LDS: with a static array the compiler knows that LDS allows three waves per SIMD and lets the registers grow to 512 / 3 --
 // 166 VGPRs, a wave that fits next to no DP workgroup's waves; with the size hidden, amdgpu_waves_per_eu below is what it allocates for)
