@@ -41,6 +41,8 @@ if has nsrow; then
   { echo "# saturated launches, narrow extension, 32 columns x 4000 rows: 12288 calls = 3 waves per SIMD (default: 3 workgroups per CU), 16384 calls = 4 waves per SIMD (MPA_DP_WG_PER_CU=4)";
     python tools/time_wide.py 32 4000 12288 4 | tail -1; MPA_DP_WG_PER_CU=4 python tools/time_wide.py 32 4000 16384 4 | tail -1;
     python tools/time_wide.py 64 4000 6144 4 | tail -1; MPA_DP_WG_PER_CU=4 python tools/time_wide.py 64 4000 8192 4 | tail -1; } >> $OUT/dp_ns_per_row.txt 2>&1
+  { echo "# wide extension classes (ext_wide_body), 20 000 rows, one pair of calls: 200 columns = one workgroup, 500 = two, 1000 = four; then 256 pairs of 1000 columns x 4000 rows";
+    for al in 200 500 1000; do python tools/time_wide.py $al 20000 2 4 | tail -1; done; python tools/time_wide.py 1000 4000 256 4 | tail -1; } >> $OUT/dp_ns_per_row.txt 2>&1
   cat $OUT/dp_ns_per_row.txt
   python tools/lite_check.py 2>&1 | head -1 > $OUT/checkpointed_traceback_blocks.txt; cat $OUT/checkpointed_traceback_blocks.txt
 fi
