@@ -31,8 +31,9 @@ template<int VG> __global__ __launch_bounds__(256) void k_long(uint32_t *out, lo
 	if (s == 0x12345) out[threadIdx.x] = s;
 }
 
-__global__ __launch_bounds__(64) void k_chase(const uint32_t *arr, uint32_t mask, uint32_t *out, int steps)
+__global__ __launch_bounds__(64) void k_chase(const uint32_t *arr, uint32_t mask, uint32_t *out, int steps, int prio)
 {
+	if (prio) __builtin_amdgcn_s_setprio(3);                   // (B above A in the SIMD's issue arbitration)
 	uint32_t p = (blockIdx.x * 2654435761u + threadIdx.x * 40503u) & mask;
 	uint32_t acc = 0, y[56];                                   // 56 + bookkeeping = 64 VGPRs allocated, like the seeding kernels
 #pragma unroll
@@ -43,12 +44,13 @@ __global__ __launch_bounds__(64) void k_chase(const uint32_t *arr, uint32_t mask
 	if (acc == 0x12345) out[threadIdx.x] = acc;
 }
 
+static int g_b_prio = 0;
 static float time_b(hipStream_t sb, const uint32_t *arr, uint32_t mask, uint32_t *out, int n_waves)
 {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0), hipEventCreate(&e1);
 	hipEventRecord(e0, sb);
-	k_chase<<<n_waves, 64, 0, sb>>>(arr, mask, out, 8);
+	k_chase<<<n_waves, 64, 0, sb>>>(arr, mask, out, 8, g_b_prio);
 	hipEventRecord(e1, sb);
 	hipEventSynchronize(e1);
 	float ms;
@@ -98,6 +100,13 @@ int main()
 	run<124>("A: 124 VGPRs, 33 KB LDS, 4 workgroups per CU", 33024, 4, sa, sb, arr, mask, out, n_waves, alone);
 	run<124>("A: 124 VGPRs, 41 KB LDS, 2 workgroups per CU", 41216, 2, sa, sb, arr, mask, out, n_waves, alone);
 	run<124>("A: 124 VGPRs, 41 KB LDS, 1 workgroup per CU", 41216, 1, sa, sb, arr, mask, out, n_waves, alone);
+	run<64>("A: 64 VGPRs, 33 KB LDS, 4 workgroups per CU", 33024, 4, sa, sb, arr, mask, out, n_waves, alone);
+	// the same with B's waves at s_setprio 3: if B now runs next to A, what held it back was the SIMD's issue arbitration (A's waves are
+	// older and each of them can issue a packed add every ~5 cycles: three or four per SIMD leave no slot), not a resource
+	g_b_prio = 1;
+	printf("# B at s_setprio 3\n");
+	run<124>("A: 124 VGPRs, 41 KB LDS, 3 workgroups per CU", 41216, 3, sa, sb, arr, mask, out, n_waves, alone);
+	run<124>("A: 124 VGPRs, 41 KB LDS, 2 workgroups per CU", 41216, 2, sa, sb, arr, mask, out, n_waves, alone);
 	run<64>("A: 64 VGPRs, 33 KB LDS, 4 workgroups per CU", 33024, 4, sa, sb, arr, mask, out, n_waves, alone);
 	return 0;
 }
