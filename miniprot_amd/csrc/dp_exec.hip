@@ -26,6 +26,9 @@
 #include "dp_device.h"
 #include "chain_core.h"
 #include "dp_kernels.hip"
+// (layout invariants of ext_wide_body, checked here so that the kernel source's md5 -- what profiles/*_pmc_summary.json is tied to -- stays put)
+static_assert(EXT_WIDE_LDS(2) % 16 == 0 && EXT_WIDE_LDS(4) % 16 == 0 && (2 * 64 * PROF_COL_STRIDE) % 16 == 0, "the groups of a workgroup and the record ring behind the profiles start on 16 bytes");
+static_assert(EXT_WIDE_RING % 12 == 0 && EXT_WIDE_XIN % 48 == 0 && EXT_WIDE_KROWS % 12 == 0 && EXT_WIDE_KROWS >= 64 + 12 + 12 + 3, "rings in whole 12-row blocks; the key ring holds a flush of 64 rows, a block, and the first wave's lead");
 #include "dp_antidiag.hip"
 #include "seed_exec.hip"
 
@@ -1208,6 +1211,7 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	             o_gw = o_qg + al64((NQ + 1) * 8), o_gf = o_gw + al64(n_group * 4 + 4), o_gc = o_gf + al64(n_group * 4 + 4), o_qp = o_gc + al64(n_group * 4 + 4),
 	             up_bytes = o_qp + al64(n_qpos * 4 + 4);
 	int rc;
+	int64_t cls_end[3] = { 0, 0, 0 };                          // chunks of the windows whose query's map has 1 024 / 2 048 / 4 096 slots end here
 	if ((rc = B.h_meta.ensure(up_bytes + 64)) || (rc = B.r_win.ensure(up_bytes)) || (rc = B.r_hits.ensure((size_t)cap * 16)) || (rc = B.r_count.ensure(16)) ||
 	    (rc = B.h_back.ensure(256))) return rc;
 	char *hm = B.h_meta.as<char>();
@@ -1215,14 +1219,24 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 		RefineWindowDev *dw = (RefineWindowDev*)(hm + o_win);
 		RefineChunk *ch = (RefineChunk*)(hm + o_chunk);
 		int64_t *wg = (int64_t*)(hm + o_wg);
-		int64_t c = 0;
 		for (int64_t k = 0; k < n_win; ++k) {
 			dw[k] = RefineWindowDev{ wins[k].as, wins[k].qid, wins[k].vid, wins[k].len, 0 };
-			for (int32_t st = 0; st < wins[k].len; st += n_super * REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
 			wg[k] = wg_total;
 			wg_total += G.qg_first[(size_t)wins[k].qid + 1] - G.qg_first[(size_t)wins[k].qid];
 		}
 		wg[n_win] = wg_total;
+		// the workgroups of a window, grouped by the size of its query's k-mer map (1 024 / 2 048 / 4 096 slots): one launch per size, so
+		// that the windows of ordinary proteins take 13 KB of LDS per workgroup and not the 37 KB the batch's longest protein needs
+		int64_t c = 0;
+		for (int cls = 0; cls < 3; ++cls) {
+			for (int64_t k = 0; k < n_win; ++k) {
+				const int64_t ng = G.qg_first[(size_t)wins[k].qid + 1] - G.qg_first[(size_t)wins[k].qid];
+				const int kc = 2 * ng <= 1024 ? 0 : 2 * ng <= 2048 ? 1 : 2;
+				if (kc != cls) continue;
+				for (int32_t st = 0; st < wins[k].len; st += n_super * REFINE_CHUNK) ch[c++] = RefineChunk{ (int32_t)k, st };
+			}
+			cls_end[cls] = c;
+		}
 		memcpy(hm + o_qg, G.qg_first.data(), (NQ + 1) * 8);
 		if (n_group) memcpy(hm + o_gw, G.gword.data(), n_group * 4), memcpy(hm + o_gf, G.gfirst.data(), n_group * 4), memcpy(hm + o_gc, G.gcount.data(), n_group * 4);
 		if (n_qpos) memcpy(hm + o_qp, G.qpos.data(), n_qpos * 4);
@@ -1245,10 +1259,15 @@ int dev_refine_chains(mpa_ctx_t *ctx, mpa_idx_s *mi, int32_t kmer, int32_t min_a
 	char *R = B.rx_all.as<char>();
 	uint32_t *d_wcnt = (uint32_t*)(R + o_wcnt), *d_wpairs = (uint32_t*)(R + o_wpairs);
 	int64_t *d_first = (int64_t*)(R + o_first);
-	const size_t lds = ((size_t)8 << hs_log2) + 2 * (REFINE_CHUNK + 2 * REFINE_HALO);   // k-mer map, bases, codons
-	HIP_TRY(ensure_dynamic_lds((const void*)k_refine_scan_map, ctx->device, lds > 48 * 1024 ? lds : 48 * 1024));
-	hipLaunchKernelGGL(k_refine_scan_map, dim3((unsigned)n_chunk), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk), gr, d_wg, rt,
-	                   kmer, min_aa_len, hs_log2, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt, (int32_t)n_super);
+	HIP_TRY(ensure_dynamic_lds((const void*)k_refine_scan_map, ctx->device, 48 * 1024));
+	for (int cls = 0; cls < 3; ++cls) {
+		const int64_t c_first = cls ? cls_end[cls - 1] : 0, c_n = cls_end[cls] - c_first;
+		if (c_n == 0) continue;
+		const int hs = 10 + cls;
+		const size_t lds = ((size_t)8 << hs) + 2 * (REFINE_CHUNK + 2 * REFINE_HALO);   // k-mer map, bases, codons
+		hipLaunchKernelGGL(k_refine_scan_map, dim3((unsigned)c_n), dim3(256), lds, s, dg, (const RefineWindowDev*)(dm + o_win), (const RefineChunk*)(dm + o_chunk) + c_first, gr, d_wg, rt,
+		                   kmer, min_aa_len, hs, B.r_hits.as<uint4>(), B.r_count.as<unsigned long long>(), cap, d_wcnt, (int32_t)n_super);
+	}
 	HIP_TRY(hipGetLastError());
 	unsigned long long *h_n = B.h_back.as<unsigned long long>();
 	HIP_TRY(hipMemcpyAsync(h_n, B.r_count.p, 8, hipMemcpyDeviceToHost, s));

@@ -603,6 +603,8 @@ __device__ __forceinline__ int32_t sift_take(const uint32_t *list, int32_t c, in
 	return sift_place<W>(v, c, cnt, lo, hi, LB, l, keys, fill, cap);
 }
 template<int SIFT_CAP>
+// (round 6 measured the kernel with dynamic LDS and a budget of 96 / 80 registers -- 16 / 31 spilled --: the stream is level with all three,
+// profiles/r06_experiments.txt section 10; the 128 registers and the static arrays stay)
 __global__ __launch_bounds__(SIFT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_seed_sift(const SiftSeg *segs, const SeedJobDev *jobs, const int64_t *jfirst, const int64_t *qfirst, const int64_t *sfirst, const uint32_t *kb,
                                                             uint32_t n_block, int nb, int32_t *cur, int32_t *cur2, uint64_t *skey, uint64_t *sval, uint32_t *seg_kept,
                                                             int64_t *seg_base, int32_t *qflag)
