@@ -324,8 +324,12 @@ struct CoopWave {
 	static __device__ __forceinline__ void note(int k, int64_t v) { if (g_extract_prof && (int)blockIdx.x < g_extract_prof_n && lane() == 0) g_extract_prof[(int64_t)blockIdx.x * 16 + 8 + k] = (long long)v; }
 };
 
+// (8 waves per SIMD = a budget of 64 VGPRs: the compiler gets there with 2 spilled registers, where it takes 85 when asked for 4..5 waves and
+// 166 when the LDS is static.  The walk is serial and waits for memory 84 % of its time: it does not miss the registers, and everything
+// that has to share a SIMD with it -- the DP round's waves first of all -- gets them: stream +4..5 % in 9 of 9 interleaved repeats,
+// profiles/r06_experiments.txt section 11)
 #ifndef MPA_EXTRACT_WAVES
-#define MPA_EXTRACT_WAVES 4
+#define MPA_EXTRACT_WAVES 8
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPA_EXTRACT_WAVES))) void k_chain_extract(ExtractArgs x, int32_t n_prob)
 {
