@@ -26,7 +26,7 @@ print("# Static resources of every kernel of libmpamd.so (hipcc --offload-arch=g
 print("# (512 VGPRs per SIMD lane, granule 8, at most 8 waves per SIMD).  Dynamic LDS on top of the static figure: k_dp_round 41 216 B per workgroup")
 print("# (3 per CU, MPA_DP_WG_PER_CU), k_walk 7 968 / 11 040 / 17 184 / 29 472 by class, k_chain_extract 7 168 per wave, k_refine_scan_map 8 << hs_log2 + 4 544")
 print("# (12.7-37 KB), k_seed_sift static only, k_glob_wide / k_ext_huge as launched.  Next to three resident DP waves (384 VGPRs) a SIMD holds one wave of")
-print("# k_seed_sift (128), k_walk or k_chain_extract (88), one of k_refine_scan_map (72).")
+print("# k_seed_sift (128), k_walk (88), two of k_chain_extract (64), one of k_refine_scan_map (72).")
 print("%-34s %5s %5s %9s %7s %6s %6s %s" % ("kernel", "VGPR", "SGPR", "LDS(stat)", "scratch", "spills", "WG", "waves/SIMD by VGPR"))
 for r in sorted(set(rows)):
     print("%-34s %5d %5d %9d %7d %6d %6d %d" % r)
